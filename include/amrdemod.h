@@ -1,0 +1,196 @@
+/*
+ * amrdemod.h -- C ABI of the MI355X (gfx950) implementation of rtlamr's
+ * IQ-to-bits hot path, protocol.Decoder.Decode (reference: protocol/decode.go).
+ *
+ * The reference has no FFI boundary of its own: its boundary is the Go API of
+ * package protocol.  This header is what a cgo binding of that package binds
+ * (INTEGRATION.md shows the Go side).  Each entry point names the reference
+ * interface it replaces (file:line into the rtlamr tree).
+ *
+ * Conventions
+ *   - extern "C", plain pointers and sizes, no C++ or torch types.
+ *   - every function returns an amr_status (0 = ok, negative = error); no
+ *     exception and no Go-style panic crosses the boundary.
+ *   - the library never keeps a caller pointer after the call returns (cgo
+ *     pointer-passing rule); result arrays are owned by the handle and stay
+ *     valid until the next amr_decode_* / amr_reset / amr_destroy on it.
+ *   - one handle = one reference Decoder = one GPU; like the Go Decoder
+ *     (decode.go:163, shared slices) a handle is not re-entrant: one caller
+ *     thread at a time.
+ *
+ * Batch semantics: amr_decode_batch(h, iq, n) is exactly n consecutive calls
+ * Decoder.Decode(iq[k*BlockSize2 : (k+1)*BlockSize2]) (main.go:235), including
+ * the SymbolLength-sample magnitude history and the PacketLength-bit quantized
+ * history the Go decoder carries between calls (decode.go:165-166).
+ */
+#ifndef AMRDEMOD_H
+#define AMRDEMOD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef int amr_status;
+#define AMR_OK 0
+#define AMR_EINVAL (-1)   /* bad argument / illegal chip length / bad preamble */
+#define AMR_ENOMEM (-2)   /* host or device allocation failed */
+#define AMR_EHIP (-3)     /* a HIP runtime call failed; amr_last_error() has the text */
+#define AMR_ENODEV (-4)   /* no usable gfx950 device: the product path has NO CPU fallback */
+#define AMR_EOVERFLOW (-5)/* internal capacity exceeded and could not be grown */
+
+#define AMR_MAX_PREAMBLES 8
+#define AMR_MAX_PREAMBLE_BITS 64
+
+typedef struct amr_handle amr_handle;
+
+/*
+ * The fields of protocol.PacketConfig that Decoder.RegisterProtocol reads from
+ * a parser's Cfg() (decode.go:27-42, 100-128).  One per registered parser.
+ */
+typedef struct amr_protocol {
+    const char *preamble;  /* ASCII '0'/'1', PacketConfig.Preamble */
+    int32_t data_rate;     /* PacketConfig.DataRate (32768 for every rtlamr parser) */
+    int32_t chip_length;   /* PacketConfig.ChipLength = -symbollength flag (main.go:77) */
+    int32_t preamble_symbols;
+    int32_t packet_symbols;
+} amr_protocol;
+
+/* Geometry computed exactly as Decoder.Allocate (decode.go:131-141). */
+typedef struct amr_geometry {
+    int32_t data_rate, chip_length, symbol_length, sample_rate;
+    int32_t preamble_symbols, packet_symbols;  /* field-wise max, decode.go:105-109 */
+    int32_t preamble_length, packet_length;
+    int32_t block_size, block_size2, buffer_length;
+    int32_t n_preambles;   /* distinct preambles = number of Search calls per Decode */
+    int32_t pkt_bytes;     /* (PacketSymbols+7)>>3, decode.go:151 */
+} amr_geometry;
+
+/*
+ * Result of one batch.  Hits are grouped by preamble id (registration order of
+ * first appearance), and inside a preamble sorted by (block, idx) ascending --
+ * the order Decoder.Search returns per call (decode.go:327).
+ *   hit_block[i]  index of the Decode call that reports the hit, counted from
+ *                 the last amr_reset (plus amr_set_block_base)
+ *   hit_idx[i]    Data.Idx, the index into Decoder.Quantized (decode.go:371)
+ *   pkt[i*pkt_bytes .. ]  Data.Bytes as built by Decoder.Slice (decode.go:363-366);
+ *                 when PacketSymbols%8 != 0 the unused high bits of the last
+ *                 byte are zero (Go leaves stale bits there; parsers ignore them).
+ */
+typedef struct amr_result {
+    uint32_t n_preambles;
+    uint32_t pkt_bytes;
+    uint64_t n_hits;
+    const uint64_t *preamble_offset;  /* [n_preambles+1]: hits of preamble p are [off[p], off[p+1]) */
+    const uint64_t *hit_block;        /* [n_hits] */
+    const uint32_t *hit_idx;          /* [n_hits] */
+    const uint8_t *pkt;               /* [n_hits * pkt_bytes] */
+} amr_result;
+
+/* Timing of the last batch, measured with HIP events on the handle's stream. */
+typedef struct amr_timing {
+    float demod_ms;   /* K1: magnitude + csum matched filter + quantize + pack */
+    float search_ms;  /* K2 + scan + K3: preamble search, compaction, slice */
+    float total_ms;   /* first kernel start to last kernel end (device side) */
+} amr_timing;
+
+/* ---- lifecycle -------------------------------------------------------- */
+
+/*
+ * NewDecoder + RegisterProtocol for each entry + Allocate
+ * (decode.go:65, 100-128, 131-160).  chip_length must be one of the values
+ * flags.go:127-132 accepts (8,32,40,...,96) and equal for all entries.
+ * device_id: HIP device ordinal.  Fails with AMR_ENODEV when the device is
+ * missing or is not gfx950.
+ */
+amr_status amr_create(const amr_protocol *protos, int32_t n_protos, int32_t device_id, amr_handle **out);
+amr_status amr_destroy(amr_handle *h);
+
+/* Forget all history: equivalent to a freshly allocated Decoder (decode.go:144-145 zero buffers). */
+amr_status amr_reset(amr_handle *h);
+
+/* PacketConfig read-back (Decoder.Cfg, decode.go:46). */
+amr_status amr_get_geometry(const amr_handle *h, amr_geometry *out);
+/* Preamble id a registered protocol (by registration index) was grouped under (decode.go:124). */
+int32_t amr_preamble_id(const amr_handle *h, int32_t proto_index);
+/* The float32 magnitude table, NewMagLUT (decode.go:209-216): 256 floats. */
+amr_status amr_get_mag_lut(const amr_handle *h, float *out256);
+
+/* Run on a caller-owned HIP stream (hipStream_t passed as void*); NULL = the handle's own stream. */
+amr_status amr_set_stream(amr_handle *h, void *hip_stream);
+/* Add a constant to reported hit_block (multi-GPU: first call index owned by this shard). */
+amr_status amr_set_block_base(amr_handle *h, uint64_t base);
+
+/* ---- the hot path ------------------------------------------------------ */
+
+/*
+ * Decoder.Decode (decode.go:163-197) for n_blocks consecutive blocks held in
+ * HOST memory (n_blocks * BlockSize2 bytes).  Copies the batch to the device,
+ * runs the kernels, returns hits and packets.  Parsers are NOT run here: the
+ * binding hands each preamble's packets to its parsers as decode.go:177-187.
+ * iq_bytes < n_blocks*BlockSize2 is AMR_EINVAL (Go panics at decode.go:222);
+ * extra bytes are ignored, as in Go.
+ */
+amr_status amr_decode_batch(amr_handle *h, const uint8_t *iq, size_t iq_bytes, size_t n_blocks, amr_result *res);
+
+/* Same, input already resident in device memory (hipMalloc'd or a torch tensor's data_ptr). */
+amr_status amr_decode_batch_device(amr_handle *h, const void *d_iq, size_t n_blocks, amr_result *res);
+
+/*
+ * Multi-GPU sharding: feed the ceil(PacketLength/BlockSize)+1
+ * blocks that precede a shard so its magnitude / quantized history equals what
+ * a single decoder would hold, without reporting hits or advancing the block
+ * counter.  halo_iq points at the first warm-up block; lead (may be NULL = zeros)
+ * at the aligned-halo bytes (amr_halo_bytes) that precede it in the stream.
+ */
+amr_status amr_prime(amr_handle *h, const uint8_t *lead, const uint8_t *halo_iq, size_t n_blocks, int on_device);
+size_t amr_halo_bytes(const amr_handle *h);
+size_t amr_prime_blocks(const amr_handle *h);
+
+/* ---- introspection used by the parity tests ---------------------------- */
+
+/*
+ * The new quantized bits of the last batch -- Decoder.Quantized[PacketLength:]
+ * after each call (decode.go:172) -- packed MSB-first as Search packs them
+ * (decode.go:259-265): n_blocks*BlockSize/8 bytes.
+ */
+amr_status amr_copy_quantized(amr_handle *h, uint8_t *out, size_t out_bytes);
+amr_status amr_get_timing(const amr_handle *h, amr_timing *out);
+const char *amr_strerror(amr_status s);
+const char *amr_last_error(void);
+/* Library / device description for logs: "amrdemod <ver> gfx950 <n> CUs ..." */
+amr_status amr_describe(const amr_handle *h, char *buf, size_t buf_bytes);
+
+/* ---- device utilities for bench and tests (not part of the decode path) -- */
+
+amr_status amr_dev_alloc(int32_t device_id, size_t bytes, void **d_ptr);
+amr_status amr_dev_free(int32_t device_id, void *d_ptr);
+amr_status amr_dev_upload(int32_t device_id, void *d_dst, const void *src, size_t bytes);
+amr_status amr_dev_download(int32_t device_id, void *dst, const void *d_src, size_t bytes);
+amr_status amr_dev_sync(int32_t device_id);
+
+/*
+ * Deterministic integer-only synthetic IQ: sample n of the
+ * stream gets h = splitmix64(seed ^ n), I = 119 + popcount(h & 0xFFFF),
+ * Q = 120 + popcount((h >> 16) & 0xFFFF).  first_sample = stream index of d_iq[0].
+ */
+amr_status amr_synth_noise(int32_t device_id, void *d_iq, uint64_t n_samples, uint64_t seed, uint64_t first_sample);
+
+/*
+ * Add Manchester-OOK bursts: packet j starts at stream sample start[j], carries
+ * n_bits bits (bits[j*stride .. ], MSB first inside each byte); bit 1 = chip
+ * high then low, bit 0 = low then high, each chip chip_length samples; "high"
+ * adds (d_i[j], d_q[j]) to (I,Q) with clamping to [0,255].  Packets must not
+ * overlap.  Samples outside [first_sample, first_sample+n_samples) are skipped.
+ */
+amr_status amr_synth_plant(int32_t device_id, void *d_iq, uint64_t n_samples, uint64_t first_sample,
+                           int32_t chip_length, uint32_t n_packets, const uint64_t *start,
+                           const uint8_t *bits, uint32_t n_bits, uint32_t stride,
+                           const int8_t *d_i, const int8_t *d_q);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* AMRDEMOD_H */

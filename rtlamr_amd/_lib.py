@@ -1,0 +1,118 @@
+"""ctypes binding of libamrdemod.so (include/amrdemod.h).  Fails loudly when the library is
+missing or no gfx950 device is present -- there is deliberately no fallback path."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(_HERE, "csrc")
+SO_PATH = os.path.join(CSRC, "libamrdemod.so")
+
+AMR_OK, AMR_EINVAL, AMR_ENOMEM, AMR_EHIP, AMR_ENODEV, AMR_EOVERFLOW = 0, -1, -2, -3, -4, -5
+
+# every symbol include/amrdemod.h declares (checked by tests/test_abi.py)
+SYMBOLS = [
+    "amr_create", "amr_destroy", "amr_reset", "amr_get_geometry", "amr_preamble_id", "amr_get_mag_lut",
+    "amr_set_stream", "amr_set_block_base", "amr_decode_batch", "amr_decode_batch_device", "amr_prime",
+    "amr_halo_bytes", "amr_prime_blocks", "amr_copy_quantized", "amr_get_timing", "amr_strerror",
+    "amr_last_error", "amr_describe", "amr_dev_alloc", "amr_dev_free", "amr_dev_upload", "amr_dev_download",
+    "amr_dev_sync", "amr_synth_noise", "amr_synth_plant",
+]
+
+
+class AmrError(RuntimeError):
+    def __init__(self, status: int, where: str, detail: str = ""):
+        self.status = status
+        super().__init__(f"{where}: status {status} ({detail})")
+
+
+class AmrProtocol(C.Structure):
+    _fields_ = [("preamble", C.c_char_p), ("data_rate", C.c_int32), ("chip_length", C.c_int32),
+                ("preamble_symbols", C.c_int32), ("packet_symbols", C.c_int32)]
+
+
+class AmrGeometry(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in (
+        "data_rate", "chip_length", "symbol_length", "sample_rate", "preamble_symbols", "packet_symbols",
+        "preamble_length", "packet_length", "block_size", "block_size2", "buffer_length", "n_preambles",
+        "pkt_bytes")]
+
+
+class AmrResult(C.Structure):
+    _fields_ = [("n_preambles", C.c_uint32), ("pkt_bytes", C.c_uint32), ("n_hits", C.c_uint64),
+                ("preamble_offset", C.POINTER(C.c_uint64)), ("hit_block", C.POINTER(C.c_uint64)),
+                ("hit_idx", C.POINTER(C.c_uint32)), ("pkt", C.POINTER(C.c_uint8))]
+
+
+class AmrTiming(C.Structure):
+    _fields_ = [("demod_ms", C.c_float), ("search_ms", C.c_float), ("total_ms", C.c_float)]
+
+
+def build(force: bool = False) -> str:
+    """Compile libamrdemod.so in-tree with hipcc for gfx950 (cross-compiles without a GPU)."""
+    srcs = [os.path.join(CSRC, f) for f in ("amrdemod.hip", "k1_demod.h", "k2_search.h", "synth.h")]
+    srcs.append(os.path.join(_HERE, "..", "include", "amrdemod.h"))
+    stale = (not os.path.exists(SO_PATH)) or any(os.path.getmtime(s) > os.path.getmtime(SO_PATH) for s in srcs)
+    if force or stale:
+        subprocess.check_call(["make", "-C", CSRC, "-s", "libamrdemod.so"] + (["-B"] if force else []))
+    return SO_PATH
+
+
+_lib = None
+
+
+def lib() -> C.CDLL:
+    """Load the library (no GPU needed to load; amr_create is what needs the device)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(SO_PATH):
+        raise AmrError(AMR_ENODEV, "rtlamr_amd",
+                       f"{SO_PATH} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                       "(there is no CPU fallback)")
+    L = C.CDLL(SO_PATH)
+    vp, u8p = C.c_void_p, C.POINTER(C.c_uint8)
+    L.amr_create.argtypes = [C.POINTER(AmrProtocol), C.c_int32, C.c_int32, C.POINTER(vp)]
+    L.amr_destroy.argtypes = [vp]
+    L.amr_reset.argtypes = [vp]
+    L.amr_get_geometry.argtypes = [vp, C.POINTER(AmrGeometry)]
+    L.amr_preamble_id.argtypes = [vp, C.c_int32]
+    L.amr_preamble_id.restype = C.c_int32
+    L.amr_get_mag_lut.argtypes = [vp, C.POINTER(C.c_float)]
+    L.amr_set_stream.argtypes = [vp, vp]
+    L.amr_set_block_base.argtypes = [vp, C.c_uint64]
+    L.amr_decode_batch.argtypes = [vp, vp, C.c_size_t, C.c_size_t, C.POINTER(AmrResult)]
+    L.amr_decode_batch_device.argtypes = [vp, vp, C.c_size_t, C.POINTER(AmrResult)]
+    L.amr_prime.argtypes = [vp, vp, vp, C.c_size_t, C.c_int]
+    L.amr_halo_bytes.argtypes = [vp]
+    L.amr_halo_bytes.restype = C.c_size_t
+    L.amr_prime_blocks.argtypes = [vp]
+    L.amr_prime_blocks.restype = C.c_size_t
+    L.amr_copy_quantized.argtypes = [vp, vp, C.c_size_t]
+    L.amr_get_timing.argtypes = [vp, C.POINTER(AmrTiming)]
+    L.amr_strerror.argtypes = [C.c_int]
+    L.amr_strerror.restype = C.c_char_p
+    L.amr_last_error.restype = C.c_char_p
+    L.amr_describe.argtypes = [vp, C.c_char_p, C.c_size_t]
+    L.amr_dev_alloc.argtypes = [C.c_int32, C.c_size_t, C.POINTER(vp)]
+    L.amr_dev_free.argtypes = [C.c_int32, vp]
+    L.amr_dev_upload.argtypes = [C.c_int32, vp, vp, C.c_size_t]
+    L.amr_dev_download.argtypes = [C.c_int32, vp, vp, C.c_size_t]
+    L.amr_dev_sync.argtypes = [C.c_int32]
+    L.amr_synth_noise.argtypes = [C.c_int32, vp, C.c_uint64, C.c_uint64, C.c_uint64]
+    L.amr_synth_plant.argtypes = [C.c_int32, vp, C.c_uint64, C.c_uint64, C.c_int32, C.c_uint32, vp, vp,
+                                  C.c_uint32, C.c_uint32, vp, vp]
+    for name in SYMBOLS:
+        fn = getattr(L, name)
+        if name not in ("amr_preamble_id", "amr_halo_bytes", "amr_prime_blocks", "amr_strerror", "amr_last_error"):
+            fn.restype = C.c_int
+    _lib = L
+    return L
+
+
+def check(status: int, where: str) -> None:
+    if status != AMR_OK:
+        L = lib()
+        raise AmrError(status, where, f"{L.amr_strerror(status).decode()}: {L.amr_last_error().decode()}")

@@ -1,0 +1,322 @@
+"""Host-side mirror of rtlamr's Go package `protocol` on top of the amrdemod C ABI.
+
+Mirrors (reference file:line):
+    PacketConfig            protocol/decode.go:27-42
+    Decoder                 protocol/decode.go:45-63   NewDecoder :65, Log :73,
+                            RegisterProtocol :100, Allocate :131, Decode :163
+    Data / NewData          protocol/parse.go:55-69
+    Parser / Message        protocol/parse.go:72-84
+    RegisterParser / NewParser   protocol/parse.go:28-51
+    NextPowerOf2            protocol/decode.go:377-379
+
+Differences forced by the host language (Python instead of Go), none of which change what a
+parser sees:
+  * Decode returns a list of messages instead of a channel; parsers return lists instead of
+    sending on msgCh and calling wg.Done().
+  * Preambles are visited in registration order (Go's map order is random, decode.go:177).
+  * Decode accepts any whole number of blocks: one Decode of n blocks == n Go Decode calls.
+  * The sample work (magnitude, filter, quantize, search, slice) happens on the GPU; the
+    Decoder object keeps no Signal / Quantized slices on the host (`quantized_packed()` fetches
+    the new bit decisions for tests).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import math
+import threading
+from dataclasses import dataclass, field
+from typing import Callable, Dict, List, Optional, Sequence
+
+import numpy as np
+
+from . import _lib
+
+TIME_FORMAT = "2006-01-02T15:04:05.000"  # parse.go:13
+
+
+@dataclass
+class PacketConfig:
+    """protocol.PacketConfig (decode.go:27-42), Go field names."""
+    Protocol: str = ""
+    Preamble: str = ""
+    DataRate: int = 0
+    BlockSize: int = 0
+    BlockSize2: int = 0
+    ChipLength: int = 0
+    SymbolLength: int = 0
+    SampleRate: int = 0
+    PreambleSymbols: int = 0
+    PacketSymbols: int = 0
+    PreambleLength: int = 0
+    PacketLength: int = 0
+    BufferLength: int = 0
+    CenterFreq: int = 0
+
+
+@dataclass
+class Data:
+    """protocol.Data (parse.go:55-59)."""
+    Idx: int = 0
+    Bits: str = ""
+    Bytes: bytes = b""
+
+
+def new_data(data: bytes) -> Data:
+    """protocol.NewData (parse.go:61-69): copy the bytes, Bits = '%08b' of every byte."""
+    b = bytes(data)
+    return Data(Idx=0, Bits="".join(f"{x:08b}" for x in b), Bytes=b)
+
+
+class Message:
+    """protocol.Message (parse.go:78-84)."""
+
+    def MsgType(self) -> str: raise NotImplementedError
+    def MeterID(self) -> int: raise NotImplementedError
+    def MeterType(self) -> int: raise NotImplementedError
+    def Checksum(self) -> bytes: raise NotImplementedError
+    def Record(self) -> List[str]: raise NotImplementedError
+
+
+class Parser:
+    """protocol.Parser (parse.go:72-76)."""
+
+    def Parse(self, pkts: List[Data]) -> List[Message]: raise NotImplementedError
+    def SetDecoder(self, d: "Decoder") -> None: pass
+    def Cfg(self) -> PacketConfig: raise NotImplementedError
+
+
+_parser_mutex = threading.Lock()
+_parsers: Dict[str, Callable[[int], Parser]] = {}
+
+
+def register_parser(name: str, fn: Callable[[int], Parser]) -> None:
+    """protocol.RegisterParser (parse.go:28-39): nil func and duplicates panic."""
+    with _parser_mutex:
+        if fn is None:
+            raise RuntimeError("parser: new parser func is nil")
+        if name in _parsers:
+            raise RuntimeError(f"parser: parser already registered ({name})")
+        _parsers[name] = fn
+
+
+def new_parser(name: str, chip_length: int) -> Parser:
+    """protocol.NewParser (parse.go:42-51)."""
+    with _parser_mutex:
+        if name not in _parsers:
+            raise ValueError(f'invalid message type: "{name}"\n')
+        return _parsers[name](chip_length)
+
+
+def next_power_of_2(v: int) -> int:
+    """protocol.NextPowerOf2 (decode.go:377-379)."""
+    return 1 << int(math.ceil(math.log2(float(v))))
+
+
+@dataclass
+class BatchResult:
+    """Hits of one batch, per preamble id: (block, idx) ascending + packet bytes."""
+    n_blocks: int
+    preamble_offset: np.ndarray  # [n_pre+1]
+    hit_block: np.ndarray        # uint64 [n]
+    hit_idx: np.ndarray          # uint32 [n]
+    pkt: np.ndarray              # uint8 [n, pkt_bytes]
+
+    def for_preamble(self, pid: int):
+        lo, hi = int(self.preamble_offset[pid]), int(self.preamble_offset[pid + 1])
+        return self.hit_block[lo:hi], self.hit_idx[lo:hi], self.pkt[lo:hi]
+
+
+class Decoder:
+    """protocol.Decoder (decode.go:45-63) backed by one amr_handle on one MI355X."""
+
+    def __init__(self, device_id: int = 0):
+        # NewDecoder, decode.go:65-71
+        self.Cfg = PacketConfig()
+        self.device_id = device_id
+        self._handle: Optional[C.c_void_p] = None
+        self._parsers: List[Parser] = []
+        self._preamble_strs: List[str] = []
+        self._preambles: Dict[str, List[Parser]] = {}
+        self._protocols: List[str] = []
+        self._pid_of_preamble: Dict[str, int] = {}
+        self._calls = 0
+        self._last_blocks = 0
+
+    # -- decode.go:100-128 ------------------------------------------------
+    def RegisterProtocol(self, p: Parser) -> None:
+        p.SetDecoder(self)
+        c = p.Cfg()
+        self.Cfg.CenterFreq = c.CenterFreq
+        self.Cfg.DataRate = max(self.Cfg.DataRate, c.DataRate)
+        self.Cfg.ChipLength = max(self.Cfg.ChipLength, c.ChipLength)
+        self.Cfg.PreambleSymbols = max(self.Cfg.PreambleSymbols, c.PreambleSymbols)
+        self.Cfg.PacketSymbols = max(self.Cfg.PacketSymbols, c.PacketSymbols)
+        if c.Preamble not in self._preamble_strs:
+            self._preamble_strs.append(c.Preamble)
+        self._preambles.setdefault(c.Preamble, []).append(p)
+        self._protocols.append(c.Protocol)
+        self._parsers.append(p)
+
+    # -- decode.go:131-160 ------------------------------------------------
+    def Allocate(self) -> None:
+        L = _lib.lib()
+        n = len(self._parsers)
+        if n == 0:
+            raise ValueError("Allocate: no protocol registered")
+        arr = (_lib.AmrProtocol * n)()
+        keep = []
+        for i, p in enumerate(self._parsers):
+            c = p.Cfg()
+            s = c.Preamble.encode()
+            keep.append(s)
+            arr[i] = _lib.AmrProtocol(s, c.DataRate, c.ChipLength, c.PreambleSymbols, c.PacketSymbols)
+        h = C.c_void_p()
+        _lib.check(L.amr_create(arr, n, self.device_id, C.byref(h)), "amr_create")
+        self._handle = h
+        g = _lib.AmrGeometry()
+        _lib.check(L.amr_get_geometry(h, C.byref(g)), "amr_get_geometry")
+        cfg = self.Cfg
+        cfg.SymbolLength, cfg.SampleRate = g.symbol_length, g.sample_rate
+        cfg.PreambleLength, cfg.PacketLength = g.preamble_length, g.packet_length
+        cfg.BlockSize, cfg.BlockSize2, cfg.BufferLength = g.block_size, g.block_size2, g.buffer_length
+        assert (cfg.DataRate, cfg.ChipLength, cfg.PreambleSymbols, cfg.PacketSymbols) == (
+            g.data_rate, g.chip_length, g.preamble_symbols, g.packet_symbols)
+        self.pkt_bytes = g.pkt_bytes
+        self.n_preambles = g.n_preambles
+        for i, p in enumerate(self._parsers):
+            self._pid_of_preamble[p.Cfg().Preamble] = L.amr_preamble_id(h, i)
+
+    def close(self) -> None:
+        if self._handle is not None:
+            _lib.lib().amr_destroy(self._handle)
+            self._handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # -- decode.go:73-90 --------------------------------------------------
+    def Log(self, out=print) -> None:
+        c = self.Cfg
+        out(f"CenterFreq: {c.CenterFreq}")
+        out(f"SampleRate: {c.SampleRate}")
+        out(f"DataRate: {c.DataRate}")
+        out(f"ChipLength: {c.ChipLength}")
+        out(f"PreambleSymbols: {c.PreambleSymbols}")
+        out(f"PreambleLength: {c.PreambleLength}")
+        out(f"PacketSymbols: {c.PacketSymbols}")
+        out(f"PacketLength: {c.PacketLength}")
+        out("Protocols: " + ",".join(self._protocols))
+        out("Preambles: " + ",".join(self._preamble_strs))
+
+    # -- the hot path -------------------------------------------------------
+    def _require(self):
+        if self._handle is None:
+            raise RuntimeError("Decoder.Allocate() has not been called")
+        return self._handle
+
+    def _collect(self, res: "_lib.AmrResult", n_blocks: int) -> BatchResult:
+        self._last_blocks = n_blocks
+        n = int(res.n_hits)
+        npre = int(res.n_preambles)
+        off = np.ctypeslib.as_array(res.preamble_offset, shape=(npre + 1,)).copy()
+        if n:
+            blk = np.ctypeslib.as_array(res.hit_block, shape=(n,)).copy()
+            idx = np.ctypeslib.as_array(res.hit_idx, shape=(n,)).copy()
+            pkt = np.ctypeslib.as_array(res.pkt, shape=(n, int(res.pkt_bytes))).copy()
+        else:
+            blk = np.zeros(0, np.uint64)
+            idx = np.zeros(0, np.uint32)
+            pkt = np.zeros((0, int(res.pkt_bytes)), np.uint8)
+        return BatchResult(n_blocks, off, blk, idx, pkt)
+
+    def decode_batch(self, iq) -> BatchResult:
+        """n = len(iq)//BlockSize2 consecutive Decode calls (decode.go:163-172 + Search/Slice), no parsers."""
+        h = self._require()
+        iq = np.ascontiguousarray(iq, dtype=np.uint8).reshape(-1)
+        if iq.size < self.Cfg.BlockSize2:
+            raise IndexError("index out of range (short input, decode.go:222)")
+        n_blocks = iq.size // self.Cfg.BlockSize2
+        res = _lib.AmrResult()
+        _lib.check(_lib.lib().amr_decode_batch(h, iq.ctypes.data, iq.size, n_blocks, C.byref(res)), "amr_decode_batch")
+        self._calls += n_blocks
+        return self._collect(res, n_blocks)
+
+    def decode_batch_device(self, d_ptr: int, n_blocks: int) -> BatchResult:
+        h = self._require()
+        res = _lib.AmrResult()
+        _lib.check(_lib.lib().amr_decode_batch_device(h, C.c_void_p(d_ptr), n_blocks, C.byref(res)),
+                   "amr_decode_batch_device")
+        self._calls += n_blocks
+        return self._collect(res, n_blocks)
+
+    def run_parsers(self, br: BatchResult) -> List[List[Message]]:
+        """decode.go:177-187 for every block of the batch: per preamble, Slice -> []Data -> each parser."""
+        first = self._calls - br.n_blocks
+        out: List[List[Message]] = [[] for _ in range(br.n_blocks)]
+        for pre in self._preamble_strs:
+            blk, idx, pkt = br.for_preamble(self._pid_of_preamble[pre])
+            if len(blk) == 0:
+                per_block = {}
+            else:
+                rel = (blk - np.uint64(first)).astype(np.int64)
+                cuts = np.flatnonzero(np.diff(rel)) + 1
+                starts = np.concatenate([[0], cuts])
+                ends = np.concatenate([cuts, [len(rel)]])
+                per_block = {int(rel[s]): (s, e) for s, e in zip(starts, ends)}
+            for k in range(br.n_blocks):
+                pkts: List[Data] = []
+                if k in per_block:
+                    s, e = per_block[k]
+                    for i in range(s, e):
+                        d = new_data(pkt[i].tobytes())
+                        d.Idx = int(idx[i])
+                        pkts.append(d)
+                elif not any(getattr(p, "ALWAYS_PARSE", False) for p in self._preambles[pre]):
+                    continue
+                for p in self._preambles[pre]:
+                    out[k].extend(p.Parse(pkts))
+        return out
+
+    def Decode(self, input) -> List[Message]:
+        """Decoder.Decode (decode.go:163-197).  One block in the unchanged main.go loop (main.go:235);
+        more blocks are allowed and are decoded as consecutive calls (messages concatenated)."""
+        br = self.decode_batch(input)
+        msgs: List[Message] = []
+        for m in self.run_parsers(br):
+            msgs.extend(m)
+        return msgs
+
+    def reset(self) -> None:
+        _lib.check(_lib.lib().amr_reset(self._require()), "amr_reset")
+        self._calls = 0
+
+    # -- test / bench helpers ----------------------------------------------
+    def quantized_packed(self) -> np.ndarray:
+        """New bit decisions of the last batch (Quantized[PacketLength:] per call), packed MSB-first."""
+        h = self._require()
+        out = np.zeros(self._last_blocks * self.Cfg.BlockSize // 8, np.uint8)
+        _lib.check(_lib.lib().amr_copy_quantized(h, out.ctypes.data, out.size), "amr_copy_quantized")
+        return out
+
+    def timing(self):
+        t = _lib.AmrTiming()
+        _lib.check(_lib.lib().amr_get_timing(self._require(), C.byref(t)), "amr_get_timing")
+        return dict(demod_ms=t.demod_ms, search_ms=t.search_ms, total_ms=t.total_ms)
+
+    def mag_lut(self) -> np.ndarray:
+        out = np.zeros(256, np.float32)
+        _lib.check(_lib.lib().amr_get_mag_lut(self._require(), out.ctypes.data_as(C.POINTER(C.c_float))), "amr_get_mag_lut")
+        return out
+
+    def describe(self) -> str:
+        buf = C.create_string_buffer(256)
+        _lib.check(_lib.lib().amr_describe(self._require(), buf, 256), "amr_describe")
+        return buf.value.decode()
+
+
+def new_decoder(device_id: int = 0) -> Decoder:
+    """protocol.NewDecoder (decode.go:65)."""
+    return Decoder(device_id)
