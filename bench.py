@@ -1,0 +1,204 @@
+#!/usr/bin/env python
+"""bench.py -- IQ Msamples/s through Decoder.Decode semantics (SCM, chip 72) on N MI355X.
+
+One "step" = one pass of the whole hot path (K1 demod + K2 search + scan + K3 slice + hit
+read-back) over one batch of 1 GiB synthetic uint8 IQ per GPU (2^29 samples = 131072 reference
+blocks of 4096 samples), resident in HBM before the timed region starts.  Weak scaling: every rank
+owns 1 GiB of an N GiB stream; ranks > 0 prime their decoder with the blocks preceding their shard;
+hits are all-gathered over RCCL every step (N > 1).
+
+Launch:  python bench.py [--gpus 1] [--steps K] [--warmup W]
+         python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+Prints ONE JSON line on rank 0.
+"""
+from __future__ import annotations
+
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import threading
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+CHIP = 72
+PROTOS = ["scm"]
+GIB_BLOCKS = 131072          # 1 GiB of SCM chip-72 blocks (8192 bytes each)
+N_PACKETS = 4096             # planted CRC-valid SCM packets per GiB
+HBM_PEAK_GBS = 8000.0        # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
+ALG_BYTES_PER_SAMPLE = 2.0   # K1 reads one (I,Q) uint8 pair per sample
+
+
+def build_packets(rank: int, bs: int, n_samples: int):
+    from rtlamr_amd import synth
+    from rtlamr_amd.parsers.scm import build_packet
+    base = rank * n_samples
+    starts = synth.packet_schedule(N_PACKETS, n_samples, 96 * 2 * CHIP, seed=1 + rank, edge_every=64, block_size=bs)
+    pk = []
+    for i, s in enumerate(starts):
+        sign = 1 if i % 2 else -1
+        pk.append(synth.Packet(int(base + s), build_packet(100000 + rank * N_PACKETS + i, (i % 12) + 1, i * 37),
+                               96, sign * (22 + i % 17), -sign * (21 + i % 13)))
+    return pk
+
+
+def cpu_baseline(dec, d_iq, bs2, seconds=12.0):
+    """The C restatement of the reference Go path (oracle/decode_oracle.c, kind "port") timed on this
+    host: same IQ bytes (first 64 MiB of rank 0's shard), one independent stream per thread."""
+    import numpy as np
+    from oracle.oracle import OracleDecoder
+    from rtlamr_amd import _lib
+    nblk = 8192  # 64 MiB
+    sample = np.empty(nblk * bs2, np.uint8)
+    _lib.check(_lib.lib().amr_dev_download(dec.device_id, sample.ctypes.data, C.c_void_p(d_iq), sample.size), "download")
+    ncores = os.cpu_count() or 1
+
+    def run(nthreads, budget):
+        done = [0] * nthreads
+        decs = [OracleDecoder(PROTOS, CHIP) for _ in range(nthreads)]
+        t_end = time.perf_counter() + budget
+
+        def work(i):
+            while time.perf_counter() < t_end:
+                decs[i].decode_stream(sample, want_q=False)   # ctypes releases the GIL
+                done[i] += nblk
+        th = [threading.Thread(target=work, args=(i,)) for i in range(nthreads)]
+        t0 = time.perf_counter()
+        [t.start() for t in th]
+        [t.join() for t in th]
+        dt = time.perf_counter() - t0
+        return sum(done) * (bs2 // 2) / dt / 1e6
+
+    one = run(1, seconds * 0.4)
+    allc = run(ncores, seconds * 0.6) if ncores > 1 else one
+    return {"value": round(allc, 1), "unit": "Msamples/s", "cores": ncores, "kind": "port",
+            "single_thread": round(one, 1),
+            "sample": f"first 64 MiB ({nblk} blocks) of the bench IQ, replayed per thread for ~{seconds:.0f} s; "
+                      "C restatement of protocol/decode.go (gcc -O2 -ffp-contract=off), one stream per thread"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--blocks", type=int, default=GIB_BLOCKS, help="blocks per GPU per step (default 1 GiB)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    distributed = world > 1
+    torch = None
+    if distributed:
+        import torch  # noqa: F811  (first, so its HIP runtime is the one in the process)
+        import torch.distributed as dist
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    import numpy as np
+    import rtlamr_amd as ra
+    from rtlamr_amd import _lib, dist as shard, synth
+
+    L = _lib.lib()
+    dec = ra.new_decoder(local_rank)
+    for p in PROTOS:
+        dec.RegisterProtocol(ra.new_parser(p, CHIP))
+    dec.Allocate()
+    bs, bs2 = dec.Cfg.BlockSize, dec.Cfg.BlockSize2
+    n_blocks = args.blocks
+    n_samples = n_blocks * bs
+    nbytes = n_blocks * bs2
+
+    # ---- synthetic workload, generated in HBM (K0) ----
+    d_iq = C.c_void_p()
+    _lib.check(L.amr_dev_alloc(local_rank, nbytes, C.byref(d_iq)), "amr_dev_alloc")
+    pk = build_packets(rank, bs, n_samples)
+    synth.device_fill(local_rank, d_iq.value, n_samples, seed=1, first_sample=rank * n_samples, packets=pk,
+                      chip_length=CHIP)
+    if rank > 0:   # rebuild the history a single decoder would carry into this shard
+        pb = dec.prime_blocks()
+        hb = pb + 1
+        d_h = C.c_void_p()
+        _lib.check(L.amr_dev_alloc(local_rank, hb * bs2, C.byref(d_h)), "amr_dev_alloc")
+        prev = build_packets(rank - 1, bs, n_samples)
+        synth.device_fill(local_rank, d_h.value, hb * bs, seed=1, first_sample=rank * n_samples - hb * bs,
+                          packets=prev[-8:] + pk[:1], chip_length=CHIP)
+        dec.prime_device(d_h.value + bs2, pb, d_lead=d_h.value + bs2 - dec.halo_bytes())
+        dec.set_block_base(rank * n_blocks)
+        _lib.check(L.amr_dev_free(local_rank, d_h), "amr_dev_free")
+
+    dev = torch.device("cuda", local_rank) if distributed else None
+
+    def sync_all():
+        if distributed:
+            dist.barrier()
+            torch.cuda.synchronize()
+        _lib.check(L.amr_dev_sync(local_rank), "amr_dev_sync")
+        if distributed:
+            dist.barrier()
+
+    def step():
+        br = dec.decode_batch_device(d_iq.value, n_blocks)
+        if distributed:
+            shard.gather_hits(shard.batch_hits_array(br, dec.n_preambles), device=dev)
+        return br
+
+    for _ in range(args.warmup):
+        step()
+    demod_ms, search_ms, n_hits = [], [], 0
+    sync_all()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        br = step()
+        t = dec.timing()
+        demod_ms.append(t["demod_ms"])
+        search_ms.append(t["search_ms"])
+        n_hits = len(br.hit_idx)
+    sync_all()
+    dt = time.perf_counter() - t0
+    if distributed:
+        tt = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+
+    if rank == 0:
+        total_samples = float(world) * args.steps * n_samples
+        k1_ms = float(np.mean(demod_ms))
+        achieved = ALG_BYTES_PER_SAMPLE * n_samples / (k1_ms * 1e-3) / 1e9
+        traffic = None
+        tf = os.path.join(ROOT, "profiles", "k1_hbm_traffic.json")
+        if os.path.exists(tf):   # written from a rocprofv3 --pmc pass of this same command (see profiles/README.md)
+            try:
+                traffic = json.load(open(tf)).get("bytes_per_launch")
+            except Exception:
+                traffic = None
+        out = {
+            "metric": "IQ Msamples/s through Decoder.Decode (SCM, 72 sym/len)",
+            "value": round(total_samples / dt / 1e6, 1),
+            "unit": "Msamples/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(dt / args.steps * 1e3, 4),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"scm_chip72_{n_blocks}_blocks_per_gpu", "protocols": PROTOS, "chip_length": CHIP,
+                       "block_size": bs, "bytes_per_gpu_per_step": nbytes, "planted_packets_per_gpu": N_PACKETS,
+                       "hits_per_step_rank0": n_hits, "parallelism": f"block-range shards x{world}"},
+            "roofline": {"bound": "hbm", "kernel": "k1_demod<72>", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
+                         "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
+                         "k1_ms": round(k1_ms, 4), "search_ms": round(float(np.mean(search_ms)), 4),
+                         "algorithmic_bytes_per_launch": ALG_BYTES_PER_SAMPLE * n_samples},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(dec, d_iq.value, bs2)
+        print(json.dumps(out), flush=True)
+    if distributed:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -289,6 +289,35 @@ class Decoder:
             msgs.extend(m)
         return msgs
 
+    # -- multi-GPU sharding support (see rtlamr_amd/dist.py) ------
+    def prime_blocks(self) -> int:
+        """Blocks that must be replayed before a shard: ceil(PacketLength/BlockSize) + 1."""
+        return int(_lib.lib().amr_prime_blocks(self._require()))
+
+    def halo_bytes(self) -> int:
+        return int(_lib.lib().amr_halo_bytes(self._require()))
+
+    def set_block_base(self, base: int) -> None:
+        """Call index of the first block this decoder will report (start of its shard)."""
+        _lib.check(_lib.lib().amr_set_block_base(self._require(), base), "amr_set_block_base")
+
+    def prime(self, halo_iq, lead=None) -> None:
+        """Demodulate the blocks preceding a shard without searching them.  halo_iq: host uint8 array
+        of whole blocks; lead: the halo_bytes() stream bytes before halo_iq (None = stream start)."""
+        h = self._require()
+        halo_iq = np.ascontiguousarray(halo_iq, dtype=np.uint8).reshape(-1)
+        nb = halo_iq.size // self.Cfg.BlockSize2
+        lp = None
+        if lead is not None:
+            lead = np.ascontiguousarray(lead, dtype=np.uint8).reshape(-1)
+            assert lead.size == self.halo_bytes()
+            lp = lead.ctypes.data
+        _lib.check(_lib.lib().amr_prime(h, lp, halo_iq.ctypes.data, nb, 0), "amr_prime")
+
+    def prime_device(self, d_halo: int, n_blocks: int, d_lead: int = 0) -> None:
+        _lib.check(_lib.lib().amr_prime(self._require(), C.c_void_p(d_lead) if d_lead else None,
+                                        C.c_void_p(d_halo), n_blocks, 1), "amr_prime")
+
     def reset(self) -> None:
         _lib.check(_lib.lib().amr_reset(self._require()), "amr_reset")
         self._calls = 0
