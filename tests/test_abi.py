@@ -1,0 +1,67 @@
+"""The C-ABI library loads without a GPU and exports every symbol include/amrdemod.h declares.
+No compute calls here (that is what -m gpu is for)."""
+import ctypes as C
+import os
+import re
+
+import pytest
+
+from rtlamr_amd import _lib
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared_symbols():
+    src = open(os.path.join(ROOT, "include", "amrdemod.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(amr_[a-z0-9_]+)\s*\(", src)))
+
+
+def test_header_symbols_all_exported(amr_lib):
+    declared = _declared_symbols()
+    assert len(declared) >= 20
+    for name in declared:
+        assert hasattr(amr_lib, name), f"{name} declared in amrdemod.h but not exported"
+    assert sorted(_lib.SYMBOLS) == declared, "rtlamr_amd/_lib.py SYMBOLS out of sync with the header"
+
+
+def test_struct_layouts_match_header():
+    assert C.sizeof(_lib.AmrGeometry) == 13 * 4
+    assert C.sizeof(_lib.AmrProtocol) == 8 + 4 * 4
+    assert C.sizeof(_lib.AmrTiming) == 12
+    assert C.sizeof(_lib.AmrResult) == 4 + 4 + 8 + 4 * 8
+
+
+def test_strerror_and_argument_checks(amr_lib):
+    assert amr_lib.amr_strerror(0) == b"ok"
+    assert b"fallback" in amr_lib.amr_strerror(_lib.AMR_ENODEV)
+    h = C.c_void_p()
+    assert amr_lib.amr_create(None, 0, 0, C.byref(h)) == _lib.AMR_EINVAL
+    assert amr_lib.amr_reset(None) == _lib.AMR_EINVAL
+    assert amr_lib.amr_preamble_id(None, 0) == -1
+
+
+def test_no_device_fails_loudly(amr_lib):
+    """Without a gfx950 GPU the product path must refuse to run (no CPU fallback)."""
+    import rtlamr_amd as ra
+    d = ra.new_decoder()
+    d.RegisterProtocol(ra.new_parser("scm", 72))
+    try:
+        d.Allocate()
+    except _lib.AmrError as e:
+        assert e.status == _lib.AMR_ENODEV
+    else:   # a GPU is present (running the CPU suite on the GPU box): creation works, nothing else to check
+        d.close()
+
+
+def test_product_package_never_imports_oracle():
+    import subprocess
+    import sys
+    code = ("import sys; import rtlamr_amd, rtlamr_amd.dist, rtlamr_amd.synth, rtlamr_amd._lib; "
+            "bad=[m for m in sys.modules if m.split('.')[0]=='oracle']; assert not bad, bad")
+    subprocess.check_call([sys.executable, "-c", code], cwd=ROOT)
+    for dirpath, _, files in os.walk(os.path.join(ROOT, "rtlamr_amd")):
+        for f in files:
+            if f.endswith((".py", ".h", ".hip", ".cpp")):
+                txt = open(os.path.join(dirpath, f)).read()
+                assert "import oracle" not in txt and "from oracle" not in txt and "liboracle" not in txt, f

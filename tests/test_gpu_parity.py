@@ -68,3 +68,92 @@ def test_end_to_end_messages_scm():
         assert want_ids <= ids, f"planted meters not all recovered: missing {want_ids - ids}"
     finally:
         dec.close()
+
+
+def _sha(a):
+    import hashlib
+    return hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
+
+
+def test_committed_golden_fixtures():
+    """tests/golden/synth.json (made by tests/golden/make_golden.py from the oracle): the HIP path
+    reproduces the committed hashes without the oracle in the loop."""
+    import json
+    import os
+    fx = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "synth.json")))
+    for c in fx["cases"]:
+        dec = util.make_decoder(c["protocols"], c["chip"])
+        try:
+            iq, _ = util.synth_stream(c["protocols"], c["chip"], c["blocks"], dec.Cfg.BlockSize, c["seed"], c["packets"])
+            assert _sha(iq) == c["iq_sha"]
+            q, h, p = util.gpu_run(dec, iq, [c["blocks"] // 3, c["blocks"] - c["blocks"] // 3])
+            assert _sha(q) == c["qsha"], c["name"]
+            assert len(h) == c["n_hits"] and _sha(h.astype("<i8")) == c["hits_sha"], c["name"]
+            assert _sha(p[:, : dec.Cfg.PacketSymbols // 8]) == c["pkt_sha"], c["name"]
+        finally:
+            dec.close()
+
+
+def test_device_generator_matches_numpy_twin():
+    import ctypes as C
+    from rtlamr_amd import _lib, synth
+    from rtlamr_amd.parsers.scm import build_packet
+    L = _lib.lib()
+    n = 1 << 18
+    first = 123456
+    pk = [synth.Packet(first + 1000 + i * 20000, build_packet(42 + i, 5, i), 96, 25 - 50 * (i % 2), 31 - 9 * i) for i in range(8)]
+    pk.append(synth.Packet(first - 5000, build_packet(7, 7, 7), 96, 40, 40))          # partly before the buffer
+    pk.append(synth.Packet(first + n - 3000, build_packet(8, 8, 8), 96, -40, 127))    # partly after, clamps
+    host = synth.noise(n, seed=9, first_sample=first)
+    synth.plant(host, pk, 72, first_sample=first)
+    d = C.c_void_p()
+    _lib.check(L.amr_dev_alloc(0, 2 * n, C.byref(d)), "alloc")
+    try:
+        synth.device_fill(0, d.value, n, 9, first, pk, 72)
+        dev = np.empty(2 * n, np.uint8)
+        _lib.check(L.amr_dev_download(0, dev.ctypes.data, d, dev.size), "download")
+    finally:
+        L.amr_dev_free(0, d)
+    assert np.array_equal(host, dev)
+
+
+@pytest.mark.parametrize("protos,chip,n_blocks", [(["scm"], 72, 300), (["idm"], 72, 150), (["scm", "r900"], 8, 400)])
+def test_sharded_decode_with_priming_equals_single_decoder(protos, chip, n_blocks):
+    """SURVEY 8e on one GPU: three handles play three ranks; each primes with the blocks preceding its
+    range (amr_prime), decodes its range, and the union of hit lists must equal the single-decoder result."""
+    from rtlamr_amd import dist, synth
+    one = util.make_decoder(protos, chip)
+    bs, bs2 = one.Cfg.BlockSize, one.Cfg.BlockSize2
+    iq, _ = util.synth_stream(protos, chip, n_blocks, bs, seed=21, n_packets=14, edge_every=2)
+    # packets across both shard edges
+    kind = [p for p in protos if p in util.PKT_BUILDERS][0]
+    fn, nbits = util.PKT_BUILDERS[kind]
+    for e in (n_blocks // 3, 2 * (n_blocks // 3)):
+        synth.plant(iq, [synth.Packet(e * bs - nbits * chip, fn(900 + e), nbits, 35, -30)], chip)
+    want = util.gpu_run(one, iq)
+    o = util.oracle_run(protos, chip, iq)
+    util.assert_same(o, want, one.Cfg.PacketSymbols)
+    one.close()
+    world = 3
+    got_h, got_p = [], []
+    for rank in range(world):
+        k0, k1 = dist.shard_range(n_blocks, world, rank)
+        dec = util.make_decoder(protos, chip)
+        try:
+            p0, _ = dist.prime_range(k0, dec.prime_blocks())
+            if k0 > 0:
+                lead = None
+                if p0 > 0:   # the aligned halo bytes preceding the first primed block
+                    lead = iq[p0 * bs2 - dec.halo_bytes(): p0 * bs2]
+                dec.prime(iq[p0 * bs2: k0 * bs2], lead)
+                dec.set_block_base(k0)
+            _, h, p = util.gpu_run(dec, iq[k0 * bs2: k1 * bs2])
+            got_h.append(h)
+            got_p.append(p)
+        finally:
+            dec.close()
+    h = np.concatenate(got_h)
+    p = np.concatenate(got_p)
+    order = np.lexsort((h[:, 2], h[:, 1], h[:, 0]))
+    assert np.array_equal(h[order], want[1])
+    assert np.array_equal(p[order], want[2])

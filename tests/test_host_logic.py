@@ -1,0 +1,112 @@
+"""Host-side mirror of package protocol + parsers + synthetic generator (CPU only)."""
+import numpy as np
+import pytest
+
+import rtlamr_amd as ra
+from rtlamr_amd import dist, synth
+from rtlamr_amd.parsers.crc import CRC
+from rtlamr_amd.parsers.idm import IdmParser, NetIdmParser, ScmPlusParser, build_idm_packet, build_scmplus_packet
+from rtlamr_amd.parsers.scm import SCM, ScmParser, build_packet
+
+
+def test_new_data_bits_and_copy():  # parse.go:61-69
+    src = bytearray(b"\xf9\x53\x00")
+    d = ra.new_data(src)
+    src[0] = 0
+    assert d.Bytes == b"\xf9\x53\x00" and d.Bits == "111110010101001100000000" and d.Idx == 0
+
+
+def test_parser_registry():  # parse.go:28-51
+    assert isinstance(ra.new_parser("scm", 72), ScmParser)
+    with pytest.raises(ValueError, match="invalid message type"):
+        ra.new_parser("nope", 72)
+    with pytest.raises(RuntimeError, match="already registered"):
+        ra.register_parser("scm", ScmParser)
+    with pytest.raises(RuntimeError, match="nil"):
+        ra.register_parser("x", None)
+
+
+def test_register_protocol_takes_field_wise_max():  # decode.go:100-128
+    d = ra.new_decoder()
+    for name in ["scm", "scm+", "idm", "r900"]:   # "all", main.go:67-73
+        d.RegisterProtocol(ra.new_parser(name, 72))
+    c = d.Cfg
+    assert (c.DataRate, c.ChipLength, c.PreambleSymbols, c.PacketSymbols) == (32768, 72, 32, 736)
+    assert c.CenterFreq == 912380000  # last registered wins (decode.go:105)
+    assert len(d._preamble_strs) == 4
+    d2 = ra.new_decoder()
+    d2.RegisterProtocol(ra.new_parser("idm", 72))
+    d2.RegisterProtocol(ra.new_parser("netidm", 72))
+    assert len(d2._preamble_strs) == 1 and len(d2._preambles[d2._preamble_strs[0]]) == 2  # shared Search
+
+
+def test_next_power_of_2():  # decode.go:377-379
+    assert [ra.next_power_of_2(v) for v in (336, 1344, 3024, 4096, 4608)] == [512, 2048, 4096, 4096, 8192]
+
+
+@pytest.mark.parametrize("name,init,poly,residue", [("IBM", 0, 0x8005, 0), ("BCH", 0, 0x6F63, 0),
+                                                    ("CCITT", 0xFFFF, 0x1021, 0x1D0F)])
+def test_crc_identity(name, init, poly, residue):
+    """crc/crc_test.go:16-37: appending the checksum (complemented for CCITT) leaves the residue."""
+    rng = np.random.default_rng(1)
+    crc = CRC(name, init, poly, residue)
+    for _ in range(64):
+        msg = rng.integers(0, 256, rng.integers(1, 64), dtype=np.uint8).tobytes()
+        cs = crc.Checksum(msg)
+        if name == "CCITT":
+            cs ^= 0xFFFF
+        assert crc.Checksum(msg + cs.to_bytes(2, "big")) == residue
+
+
+def test_scm_packet_roundtrip_and_rejects():
+    p = ScmParser(72)
+    pkt = build_packet(0x2ABCDEF, 7, 123456, tamper_phy=2, tamper_enc=1)
+    (m,) = p.Parse([ra.new_data(pkt)])
+    assert (m.ID, m.Type, m.Consumption, m.TamperPhy, m.TamperEnc) == (0x2ABCDEF, 7, 123456, 2, 1)
+    assert m.MsgType() == "SCM" and m.MeterID() == m.ID and m.Checksum() == pkt[10:12]
+    bad = bytearray(pkt)
+    bad[5] ^= 1
+    assert p.Parse([ra.new_data(bytes(bad))]) == []           # CRC fails (scm.go:76)
+    assert len(p.Parse([ra.new_data(pkt), ra.new_data(pkt)])) == 1   # dedupe by bytes (scm.go:69-73)
+    assert p.Parse([ra.new_data(build_packet(0, 7, 1))]) == []  # ID 0 rejected (scm.go:83)
+
+
+def test_idm_scmplus_roundtrip():
+    (m,) = IdmParser(72).Parse([ra.new_data(build_idm_packet(123456789, ert_type=8, consumption=4242))])
+    assert (m.ERTSerialNumber, m.ERTType, m.LastConsumptionCount, m.Preamble) == (123456789, 8, 4242, 0x555516A3)
+    assert len(NetIdmParser(72).Parse([ra.new_data(build_idm_packet(5))])) == 1
+    (s,) = ScmPlusParser(72).Parse([ra.new_data(build_scmplus_packet(777, consumption=99))])
+    assert (s.EndpointID, s.Consumption, s.FrameSync) == (777, 99, 0x16A3)
+
+
+def test_synth_generator_is_deterministic_and_position_based():
+    a = synth.noise(4096, seed=5, first_sample=0)
+    b = synth.noise(1024, seed=5, first_sample=1000)
+    assert np.array_equal(a[2000:2000 + 2048], b)
+    assert 126.5 < a[0::2].mean() < 127.5 and 127.5 < a[1::2].mean() < 128.5
+    assert a.min() >= 119 and a.max() <= 136
+    assert int(synth.splitmix64(np.array([0], np.uint64))[0]) == 0xE220A8397B1DCDAF  # published splitmix64 vector
+
+
+def test_plant_is_clamped_and_manchester():
+    iq = np.full(2 * 1000, 250, np.uint8)
+    synth.plant(iq, [synth.Packet(100, b"\x80", 2, 20, -20)], 8)   # bits 1,0
+    I = iq[0::2]
+    assert I[100:108].tolist() == [255] * 8 and I[108:116].tolist() == [250] * 8   # bit 1: high, low
+    assert I[116:124].tolist() == [250] * 8 and I[124:132].tolist() == [255] * 8   # bit 0: low, high
+    assert iq[1::2][100:108].tolist() == [230] * 8
+
+
+def test_shard_ranges_cover_stream_exactly():
+    for total, world in [(131072, 8), (1000, 3), (7, 8)]:
+        spans = [dist.shard_range(total, world, r) for r in range(world)]
+        assert spans[0][0] == 0 and spans[-1][1] == total
+        assert all(spans[i][1] == spans[i + 1][0] for i in range(world - 1))
+    assert dist.prime_range(100, 5) == (95, 100) and dist.prime_range(3, 5) == (0, 3)
+
+
+def test_decode_short_input_mirrors_go_panic():
+    d = ra.new_decoder()
+    d.RegisterProtocol(ra.new_parser("scm", 72))
+    with pytest.raises(RuntimeError, match="Allocate"):
+        d.decode_batch(np.zeros(8192, np.uint8))
