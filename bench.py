@@ -141,25 +141,33 @@ def main():
         if distributed:
             dist.barrier()
 
-    def step():
-        br = dec.decode_batch_device(d_iq.value, n_blocks)
+    def finish():
+        """Collect the oldest batch: read back its hits and (N > 1) all-gather them over RCCL."""
+        br = dec.collect(copy=False)
         if distributed:
             shard.gather_hits(shard.batch_hits_array(br, dec.n_preambles), device=dev)
         return br
 
-    for _ in range(args.warmup):
-        step()
-    demod_ms, search_ms, n_hits = [], [], 0
+    def run(n):
+        """n steps through the two-deep pipeline: the GPU runs batch i+1 while the host reads back batch i."""
+        out = []
+        dec.submit_device(d_iq.value, n_blocks)
+        for _ in range(n - 1):
+            dec.submit_device(d_iq.value, n_blocks)
+            out.append((finish(), dec.timing()))
+        out.append((finish(), dec.timing()))
+        return out
+
+    if args.warmup:
+        run(args.warmup)
     sync_all()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        br = step()
-        t = dec.timing()
-        demod_ms.append(t["demod_ms"])
-        search_ms.append(t["search_ms"])
-        n_hits = len(br.hit_idx)
+    res = run(args.steps)
     sync_all()
     dt = time.perf_counter() - t0
+    demod_ms = [t["demod_ms"] for _, t in res]
+    search_ms = [t["search_ms"] for _, t in res]
+    n_hits = len(res[-1][0].hit_idx)
     if distributed:
         tt = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)

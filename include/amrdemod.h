@@ -11,9 +11,10 @@
  *   - extern "C", plain pointers and sizes, no C++ or torch types.
  *   - every function returns an amr_status (0 = ok, negative = error); no
  *     exception and no Go-style panic crosses the boundary.
- *   - the library never keeps a caller pointer after the call returns (cgo
- *     pointer-passing rule); result arrays are owned by the handle and stay
- *     valid until the next amr_decode_* / amr_reset / amr_destroy on it.
+ *   - the library never keeps a caller HOST pointer after the call returns (cgo
+ *     pointer-passing rule); result arrays are owned by the handle (pinned host
+ *     memory) and stay valid until the next amr_decode_* / second amr_submit_device /
+ *     amr_reset / amr_destroy on it.
  *   - one handle = one reference Decoder = one GPU; like the Go Decoder
  *     (decode.go:163, shared slices) a handle is not re-entrant: one caller
  *     thread at a time.
@@ -137,6 +138,16 @@ amr_status amr_decode_batch(amr_handle *h, const uint8_t *iq, size_t iq_bytes, s
 
 /* Same, input already resident in device memory (hipMalloc'd or a torch tensor's data_ptr). */
 amr_status amr_decode_batch_device(amr_handle *h, const void *d_iq, size_t n_blocks, amr_result *res);
+
+/*
+ * Pipelined form for throughput-oriented callers (file replay, many-SDR aggregation): submit
+ * enqueues a batch and returns immediately, collect waits for the OLDEST submitted batch and returns
+ * its result.  At most two batches may be in flight; the GPU then runs batch i+1 while the host reads
+ * back and parses batch i.  amr_decode_batch_device == submit + collect.  A result stays valid until
+ * the second submit after the collect that returned it.  d_iq must stay untouched until collected.
+ */
+amr_status amr_submit_device(amr_handle *h, const void *d_iq, size_t n_blocks);
+amr_status amr_collect(amr_handle *h, amr_result *res);
 
 /*
  * Multi-GPU sharding: feed the ceil(PacketLength/BlockSize)+1

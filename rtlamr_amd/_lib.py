@@ -15,7 +15,7 @@ AMR_OK, AMR_EINVAL, AMR_ENOMEM, AMR_EHIP, AMR_ENODEV, AMR_EOVERFLOW = 0, -1, -2,
 # every symbol include/amrdemod.h declares (checked by tests/test_abi.py)
 SYMBOLS = [
     "amr_create", "amr_destroy", "amr_reset", "amr_get_geometry", "amr_preamble_id", "amr_get_mag_lut",
-    "amr_set_stream", "amr_set_block_base", "amr_decode_batch", "amr_decode_batch_device", "amr_prime",
+    "amr_set_stream", "amr_set_block_base", "amr_decode_batch", "amr_decode_batch_device", "amr_submit_device", "amr_collect", "amr_prime",
     "amr_halo_bytes", "amr_prime_blocks", "amr_copy_quantized", "amr_get_timing", "amr_strerror",
     "amr_last_error", "amr_describe", "amr_dev_alloc", "amr_dev_free", "amr_dev_upload", "amr_dev_download",
     "amr_dev_sync", "amr_synth_noise", "amr_synth_plant",
@@ -85,6 +85,8 @@ def lib() -> C.CDLL:
     L.amr_set_block_base.argtypes = [vp, C.c_uint64]
     L.amr_decode_batch.argtypes = [vp, vp, C.c_size_t, C.c_size_t, C.POINTER(AmrResult)]
     L.amr_decode_batch_device.argtypes = [vp, vp, C.c_size_t, C.POINTER(AmrResult)]
+    L.amr_submit_device.argtypes = [vp, vp, C.c_size_t]
+    L.amr_collect.argtypes = [vp, C.POINTER(AmrResult)]
     L.amr_prime.argtypes = [vp, vp, vp, C.c_size_t, C.c_int]
     L.amr_halo_bytes.argtypes = [vp]
     L.amr_halo_bytes.restype = C.c_size_t

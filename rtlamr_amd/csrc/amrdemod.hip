@@ -60,6 +60,28 @@ bool legal_chip_length(int cl)
 
 }  // namespace
 
+// One in-flight batch.  Two slots let the host read back batch i (copy stream) while the GPU
+// already runs batch i+1 (compute stream); the quantized history flows slot -> slot.
+struct Slot {
+    uint32_t *d_qt = nullptr;     size_t qt_tiles = 0;     // tiled bitstream, tile 0 = history tile
+    uint32_t *d_counts = nullptr; uint64_t *d_offsets = nullptr; size_t cnt_tiles = 0;
+    uint64_t *d_offs_pre = nullptr;                        // [n_pre+1] + overflow word behind it
+    uint32_t *d_overflow = nullptr;
+    uint32_t *d_staging = nullptr; size_t staging_tiles = 0; uint32_t stage_cap = 1024;
+    uint64_t *d_hit_block = nullptr; uint32_t *d_hit_idx = nullptr; uint8_t *d_pkt = nullptr; uint64_t out_cap = 0;
+    // pinned host mirrors
+    uint64_t *h_off = nullptr;    // [AMR_MAX_PREAMBLES+1]
+    uint32_t *h_ovf = nullptr;
+    uint64_t *h_block = nullptr; uint32_t *h_idx = nullptr; uint8_t *h_pkt = nullptr; uint64_t host_cap = 0;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr, ev2 = nullptr, ev_done = nullptr;
+    // the batch in flight
+    bool pending = false, search = false;
+    const uint8_t *d_iq = nullptr;
+    size_t n_blocks = 0;
+    uint32_t n_tiles = 0;
+    uint64_t calls_base = 0;
+};
+
 struct amr_handle {
     int device = 0;
     amr_geometry geom{};
@@ -69,30 +91,24 @@ struct amr_handle {
     uint32_t halo_bytes = 0;   // HBA: aligned halo K1 reads before a block
     uint32_t hist_rows = 0;    // ceil(PL/BS)
 
-    hipStream_t own_stream = nullptr, stream = nullptr;
-    hipEvent_t ev0 = nullptr, ev1 = nullptr, ev2 = nullptr;
+    hipStream_t own_stream = nullptr, stream = nullptr, copy_stream = nullptr;
     bool timing_valid = false;
     amr_timing timing{};
 
     float *d_lut = nullptr;
     uint8_t *d_carry = nullptr;
     bool zero_halo = true;
+    bool dense_search = false;   // set when the sparse-list search overflowed once
     uint8_t *d_iq = nullptr;      size_t iq_cap = 0;       // staging for host input
-    uint32_t *d_qt = nullptr;     size_t qt_tiles = 0;     // tiles allocated
-    uint32_t *d_counts = nullptr; uint64_t *d_offsets = nullptr; size_t cnt_tiles = 0;
-    uint64_t *d_offs_pre = nullptr;
-    uint32_t *d_overflow = nullptr;
-    uint32_t *d_staging = nullptr; size_t staging_tiles = 0; uint32_t stage_cap = 1024;
-    uint64_t *d_hit_pos = nullptr; uint8_t *d_pkt = nullptr; uint64_t out_cap = 0;
     uint32_t *d_untile = nullptr; size_t untile_words = 0;
 
+    Slot slot[2];
+    int next_slot = 0;           // slot the next submit uses
+    int n_pending = 0;           // submitted, not yet collected (oldest = next_slot - n_pending)
+    int last_slot = -1;          // slot of the last collected batch (amr_copy_quantized, result storage)
     uint64_t calls_done = 0, block_base = 0;
     size_t last_n_blocks = 0;
-
-    // result storage (valid until the next call)
-    std::vector<uint64_t> r_off, r_block, r_pos;
-    std::vector<uint32_t> r_idx;
-    std::vector<uint8_t> r_pkt;
+    std::vector<uint64_t> r_off;
 };
 
 namespace {
@@ -104,6 +120,16 @@ amr_status dev_realloc(T *&p, size_t count)
     if (count == 0) return AMR_OK;
     hipError_t e = hipMalloc((void **)&p, count * sizeof(T));
     if (e != hipSuccess) { p = nullptr; return fail(AMR_ENOMEM, "hipMalloc", e); }
+    return AMR_OK;
+}
+
+template <typename T>
+amr_status host_realloc(T *&p, size_t count)
+{
+    if (p) { hipError_t e = hipHostFree(p); p = nullptr; if (e != hipSuccess) return fail(AMR_EHIP, "hipHostFree", e); }
+    if (count == 0) return AMR_OK;
+    hipError_t e = hipHostMalloc((void **)&p, count * sizeof(T), hipHostMallocDefault);
+    if (e != hipSuccess) { p = nullptr; return fail(AMR_ENOMEM, "hipHostMalloc", e); }
     return AMR_OK;
 }
 
@@ -125,169 +151,225 @@ void launch_k1(int cl, dim3 grid, hipStream_t st, const amr::K1Args &a)
     }
 }
 
-amr_status ensure_capacity(amr_handle *h, size_t n_blocks)
+// Grow the tiled bitstream of BOTH slots (the history tile of one slot is written by the batch that
+// ran in the other), keeping tile 0.
+amr_status ensure_qt(amr_handle *h, size_t tiles)
 {
-    const size_t bt = (n_blocks + 63) / 64;   // batch tiles
     const size_t tile_words = (size_t)64 * h->sg.wpb;
-    if (bt + 2 > h->qt_tiles) {
-        // keep the history tile across a regrow
+    for (Slot &s : h->slot) {
+        if (tiles <= s.qt_tiles) continue;
         uint32_t *nq = nullptr;
-        const size_t nt = bt + 2;
-        hipError_t e = hipMalloc((void **)&nq, nt * tile_words * 4);
+        hipError_t e = hipMalloc((void **)&nq, tiles * tile_words * 4);
         if (e != hipSuccess) return fail(AMR_ENOMEM, "hipMalloc(qt)", e);
-        if (h->d_qt) {
-            HIP_TRY(hipMemcpyAsync(nq, h->d_qt, tile_words * 4, hipMemcpyDeviceToDevice, h->stream));
+        if (s.d_qt) {
             HIP_TRY(hipStreamSynchronize(h->stream));
-            HIP_TRY(hipFree(h->d_qt));
+            HIP_TRY(hipMemcpy(nq, s.d_qt, tile_words * 4, hipMemcpyDeviceToDevice));
+            HIP_TRY(hipFree(s.d_qt));
         } else {
-            HIP_TRY(hipMemsetAsync(nq, 0, tile_words * 4, h->stream));
+            HIP_TRY(hipMemset(nq, 0, tile_words * 4));
         }
-        h->d_qt = nq;
-        h->qt_tiles = nt;
-    }
-    const size_t st = bt + 1;                 // tiles searched
-    if (st > h->cnt_tiles) {
-        AMR_TRY(dev_realloc(h->d_counts, st * h->sg.n_pre));
-        AMR_TRY(dev_realloc(h->d_offsets, st * h->sg.n_pre));
-        h->cnt_tiles = st;
-    }
-    if (st > h->staging_tiles) {
-        AMR_TRY(dev_realloc(h->d_staging, st * h->sg.n_pre * h->stage_cap));
-        h->staging_tiles = st;
-    }
-    if (h->out_cap == 0) {
-        h->out_cap = 1 << 16;
-        AMR_TRY(dev_realloc(h->d_hit_pos, h->out_cap));
-        AMR_TRY(dev_realloc(h->d_pkt, h->out_cap * h->sg.pkt_bytes));
+        s.d_qt = nq;
+        s.qt_tiles = tiles;
     }
     return AMR_OK;
 }
 
-// K1 for n_blocks rows starting at d_iq, then (optionally) search; history/carry update last.
-amr_status run_batch(amr_handle *h, const uint8_t *d_iq, size_t n_blocks, bool search, amr_result *res)
+amr_status ensure_capacity(amr_handle *h, Slot &s, size_t n_blocks)
+{
+    const size_t bt = (n_blocks + 63) / 64;   // batch tiles
+    AMR_TRY(ensure_qt(h, bt + 2));
+    const size_t st = bt + 1;                 // tiles searched
+    if (st > s.cnt_tiles) {
+        AMR_TRY(dev_realloc(s.d_counts, st * h->sg.n_pre));
+        AMR_TRY(dev_realloc(s.d_offsets, st * h->sg.n_pre));
+        s.cnt_tiles = st;
+    }
+    if (st > s.staging_tiles) {
+        AMR_TRY(dev_realloc(s.d_staging, st * h->sg.n_pre * s.stage_cap));
+        s.staging_tiles = st;
+    }
+    if (s.out_cap == 0) {
+        s.out_cap = 1 << 16;
+        AMR_TRY(dev_realloc(s.d_hit_block, s.out_cap));
+        AMR_TRY(dev_realloc(s.d_hit_idx, s.out_cap));
+        AMR_TRY(dev_realloc(s.d_pkt, s.out_cap * h->sg.pkt_bytes));
+    }
+    return AMR_OK;
+}
+
+// K2 + K2s + K3 for the batch held by slot s (may be re-run after a capacity overflow).
+amr_status enqueue_search(amr_handle *h, Slot &s)
+{
+    hipStream_t st = h->stream;
+    const uint32_t n_pre = h->sg.n_pre;
+    const uint32_t bs = (uint32_t)h->geom.block_size;
+    amr::K2Args k2{};
+    k2.qt = s.d_qt;
+    k2.counts = s.d_counts;
+    k2.staging = s.d_staging;
+    k2.overflow = s.d_overflow;
+    k2.n_tiles = s.n_tiles;
+    k2.cap = s.stage_cap;
+    k2.n_lo = -(int64_t)h->geom.packet_length;
+    k2.n_hi = (int64_t)s.n_blocks * bs - (int64_t)h->geom.packet_length;
+    k2.g = h->sg;
+    HIP_TRY(hipMemsetAsync(s.d_overflow, 0, 4, st));
+    if (!h->dense_search && n_pre <= 4) {
+        const size_t lds2 = amr::k2_fast_lds_bytes(h->sg.wpb, (int)n_pre);
+#define AMR_K2_CASE(N)                                                                                           \
+    case N:                                                                                                      \
+        HIP_TRY(hipFuncSetAttribute((const void *)amr::k2_search_fast<N>, hipFuncAttributeMaxDynamicSharedMemorySize, \
+                                    (int)lds2));                                                                 \
+        hipLaunchKernelGGL(amr::k2_search_fast<N>, dim3(s.n_tiles), dim3(256), lds2, st, k2);                    \
+        break;
+        switch (n_pre) { AMR_K2_CASE(1) AMR_K2_CASE(2) AMR_K2_CASE(3) AMR_K2_CASE(4) }
+#undef AMR_K2_CASE
+    } else {
+        const size_t lds2 = ((size_t)h->sg.wpb * 65 + 8) * 4;
+        HIP_TRY(hipFuncSetAttribute((const void *)amr::k2_search_dense, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    (int)lds2));
+        hipLaunchKernelGGL(amr::k2_search_dense, dim3(s.n_tiles), dim3(256), lds2, st, k2);
+    }
+    amr::ScanArgs sc{s.d_counts, s.d_offsets, s.d_offs_pre, s.n_tiles, n_pre};
+    hipLaunchKernelGGL(amr::k2s_scan, dim3(1), dim3(1024), 0, st, sc);
+    amr::K3Args k3{};
+    k3.qt = s.d_qt; k3.counts = s.d_counts; k3.offsets = s.d_offsets; k3.staging = s.d_staging;
+    k3.hit_block = s.d_hit_block; k3.hit_idx = s.d_hit_idx; k3.pkt = s.d_pkt; k3.out_cap = s.out_cap;
+    k3.block_base = s.calls_base; k3.n_tiles = s.n_tiles; k3.cap = s.stage_cap; k3.g = h->sg;
+    hipLaunchKernelGGL(amr::k3_slice, dim3(s.n_tiles, n_pre), dim3(256), 0, st, k3);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipEventRecord(s.ev2, st));
+    HIP_TRY(hipMemcpyAsync(s.h_off, s.d_offs_pre, (n_pre + 1) * 8, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipMemcpyAsync(s.h_ovf, s.d_overflow, 4, hipMemcpyDeviceToHost, st));
+    return AMR_OK;
+}
+
+// Enqueue one batch on the compute stream: K1, (search), history + carry update.  Returns at once.
+amr_status submit(amr_handle *h, const uint8_t *d_iq, size_t n_blocks, bool search)
 {
     HIP_TRY(hipSetDevice(h->device));
     if (n_blocks == 0 || n_blocks > 0x7fffffffull) return fail(AMR_EINVAL, "n_blocks out of range");
-    AMR_TRY(ensure_capacity(h, n_blocks));
+    if (h->n_pending >= 2) return fail(AMR_EINVAL, "two batches already in flight: call amr_collect first");
+    Slot &s = h->slot[h->next_slot];
+    Slot &other = h->slot[h->next_slot ^ 1];
+    AMR_TRY(ensure_capacity(h, s, n_blocks));
     hipStream_t st = h->stream;
     const uint32_t bs = (uint32_t)h->geom.block_size;
     const uint32_t full = (uint32_t)(n_blocks / 64), rem = (uint32_t)(n_blocks % 64);
+
+    s.d_iq = d_iq;
+    s.n_blocks = n_blocks;
+    s.n_tiles = (uint32_t)((n_blocks + 63) / 64) + 1;
+    s.search = search;
+    s.calls_base = h->calls_done + h->block_base;
 
     amr::K1Args k1{};
     k1.iq = d_iq;
     k1.carry = h->d_carry;
     k1.lut = h->d_lut;
-    k1.qt = h->d_qt;
+    k1.qt = s.d_qt;
     k1.n_blocks = (uint32_t)n_blocks;
     k1.block_size = bs;
     k1.zero_halo = h->zero_halo ? 1u : 0u;
 
-    HIP_TRY(hipEventRecord(h->ev0, st));
+    HIP_TRY(hipEventRecord(s.ev0, st));
     if (full) { k1.wg_first = 0; launch_k1<false>(h->geom.chip_length, dim3(full), st, k1); }
     if (rem) { k1.wg_first = full; launch_k1<true>(h->geom.chip_length, dim3(1), st, k1); }
     HIP_TRY(hipGetLastError());
-    HIP_TRY(hipEventRecord(h->ev1, st));
+    HIP_TRY(hipEventRecord(s.ev1, st));
+    if (search) AMR_TRY(enqueue_search(h, s));
+    else HIP_TRY(hipEventRecord(s.ev2, st));
 
-    const uint32_t n_tiles = (uint32_t)((n_blocks + 63) / 64) + 1;
-    uint64_t total = 0;
-    if (search) {
-        const uint32_t n_pre = h->sg.n_pre;
-        for (int attempt = 0;; ++attempt) {
-            amr::K2Args k2{};
-            k2.qt = h->d_qt;
-            k2.counts = h->d_counts;
-            k2.staging = h->d_staging;
-            k2.overflow = h->d_overflow;
-            k2.n_tiles = n_tiles;
-            k2.cap = h->stage_cap;
-            k2.n_lo = -(int64_t)h->geom.packet_length;
-            k2.n_hi = (int64_t)n_blocks * bs - (int64_t)h->geom.packet_length;
-            k2.g = h->sg;
-            HIP_TRY(hipMemsetAsync(h->d_overflow, 0, 4, st));
-            const size_t lds2 = ((size_t)h->sg.wpb * 65 + 8) * 4;
-            hipLaunchKernelGGL(amr::k2_search, dim3(n_tiles), dim3(256), lds2, st, k2);
-            amr::ScanArgs sc{h->d_counts, h->d_offsets, h->d_offs_pre, n_tiles, n_pre};
-            hipLaunchKernelGGL(amr::k2s_scan, dim3(1), dim3(1024), 0, st, sc);
-            amr::K3Args k3{};
-            k3.qt = h->d_qt; k3.counts = h->d_counts; k3.offsets = h->d_offsets; k3.staging = h->d_staging;
-            k3.hit_pos = h->d_hit_pos; k3.pkt = h->d_pkt; k3.out_cap = h->out_cap;
-            k3.n_tiles = n_tiles; k3.cap = h->stage_cap; k3.g = h->sg;
-            hipLaunchKernelGGL(amr::k3_slice, dim3(n_tiles, n_pre), dim3(256), 0, st, k3);
-            HIP_TRY(hipGetLastError());
-            HIP_TRY(hipEventRecord(h->ev2, st));
-
-            h->r_off.assign(n_pre + 1, 0);
-            uint32_t ovf = 0;
-            HIP_TRY(hipMemcpyAsync(h->r_off.data(), h->d_offs_pre, (n_pre + 1) * 8, hipMemcpyDeviceToHost, st));
-            HIP_TRY(hipMemcpyAsync(&ovf, h->d_overflow, 4, hipMemcpyDeviceToHost, st));
-            HIP_TRY(hipStreamSynchronize(st));
-            total = h->r_off[n_pre];
-            if (attempt > 8) return fail(AMR_EOVERFLOW, "hit capacity could not be grown");
-            if (ovf) {  // some tile found more hits than its staging slot holds: grow and redo the search
-                h->stage_cap *= 8;
-                const uint64_t lim = (uint64_t)64 * bs;
-                if (h->stage_cap > lim) h->stage_cap = (uint32_t)lim;
-                AMR_TRY(dev_realloc(h->d_staging, h->staging_tiles * n_pre * (size_t)h->stage_cap));
-                continue;
-            }
-            if (total > h->out_cap) {
-                uint64_t nc = h->out_cap;
-                while (nc < total) nc *= 2;
-                h->out_cap = nc;
-                AMR_TRY(dev_realloc(h->d_hit_pos, h->out_cap));
-                AMR_TRY(dev_realloc(h->d_pkt, h->out_cap * h->sg.pkt_bytes));
-                continue;
-            }
-            break;
-        }
-    } else {
-        HIP_TRY(hipEventRecord(h->ev2, st));
-    }
-
-    // state carried to the next batch: quantized history rows and the IQ halo (decode.go:165-166)
-    amr::HistArgs ha{h->d_qt, (uint32_t)n_blocks, h->hist_rows, h->sg.wpb, h->sg.lg_wpb};
+    // state carried to the next batch (decode.go:165-166): last rows of this slot's bitstream become the
+    // history tile of the OTHER slot (where the next batch runs); last HBA bytes of IQ become the carry
+    amr::HistArgs ha{s.d_qt, other.d_qt, (uint32_t)n_blocks, h->hist_rows, h->sg.wpb, h->sg.lg_wpb};
     hipLaunchKernelGGL(amr::k_hist_update, dim3(1), dim3(1024), (size_t)h->hist_rows * h->sg.wpb * 4, st, ha);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipMemcpyAsync(h->d_carry, d_iq + n_blocks * (size_t)h->geom.block_size2 - h->halo_bytes, h->halo_bytes,
                            hipMemcpyDeviceToDevice, st));
+    HIP_TRY(hipEventRecord(s.ev_done, st));
     h->zero_halo = false;
+    if (search) h->calls_done += n_blocks;
+    s.pending = true;
+    h->n_pending++;
+    h->next_slot ^= 1;
+    return AMR_OK;
+}
 
-    if (search) {
-        h->r_pos.resize(total);
-        h->r_pkt.resize(total * h->sg.pkt_bytes);
-        if (total) {
-            HIP_TRY(hipMemcpyAsync(h->r_pos.data(), h->d_hit_pos, total * 8, hipMemcpyDeviceToHost, st));
-            HIP_TRY(hipMemcpyAsync(h->r_pkt.data(), h->d_pkt, total * h->sg.pkt_bytes, hipMemcpyDeviceToHost, st));
+// Wait for the oldest batch in flight, grow capacities / re-run the search if it overflowed, read back hits.
+amr_status collect(amr_handle *h, amr_result *res)
+{
+    HIP_TRY(hipSetDevice(h->device));
+    if (h->n_pending == 0) return fail(AMR_EINVAL, "amr_collect: nothing in flight");
+    const int si = (h->n_pending == 2) ? h->next_slot : (h->next_slot ^ 1);
+    Slot &s = h->slot[si];
+    const uint32_t n_pre = h->sg.n_pre;
+    HIP_TRY(hipEventSynchronize(s.ev_done));
+    uint64_t total = 0;
+    if (s.search) {
+        for (int attempt = 0;; ++attempt) {
+            const uint32_t ovf = *s.h_ovf;
+            total = s.h_off[n_pre];
+            if (attempt > 8) return fail(AMR_EOVERFLOW, "hit capacity could not be grown");
+            bool rerun = false;
+            if (ovf & 2u) { h->dense_search = true; rerun = true; }   // sparse hit list overflowed: dense kernel
+            if (ovf & 1u) {   // a tile found more hits than its staging slot holds
+                s.stage_cap *= 8;
+                const uint64_t lim = (uint64_t)64 * h->geom.block_size;
+                if (s.stage_cap > lim) s.stage_cap = (uint32_t)lim;
+                HIP_TRY(hipStreamSynchronize(h->stream));
+                AMR_TRY(dev_realloc(s.d_staging, s.staging_tiles * n_pre * (size_t)s.stage_cap));
+                rerun = true;
+            } else if (!rerun && total > s.out_cap) {
+                uint64_t nc = s.out_cap;
+                while (nc < total) nc *= 2;
+                s.out_cap = nc;
+                HIP_TRY(hipStreamSynchronize(h->stream));
+                AMR_TRY(dev_realloc(s.d_hit_block, s.out_cap));
+                AMR_TRY(dev_realloc(s.d_hit_idx, s.out_cap));
+                AMR_TRY(dev_realloc(s.d_pkt, s.out_cap * h->sg.pkt_bytes));
+                rerun = true;
+            }
+            if (!rerun) break;
+            // the slot's bitstream is intact until the slot is reused, so the search can simply run again
+            AMR_TRY(enqueue_search(h, s));
+            HIP_TRY(hipStreamSynchronize(h->stream));
+        }
+        if (total > s.host_cap) {
+            uint64_t nc = s.host_cap ? s.host_cap : (1 << 16);
+            while (nc < total) nc *= 2;
+            AMR_TRY(host_realloc(s.h_block, nc));
+            AMR_TRY(host_realloc(s.h_idx, nc));
+            AMR_TRY(host_realloc(s.h_pkt, nc * h->sg.pkt_bytes));
+            s.host_cap = nc;
+        }
+        if (total) {   // on the copy stream: overlaps the next batch's kernels
+            HIP_TRY(hipMemcpyAsync(s.h_block, s.d_hit_block, total * 8, hipMemcpyDeviceToHost, h->copy_stream));
+            HIP_TRY(hipMemcpyAsync(s.h_idx, s.d_hit_idx, total * 4, hipMemcpyDeviceToHost, h->copy_stream));
+            HIP_TRY(hipMemcpyAsync(s.h_pkt, s.d_pkt, total * h->sg.pkt_bytes, hipMemcpyDeviceToHost, h->copy_stream));
+            HIP_TRY(hipStreamSynchronize(h->copy_stream));
         }
     }
-    HIP_TRY(hipStreamSynchronize(st));
-
     float a = 0, b = 0, c = 0;
-    if (hipEventElapsedTime(&a, h->ev0, h->ev1) == hipSuccess && hipEventElapsedTime(&b, h->ev1, h->ev2) == hipSuccess &&
-        hipEventElapsedTime(&c, h->ev0, h->ev2) == hipSuccess) {
+    if (hipEventElapsedTime(&a, s.ev0, s.ev1) == hipSuccess && hipEventElapsedTime(&b, s.ev1, s.ev2) == hipSuccess &&
+        hipEventElapsedTime(&c, s.ev0, s.ev2) == hipSuccess) {
         h->timing = amr_timing{a, b, c};
         h->timing_valid = true;
     }
-
-    if (search) {
-        h->r_block.resize(total);
-        h->r_idx.resize(total);
-        const uint32_t lg = h->sg.lg_block_size;
-        for (uint64_t i = 0; i < total; ++i) {
-            const uint64_t pos = h->r_pos[i];
-            h->r_block[i] = (pos >> lg) + h->calls_done + h->block_base;
-            h->r_idx[i] = (uint32_t)(pos & (bs - 1));
-        }
-        h->calls_done += n_blocks;
-        h->last_n_blocks = n_blocks;
+    s.pending = false;
+    h->n_pending--;
+    if (s.search) {
+        h->last_slot = si;
+        h->last_n_blocks = s.n_blocks;
+        h->r_off.assign(s.h_off, s.h_off + n_pre + 1);
         if (res) {
-            res->n_preambles = h->sg.n_pre;
+            res->n_preambles = n_pre;
             res->pkt_bytes = h->sg.pkt_bytes;
             res->n_hits = total;
             res->preamble_offset = h->r_off.data();
-            res->hit_block = h->r_block.data();
-            res->hit_idx = h->r_idx.data();
-            res->pkt = h->r_pkt.data();
+            res->hit_block = s.h_block;
+            res->hit_idx = s.h_idx;
+            res->pkt = s.h_pkt;
         }
     }
     return AMR_OK;
@@ -296,10 +378,17 @@ amr_status run_batch(amr_handle *h, const uint8_t *d_iq, size_t n_blocks, bool s
 amr_status stage_host_input(amr_handle *h, const uint8_t *iq, size_t bytes)
 {
     if (bytes > h->iq_cap) {
+        HIP_TRY(hipStreamSynchronize(h->stream));
         AMR_TRY(dev_realloc(h->d_iq, bytes));
         h->iq_cap = bytes;
     }
     HIP_TRY(hipMemcpyAsync(h->d_iq, iq, bytes, hipMemcpyHostToDevice, h->stream));
+    return AMR_OK;
+}
+
+amr_status drain(amr_handle *h)
+{
+    while (h->n_pending) AMR_TRY(collect(h, nullptr));
     return AMR_OK;
 }
 
@@ -323,6 +412,7 @@ amr_status amr_create(const amr_protocol *protos, int32_t n_protos, int32_t devi
     amr_handle *h = new (std::nothrow) amr_handle();
     if (!h) return fail(AMR_ENOMEM, "new amr_handle");
     h->device = device_id;
+    h->dense_search = getenv("AMR_DENSE_SEARCH") != nullptr;   // test hook: force the fallback search kernel
 
     // RegisterProtocol, decode.go:100-128: field-wise max, preambles grouped by value
     amr_geometry &g = h->geom;
@@ -398,14 +488,20 @@ amr_status amr_create(const amr_protocol *protos, int32_t n_protos, int32_t devi
 
     hipError_t e = hipSetDevice(device_id);
     if (e == hipSuccess) e = hipStreamCreateWithFlags(&h->own_stream, hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipStreamCreateWithFlags(&h->copy_stream, hipStreamNonBlocking);
     h->stream = h->own_stream;
-    if (e == hipSuccess) e = hipEventCreate(&h->ev0);
-    if (e == hipSuccess) e = hipEventCreate(&h->ev1);
-    if (e == hipSuccess) e = hipEventCreate(&h->ev2);
+    for (Slot &sl : h->slot) {
+        if (e == hipSuccess) e = hipEventCreate(&sl.ev0);
+        if (e == hipSuccess) e = hipEventCreate(&sl.ev1);
+        if (e == hipSuccess) e = hipEventCreate(&sl.ev2);
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&sl.ev_done, hipEventDisableTiming);
+        if (e == hipSuccess) e = hipMalloc((void **)&sl.d_offs_pre, (AMR_MAX_PREAMBLES + 1) * 8);
+        if (e == hipSuccess) e = hipMalloc((void **)&sl.d_overflow, 4);
+        if (e == hipSuccess) e = hipHostMalloc((void **)&sl.h_off, (AMR_MAX_PREAMBLES + 1) * 8, hipHostMallocDefault);
+        if (e == hipSuccess) e = hipHostMalloc((void **)&sl.h_ovf, 4, hipHostMallocDefault);
+    }
     if (e == hipSuccess) e = hipMalloc((void **)&h->d_lut, 1024);
     if (e == hipSuccess) e = hipMalloc((void **)&h->d_carry, h->halo_bytes);
-    if (e == hipSuccess) e = hipMalloc((void **)&h->d_offs_pre, (AMR_MAX_PREAMBLES + 1) * 8);
-    if (e == hipSuccess) e = hipMalloc((void **)&h->d_overflow, 4);
     if (e == hipSuccess) e = hipMemcpy(h->d_lut, h->lut, 1024, hipMemcpyHostToDevice);
     if (e == hipSuccess) e = hipMemset(h->d_carry, 0, h->halo_bytes);
     if (e != hipSuccess) { amr_destroy(h); return fail(AMR_EHIP, "amr_create: device setup", e); }
@@ -417,14 +513,21 @@ amr_status amr_destroy(amr_handle *h)
 {
     if (!h) return AMR_OK;
     (void)hipSetDevice(h->device);
-    if (h->own_stream) (void)hipStreamSynchronize(h->own_stream);
-    void *ptrs[] = {h->d_lut, h->d_carry, h->d_iq, h->d_qt, h->d_counts, h->d_offsets, h->d_offs_pre,
-                    h->d_overflow, h->d_staging, h->d_hit_pos, h->d_pkt, h->d_untile};
+    if (h->stream) (void)hipStreamSynchronize(h->stream);
+    if (h->copy_stream) (void)hipStreamSynchronize(h->copy_stream);
+    void *ptrs[] = {h->d_lut, h->d_carry, h->d_iq, h->d_untile};
     for (void *p : ptrs) if (p) (void)hipFree(p);
-    if (h->ev0) (void)hipEventDestroy(h->ev0);
-    if (h->ev1) (void)hipEventDestroy(h->ev1);
-    if (h->ev2) (void)hipEventDestroy(h->ev2);
+    for (Slot &sl : h->slot) {
+        void *dp[] = {sl.d_qt, sl.d_counts, sl.d_offsets, sl.d_offs_pre, sl.d_overflow, sl.d_staging, sl.d_hit_block,
+                      sl.d_hit_idx, sl.d_pkt};
+        for (void *p : dp) if (p) (void)hipFree(p);
+        void *hp[] = {sl.h_off, sl.h_ovf, sl.h_block, sl.h_idx, sl.h_pkt};
+        for (void *p : hp) if (p) (void)hipHostFree(p);
+        hipEvent_t evs[] = {sl.ev0, sl.ev1, sl.ev2, sl.ev_done};
+        for (hipEvent_t ev : evs) if (ev) (void)hipEventDestroy(ev);
+    }
     if (h->own_stream) (void)hipStreamDestroy(h->own_stream);
+    if (h->copy_stream) (void)hipStreamDestroy(h->copy_stream);
     delete h;
     return AMR_OK;
 }
@@ -433,7 +536,9 @@ amr_status amr_reset(amr_handle *h)
 {
     if (!h) return fail(AMR_EINVAL, "null handle");
     HIP_TRY(hipSetDevice(h->device));
-    if (h->d_qt) HIP_TRY(hipMemsetAsync(h->d_qt, 0, (size_t)64 * h->sg.wpb * 4, h->stream));
+    AMR_TRY(drain(h));
+    for (Slot &sl : h->slot)
+        if (sl.d_qt) HIP_TRY(hipMemsetAsync(sl.d_qt, 0, (size_t)64 * h->sg.wpb * 4, h->stream));
     HIP_TRY(hipStreamSynchronize(h->stream));
     h->zero_halo = true;
     h->calls_done = 0;
@@ -481,14 +586,30 @@ amr_status amr_decode_batch(amr_handle *h, const uint8_t *iq, size_t iq_bytes, s
     const size_t need = n_blocks * (size_t)h->geom.block_size2;
     if (iq_bytes < need) return fail(AMR_EINVAL, "short input (the Go decoder panics here, decode.go:222)");
     HIP_TRY(hipSetDevice(h->device));
+    AMR_TRY(drain(h));   // the host staging buffer is single: finish what is in flight first
     AMR_TRY(stage_host_input(h, iq, need));
-    return run_batch(h, h->d_iq, n_blocks, true, res);
+    AMR_TRY(submit(h, h->d_iq, n_blocks, true));
+    return collect(h, res);
 }
 
 amr_status amr_decode_batch_device(amr_handle *h, const void *d_iq, size_t n_blocks, amr_result *res)
 {
     if (!h || !d_iq) return fail(AMR_EINVAL, "null argument");
-    return run_batch(h, (const uint8_t *)d_iq, n_blocks, true, res);
+    AMR_TRY(drain(h));
+    AMR_TRY(submit(h, (const uint8_t *)d_iq, n_blocks, true));
+    return collect(h, res);
+}
+
+amr_status amr_submit_device(amr_handle *h, const void *d_iq, size_t n_blocks)
+{
+    if (!h || !d_iq) return fail(AMR_EINVAL, "null argument");
+    return submit(h, (const uint8_t *)d_iq, n_blocks, true);
+}
+
+amr_status amr_collect(amr_handle *h, amr_result *res)
+{
+    if (!h) return fail(AMR_EINVAL, "null argument");
+    return collect(h, res);
 }
 
 size_t amr_halo_bytes(const amr_handle *h) { return h ? h->halo_bytes : 0; }
@@ -503,12 +624,14 @@ amr_status amr_prime(amr_handle *h, const uint8_t *lead, const uint8_t *halo_iq,
                                on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, h->stream));
         h->zero_halo = false;
     }
+    AMR_TRY(drain(h));
     const uint8_t *src = halo_iq;
     if (!on_device) {
         AMR_TRY(stage_host_input(h, halo_iq, n_blocks * (size_t)h->geom.block_size2));
         src = h->d_iq;
     }
-    return run_batch(h, src, n_blocks, false, nullptr);
+    AMR_TRY(submit(h, src, n_blocks, false));
+    return collect(h, nullptr);
 }
 
 amr_status amr_copy_quantized(amr_handle *h, uint8_t *out, size_t out_bytes)
@@ -516,13 +639,14 @@ amr_status amr_copy_quantized(amr_handle *h, uint8_t *out, size_t out_bytes)
     if (!h || !out) return fail(AMR_EINVAL, "null argument");
     const size_t words = h->last_n_blocks * h->sg.wpb;
     if (out_bytes < words * 4) return fail(AMR_EINVAL, "output buffer too small");
-    if (words == 0) return AMR_OK;
+    if (words == 0 || h->last_slot < 0) return AMR_OK;
     HIP_TRY(hipSetDevice(h->device));
+    AMR_TRY(drain(h));
     if (words > h->untile_words) {
         AMR_TRY(dev_realloc(h->d_untile, words));
         h->untile_words = words;
     }
-    hipLaunchKernelGGL(amr::k_untile, dim3((unsigned)((words + 255) / 256)), dim3(256), 0, h->stream, h->d_qt, h->d_untile,
+    hipLaunchKernelGGL(amr::k_untile, dim3((unsigned)((words + 255) / 256)), dim3(256), 0, h->stream, h->slot[h->last_slot].d_qt, h->d_untile,
                        (uint32_t)h->last_n_blocks, h->sg.lg_wpb);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipMemcpyAsync(out, h->d_untile, words * 4, hipMemcpyDeviceToHost, h->stream));

@@ -64,7 +64,7 @@ __device__ __forceinline__ uint32_t k2_word(const uint32_t *lds, uint32_t x, uin
     return lds[(x & wpb_mask) * 65 + l + (x >> lg_wpb)];
 }
 
-__global__ __launch_bounds__(256) void k2_search(const K2Args a)
+__global__ __launch_bounds__(256) void k2_search_dense(const K2Args a)
 {
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];  // wpb*65 words + 8 counters
     const SearchGeom &g = a.g;
@@ -157,6 +157,202 @@ __global__ __launch_bounds__(256) void k2_search(const K2Args a)
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// k2_search_fast<NPRE>: the production search.  Same result as k2_search_dense, organised for the
+// common case that hits are sparse:
+//   * lane = row (reference block) of the tile, exactly the layout K1 stored, so the tile is copied
+//     to LDS as it lies in HBM ([word][65], column 64 = row 0 of the next tile);
+//   * a wave handles 4 consecutive words (128 positions) of all 64 rows per step: the per-tap scalar
+//     work (offset, shift, preamble bit) is shared by 4 words and the 4 (5 when the window is
+//     shifted by 16 bits) LDS reads use immediate offsets;
+//   * no barrier in the search loop: non-zero result masks are appended to a small per-wave list;
+//     a per-tile exclusive scan over (row, wave) popcounts then gives every list entry its rank, and
+//     each entry is emitted by 32 lanes at once (lane b = bit b), in stream order.
+// If a wave's list overflows (pathological input), bit 1 of *overflow is set and the host re-runs the
+// tile set with k2_search_dense.
+constexpr int kListCap = 256;  // (key, mask) entries per wave
+
+template <int NPRE>
+__global__ __launch_bounds__(256) void k2_search_fast(const K2Args a)
+{
+    extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
+    const uint32_t T = blockIdx.x, tid = threadIdx.x, lane = tid & 63, v = tid >> 6;
+    const uint32_t wpb = a.g.wpb, lg_wpb = a.g.lg_wpb, wpb_mask = wpb - 1;
+    const uint32_t lg_bs = a.g.lg_block_size;
+    const uint32_t SL = a.g.symbol_length, maxL = a.g.max_pre_len;
+    const uint32_t tile_words = 64u << lg_wpb;
+    uint32_t *tile = lds;                              // [wpb][65]
+    uint32_t *lists = tile + wpb * 65;                 // [4][kListCap][2]
+    uint32_t *cnts = lists + 4 * kListCap * 2;         // [NPRE][256], index row*4+wave
+    uint32_t *bases = cnts + NPRE * 256;               // [NPRE][256]
+    uint32_t *wtot = bases + NPRE * 256;               // [4]
+
+    uint64_t pbits[NPRE];
+    uint32_t plen[NPRE];
+#pragma unroll
+    for (int q = 0; q < NPRE; ++q) { pbits[q] = a.g.pre_bits[q]; plen[q] = a.g.pre_len[q]; }
+
+    // ---- stage the tile: straight copy of the HBM layout, 16 bytes per lane per load ----
+    {
+        const uint4 *src4 = reinterpret_cast<const uint4 *>(a.qt + (size_t)T * tile_words);
+        for (uint32_t i = tid; i < tile_words / 4; i += 256) {
+            const uint4 x = src4[i];
+            const uint32_t w = i >> 4, l4 = (i & 15) * 4;
+            uint32_t *d = tile + w * 65 + l4;
+            d[0] = x.x; d[1] = x.y; d[2] = x.z; d[3] = x.w;
+        }
+        const uint32_t *nxt = a.qt + (size_t)(T + 1) * tile_words;
+        for (uint32_t w = tid; w < wpb; w += 256) tile[w * 65 + 64] = nxt[(size_t)w << 6];
+    }
+    __syncthreads();
+
+    // ---- valid word range of this lane's row: n_lo <= R*BS + 32w < n_hi ----
+    const int64_t rowbase = ((int64_t)T * 64 + lane - 64) << lg_bs;
+    int64_t lo64 = (a.n_lo - rowbase) >> 5, hi64 = (a.n_hi - rowbase) >> 5;
+    const uint32_t w_lo = (uint32_t)(lo64 < 0 ? 0 : lo64 > (int64_t)wpb ? wpb : lo64);
+    const uint32_t w_hi = (uint32_t)(hi64 < 0 ? 0 : hi64 > (int64_t)wpb ? wpb : hi64);
+
+    uint32_t cnt[NPRE];
+#pragma unroll
+    for (int q = 0; q < NPRE; ++q) cnt[q] = 0;
+    uint32_t list_n = 0;                                // wave-uniform
+    uint32_t *mylist = lists + v * (kListCap * 2);
+    const uint32_t wq = wpb >> 2;                       // words per wave
+    const uint32_t *lane_tile = tile + lane;
+
+    for (uint32_t c = 0; c < (wq >> 2); ++c) {
+        const uint32_t w0 = v * wq + 4 * c;
+        uint32_t M[NPRE][4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const uint32_t ok = (w0 + j >= w_lo && w0 + j < w_hi) ? 0xffffffffu : 0u;
+#pragma unroll
+            for (int q = 0; q < NPRE; ++q) M[q][j] = ok;
+        }
+        for (uint32_t p = 0; p < maxL; ++p) {
+            if (p >= 8) {   // in noise all 8192 positions of a step die after ~14 taps
+                uint32_t any = 0;
+#pragma unroll
+                for (int q = 0; q < NPRE; ++q) any |= (M[q][0] | M[q][1]) | (M[q][2] | M[q][3]);
+                if (!__any(any != 0)) break;
+            }
+            const uint32_t o = p * SL;
+            const uint32_t x0 = w0 + (o >> 5);
+            const bool shifted = (o & 31) != 0;          // SL multiple of 16: shift is 0 or 16
+            const uint32_t xm = x0 & wpb_mask;
+            uint32_t A[5];
+            if (xm + 5 <= wpb) {                         // all words in one row: immediate offsets
+                const uint32_t *src = lane_tile + xm * 65 + (x0 >> lg_wpb);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) A[j] = src[j * 65];
+                A[4] = shifted ? src[4 * 65] : 0;
+            } else {                                     // the window crosses into the next row
+#pragma unroll
+                for (int j = 0; j < 5; ++j) {
+                    const uint32_t x = x0 + j;
+                    A[j] = lane_tile[(x & wpb_mask) * 65 + (x >> lg_wpb)];
+                }
+            }
+            uint32_t W[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) W[j] = shifted ? __builtin_amdgcn_alignbit(A[j], A[j + 1], 16) : A[j];
+#pragma unroll
+            for (int q = 0; q < NPRE; ++q) {
+                if (p < plen[q]) {
+                    if ((pbits[q] >> p) & 1) {
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) M[q][j] &= W[j];
+                    } else {
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) M[q][j] &= ~W[j];
+                    }
+                }
+            }
+        }
+        // record the (rare) non-zero masks
+#pragma unroll
+        for (int q = 0; q < NPRE; ++q) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const uint32_t m = M[q][j];
+                const uint64_t b = __ballot(m != 0);
+                if (b) {
+                    const uint32_t idx = list_n + __builtin_amdgcn_mbcnt_hi((uint32_t)(b >> 32),
+                                                                            __builtin_amdgcn_mbcnt_lo((uint32_t)b, 0));
+                    if (m != 0 && idx < (uint32_t)kListCap) {
+                        mylist[idx * 2] = ((uint32_t)q << 16) | (lane << 8) | (w0 + j);
+                        mylist[idx * 2 + 1] = m;
+                    }
+                    list_n += __popcll(b);
+                    cnt[q] += __popc(m);
+                }
+            }
+        }
+    }
+
+    // ---- ranks: exclusive scan over (row, wave) in stream order, per preamble ----
+#pragma unroll
+    for (int q = 0; q < NPRE; ++q) cnts[q * 256 + lane * 4 + v] = cnt[q];
+    __syncthreads();
+    uint32_t total[NPRE];
+#pragma unroll
+    for (int q = 0; q < NPRE; ++q) {
+        const uint32_t val = cnts[q * 256 + tid];
+        uint32_t inc = val;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const uint32_t t = __shfl_up(inc, d);
+            if (lane >= (uint32_t)d) inc += t;
+        }
+        if (lane == 63) wtot[v] = inc;
+        __syncthreads();
+        uint32_t base = 0;
+        for (uint32_t u = 0; u < v; ++u) base += wtot[u];
+        total[q] = wtot[0] + wtot[1] + wtot[2] + wtot[3];
+        bases[q * 256 + tid] = base + inc - val;
+        __syncthreads();
+    }
+
+    // ---- emit: every list entry by 32 lanes at once, lane b = bit b (MSB first = stream order) ----
+    uint32_t run[NPRE];
+#pragma unroll
+    for (int q = 0; q < NPRE; ++q) run[q] = 0;
+    const uint32_t n_emit = list_n < (uint32_t)kListCap ? list_n : (uint32_t)kListCap;
+    for (uint32_t e = 0; e < n_emit; ++e) {
+        const uint32_t key = __builtin_amdgcn_readfirstlane(mylist[e * 2]);
+        const uint32_t m = __builtin_amdgcn_readfirstlane(mylist[e * 2 + 1]);
+        const uint32_t q = key >> 16, l = (key >> 8) & 63, w = key & 0xff;
+        uint32_t r = 0;
+#pragma unroll
+        for (int qq = 0; qq < NPRE; ++qq)
+            if (q == (uint32_t)qq) r = __builtin_amdgcn_readlane(run[qq], l);
+        const uint32_t base = bases[q * 256 + l * 4 + v] + r;
+        if (lane < 32 && ((m >> (31 - lane)) & 1)) {
+            const uint32_t before = lane ? __popc(m >> (32 - lane)) : 0;
+            const uint32_t rank = base + before;
+            if (rank < a.cap) a.staging[((size_t)T * NPRE + q) * a.cap + rank] = (l << lg_bs) + (w << 5) + lane;
+        }
+        const uint32_t add = (lane == l) ? __popc(m) : 0;
+#pragma unroll
+        for (int qq = 0; qq < NPRE; ++qq)
+            if (q == (uint32_t)qq) run[qq] += add;
+    }
+
+    if (tid == 0) {
+#pragma unroll
+        for (int q = 0; q < NPRE; ++q) {
+            a.counts[q * a.n_tiles + T] = total[q] < a.cap ? total[q] : a.cap;
+            if (total[q] > a.cap) atomicOr(a.overflow, 1u);
+        }
+    }
+    if (lane == 0 && list_n > (uint32_t)kListCap) atomicOr(a.overflow, 2u);
+}
+
+inline size_t k2_fast_lds_bytes(uint32_t wpb, int npre)
+{
+    return ((size_t)wpb * 65 + 4 * kListCap * 2 + 2 * (size_t)npre * 256 + 8) * 4;
+}
+
 // K2s: exclusive scan of counts[n_pre*n_tiles] (preamble-major) -> offsets, plus
 // per-preamble bases offs_pre[n_pre+1].  One workgroup; n is a few thousand.
 struct ScanArgs {
@@ -199,7 +395,9 @@ struct K3Args {
     const uint32_t *counts;
     const uint64_t *offsets;
     const uint32_t *staging;
-    uint64_t *hit_pos;     // [out_cap] pos = k_rel*BS + idx, k_rel = call index inside the batch
+    uint64_t *hit_block;   // [out_cap] call index = block_base + (pos >> lg BS), pos = n + PacketLength
+    uint32_t *hit_idx;     // [out_cap] idx = pos & (BS-1)  (Data.Idx, decode.go:371)
+    uint64_t block_base;   // call index of the first block of the batch
     uint8_t *pkt;          // [out_cap * pkt_bytes]
     uint64_t out_cap;
     uint32_t n_tiles;
@@ -233,7 +431,11 @@ __global__ __launch_bounds__(256) void k3_slice(const K3Args a)
         const uint32_t local = src[h];
         // n relative to batch sample 0 of the first preamble bit
         const int64_t n = ((int64_t)T * 64 - 64) * (int64_t)g.block_size + local;
-        if (j == 0) a.hit_pos[slot] = (uint64_t)(n + g.packet_length);
+        if (j == 0) {
+            const uint64_t pos = (uint64_t)(n + g.packet_length);
+            a.hit_block[slot] = a.block_base + (pos >> g.lg_block_size);
+            a.hit_idx[slot] = (uint32_t)pos & (g.block_size - 1);
+        }
         uint32_t byte = 0;
         for (uint32_t k = 0; k < 8; ++k) {
             const uint32_t p = j * 8 + k;
@@ -246,7 +448,8 @@ __global__ __launch_bounds__(256) void k3_slice(const K3Args a)
 // After a batch: the last `hr` rows (reference blocks) become the history rows 64-hr..63 of tile 0.
 // Single workgroup, reads everything before writing anything (rows may move inside tile 0).
 struct HistArgs {
-    uint32_t *qt;
+    const uint32_t *qt;     // bitstream of the batch just processed (its tile 0 = the old history)
+    uint32_t *qt_next;      // bitstream buffer the next batch will use: receives the new history tile
     uint32_t n_blocks;  // rows in the batch just processed
     uint32_t hr;        // history rows kept = ceil(PL/BS) (<= 63)
     uint32_t wpb, lg_wpb;
@@ -265,7 +468,7 @@ __global__ __launch_bounds__(1024) void k_hist_update(const HistArgs a)
     __syncthreads();
     for (uint32_t i = threadIdx.x; i < n; i += 1024) {
         const uint32_t j = i >> a.lg_wpb, w = i & (a.wpb - 1);
-        a.qt[(w << 6) + (64 - a.hr + j)] = tmp[i];
+        a.qt_next[(w << 6) + (64 - a.hr + j)] = tmp[i];
     }
 }
 

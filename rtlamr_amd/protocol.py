@@ -116,6 +116,7 @@ def next_power_of_2(v: int) -> int:
 class BatchResult:
     """Hits of one batch, per preamble id: (block, idx) ascending + packet bytes."""
     n_blocks: int
+    first_block: int             # call index of the batch's first block
     preamble_offset: np.ndarray  # [n_pre+1]
     hit_block: np.ndarray        # uint64 [n]
     hit_idx: np.ndarray          # uint32 [n]
@@ -141,6 +142,8 @@ class Decoder:
         self._pid_of_preamble: Dict[str, int] = {}
         self._calls = 0
         self._last_blocks = 0
+        self._block_base = 0
+        self._inflight: List[tuple] = []   # (n_blocks, first_block) of submitted, uncollected batches
 
     # -- decode.go:100-128 ------------------------------------------------
     def RegisterProtocol(self, p: Parser) -> None:
@@ -217,20 +220,24 @@ class Decoder:
             raise RuntimeError("Decoder.Allocate() has not been called")
         return self._handle
 
-    def _collect(self, res: "_lib.AmrResult", n_blocks: int) -> BatchResult:
+    def _collect(self, res: "_lib.AmrResult", n_blocks: int, first_block: int, copy: bool = True) -> BatchResult:
+        """copy=False returns views into the library's pinned result buffers (valid until the second
+        submit after this collect) -- for throughput loops that only inspect the result."""
         self._last_blocks = n_blocks
         n = int(res.n_hits)
         npre = int(res.n_preambles)
         off = np.ctypeslib.as_array(res.preamble_offset, shape=(npre + 1,)).copy()
         if n:
-            blk = np.ctypeslib.as_array(res.hit_block, shape=(n,)).copy()
-            idx = np.ctypeslib.as_array(res.hit_idx, shape=(n,)).copy()
-            pkt = np.ctypeslib.as_array(res.pkt, shape=(n, int(res.pkt_bytes))).copy()
+            blk = np.ctypeslib.as_array(res.hit_block, shape=(n,))
+            idx = np.ctypeslib.as_array(res.hit_idx, shape=(n,))
+            pkt = np.ctypeslib.as_array(res.pkt, shape=(n, int(res.pkt_bytes)))
+            if copy:
+                blk, idx, pkt = blk.copy(), idx.copy(), pkt.copy()
         else:
             blk = np.zeros(0, np.uint64)
             idx = np.zeros(0, np.uint32)
             pkt = np.zeros((0, int(res.pkt_bytes)), np.uint8)
-        return BatchResult(n_blocks, off, blk, idx, pkt)
+        return BatchResult(n_blocks, first_block, off, blk, idx, pkt)
 
     def decode_batch(self, iq) -> BatchResult:
         """n = len(iq)//BlockSize2 consecutive Decode calls (decode.go:163-172 + Search/Slice), no parsers."""
@@ -241,20 +248,35 @@ class Decoder:
         n_blocks = iq.size // self.Cfg.BlockSize2
         res = _lib.AmrResult()
         _lib.check(_lib.lib().amr_decode_batch(h, iq.ctypes.data, iq.size, n_blocks, C.byref(res)), "amr_decode_batch")
+        first = self._calls + self._block_base
         self._calls += n_blocks
-        return self._collect(res, n_blocks)
+        return self._collect(res, n_blocks, first)
 
     def decode_batch_device(self, d_ptr: int, n_blocks: int) -> BatchResult:
         h = self._require()
         res = _lib.AmrResult()
         _lib.check(_lib.lib().amr_decode_batch_device(h, C.c_void_p(d_ptr), n_blocks, C.byref(res)),
                    "amr_decode_batch_device")
+        first = self._calls + self._block_base
         self._calls += n_blocks
-        return self._collect(res, n_blocks)
+        return self._collect(res, n_blocks, first)
+
+    def submit_device(self, d_ptr: int, n_blocks: int) -> None:
+        """Pipelined form: enqueue a device-resident batch and return (at most two in flight)."""
+        _lib.check(_lib.lib().amr_submit_device(self._require(), C.c_void_p(d_ptr), n_blocks), "amr_submit_device")
+        self._inflight.append((n_blocks, self._calls + self._block_base))
+        self._calls += n_blocks
+
+    def collect(self, copy: bool = True) -> BatchResult:
+        """Result of the oldest submitted batch."""
+        res = _lib.AmrResult()
+        _lib.check(_lib.lib().amr_collect(self._require(), C.byref(res)), "amr_collect")
+        n_blocks, first = self._inflight.pop(0)
+        return self._collect(res, n_blocks, first, copy)
 
     def run_parsers(self, br: BatchResult) -> List[List[Message]]:
         """decode.go:177-187 for every block of the batch: per preamble, Slice -> []Data -> each parser."""
-        first = self._calls - br.n_blocks
+        first = br.first_block
         out: List[List[Message]] = [[] for _ in range(br.n_blocks)]
         for pre in self._preamble_strs:
             blk, idx, pkt = br.for_preamble(self._pid_of_preamble[pre])
@@ -300,6 +322,7 @@ class Decoder:
     def set_block_base(self, base: int) -> None:
         """Call index of the first block this decoder will report (start of its shard)."""
         _lib.check(_lib.lib().amr_set_block_base(self._require(), base), "amr_set_block_base")
+        self._block_base = base
 
     def prime(self, halo_iq, lead=None) -> None:
         """Demodulate the blocks preceding a shard without searching them.  halo_iq: host uint8 array

@@ -101,7 +101,7 @@ def test_device_generator_matches_numpy_twin():
     L = _lib.lib()
     n = 1 << 18
     first = 123456
-    pk = [synth.Packet(first + 1000 + i * 20000, build_packet(42 + i, 5, i), 96, 25 - 50 * (i % 2), 31 - 9 * i) for i in range(8)]
+    pk = [synth.Packet(first + 12000 + i * 20000, build_packet(42 + i, 5, i), 96, 25 - 50 * (i % 2), 31 - 9 * i) for i in range(8)]
     pk.append(synth.Packet(first - 5000, build_packet(7, 7, 7), 96, 40, 40))          # partly before the buffer
     pk.append(synth.Packet(first + n - 3000, build_packet(8, 8, 8), 96, -40, 127))    # partly after, clamps
     host = synth.noise(n, seed=9, first_sample=first)
@@ -117,14 +117,15 @@ def test_device_generator_matches_numpy_twin():
     assert np.array_equal(host, dev)
 
 
-@pytest.mark.parametrize("protos,chip,n_blocks", [(["scm"], 72, 300), (["idm"], 72, 150), (["scm", "r900"], 8, 400)])
-def test_sharded_decode_with_priming_equals_single_decoder(protos, chip, n_blocks):
+@pytest.mark.parametrize("protos,chip,n_blocks,npk", [(["scm"], 72, 300, 14), (["idm"], 72, 150, 6),
+                                                          (["scm", "r900"], 8, 400, 14)])
+def test_sharded_decode_with_priming_equals_single_decoder(protos, chip, n_blocks, npk):
     """SURVEY 8e on one GPU: three handles play three ranks; each primes with the blocks preceding its
     range (amr_prime), decodes its range, and the union of hit lists must equal the single-decoder result."""
     from rtlamr_amd import dist, synth
     one = util.make_decoder(protos, chip)
     bs, bs2 = one.Cfg.BlockSize, one.Cfg.BlockSize2
-    iq, _ = util.synth_stream(protos, chip, n_blocks, bs, seed=21, n_packets=14, edge_every=2)
+    iq, _ = util.synth_stream(protos, chip, n_blocks, bs, seed=21, n_packets=npk, edge_every=2)
     # packets across both shard edges
     kind = [p for p in protos if p in util.PKT_BUILDERS][0]
     fn, nbits = util.PKT_BUILDERS[kind]
@@ -157,3 +158,38 @@ def test_sharded_decode_with_priming_equals_single_decoder(protos, chip, n_block
     order = np.lexsort((h[:, 2], h[:, 1], h[:, 0]))
     assert np.array_equal(h[order], want[1])
     assert np.array_equal(p[order], want[2])
+
+
+def test_dense_search_fallback_kernel(monkeypatch):
+    """k2_search_dense (used when a wave's sparse hit list overflows) must give the same results."""
+    monkeypatch.setenv("AMR_DENSE_SEARCH", "1")
+    _check(["scm", "idm"], 72, 130, seed=31, n_packets=8, batches=[64, 66])
+
+
+def test_pathological_hit_density_grows_capacities():
+    """A 1-bit preamble matches ~half of all positions: overflows the sparse lists (-> dense kernel), the
+    per-tile staging slots and the output arrays; all must grow transparently and still match the oracle."""
+    import rtlamr_amd as ra
+
+    class OneBit(ra.Parser):
+        def __init__(self):
+            self.cfg = ra.PacketConfig(Protocol="onebit", Preamble="1", DataRate=32768, ChipLength=72,
+                                       PreambleSymbols=21, PacketSymbols=96)
+
+        def Cfg(self):
+            return self.cfg
+
+        def Parse(self, pkts):
+            return []
+
+    dec = ra.new_decoder()
+    dec.RegisterProtocol(OneBit())
+    dec.Allocate()
+    try:
+        iq, _ = util.synth_stream(["scm"], 72, 70, dec.Cfg.BlockSize, seed=8, n_packets=3)
+        o = util.oracle_run([("1", 21, 96)], 72, iq, hits_cap=iq.size // 2)
+        g = util.gpu_run(dec, iq, [30, 40])
+        util.assert_same(o, g, 96)
+        assert len(g[1]) > 100000
+    finally:
+        dec.close()

@@ -18,10 +18,10 @@ def make_decoder(protos, chip) -> ra.Decoder:
     return d
 
 
-def oracle_run(protos, chip, iq, mode=0):
+def oracle_run(protos, chip, iq, mode=0, hits_cap=None):
     """-> (qpacked, hits sorted by (pid, block, idx) as int64[n,3], pkt[n,B])"""
     o = OracleDecoder(list(protos), chip)
-    q, hits, hb = o.decode_stream(iq, mode=mode, hits_cap=max(1 << 16, iq.size // 64))
+    q, hits, hb = o.decode_stream(iq, mode=mode, hits_cap=hits_cap or max(1 << 16, iq.size // 64))
     if len(hits):
         order = np.lexsort((hits[:, 2], hits[:, 0], hits[:, 1]))
         hits, hb = hits[order], hb[order]
