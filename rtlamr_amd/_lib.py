@@ -68,11 +68,12 @@ def lib() -> C.CDLL:
     global _lib
     if _lib is not None:
         return _lib
-    if not os.path.exists(SO_PATH):
+    path = os.environ.get("AMR_LIB_OVERRIDE", SO_PATH)   # developer hook: diagnostic builds of the same ABI
+    if not os.path.exists(path):
         raise AmrError(AMR_ENODEV, "rtlamr_amd",
                        f"{SO_PATH} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
                        "(there is no CPU fallback)")
-    L = C.CDLL(SO_PATH)
+    L = C.CDLL(path)
     vp, u8p = C.c_void_p, C.POINTER(C.c_uint8)
     L.amr_create.argtypes = [C.POINTER(AmrProtocol), C.c_int32, C.c_int32, C.POINTER(vp)]
     L.amr_destroy.argtypes = [vp]

@@ -40,6 +40,13 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+// Developer diagnostics (never defined in the product build): 1 = no HBM traffic after the first tile
+// (times the LDS/VALU side alone), 2 = HBM->LDS staging + row reads only (times the memory side alone),
+// 3 = no output stores.
+#ifndef AMR_K1_DIAG
+#define AMR_K1_DIAG 0
+#endif
+
 namespace amr {
 
 constexpr int kRows = 64;                       // block-rows per wave, one per lane
@@ -64,19 +71,27 @@ struct K1Geom {
     static constexpr int HBA = (HB + 127) & ~127;     // rounded up to whole cache lines
     static constexpr int SKIP = (HBA - HB) / 2;       // leading samples forced to magnitude 0
     static constexpr int WARM = SKIP + SL;            // steps before the first output bit
-    static constexpr int GPB = CL / 8;                // 8-sample groups per unrolled body
-    static constexpr int NPB = (WARM + CL - 1) / CL;  // bodies that need the zero-magnitude predicate
+    static constexpr int RING = CL + 8;               // csum history ring (registers), one unrolled body = RING samples
+    static constexpr int GPB = RING / 8;              // 8-sample groups per unrolled body
+    static constexpr int NPB = (WARM + RING - 1) / RING;  // bodies that need the zero-magnitude predicate
     static constexpr int NPT = HBA / kTileBytes;      // staging tiles that lie in the halo
 };
 
+// cache policy of the IQ stream: "nt" (aux bit 1).  Every byte is read exactly once, so keeping it out of the
+// L2 / Infinity Cache replacement queues is worth 6.1 -> 7.0 TB/s on the bare staging loop (tools/dma_bench2.hip).
+constexpr int kAuxNT = 2;
 typedef __attribute__((address_space(3))) void *lds_ptr_t;
 typedef const __attribute__((address_space(1))) void *glb_ptr_t;
 
 template <int CL>
 struct K1Lane {
-    float hc[CL];  // hc[r] = c[t'] for the latest t' = r (mod CL)
-    float hd[CL];  // hd[r] = c[t'] - c[t'-CL] for the same t'
-    float c;       // running sum c[t]
+    // Rings of RING = CL+8 registers, indexed statically (the sample loop is unrolled RING times): step t
+    // writes slot t%RING and reads slot (t+8)%RING = the value of step t-CL.  Because a slot is dead for 8
+    // steps before it is overwritten, every value is produced straight into its final register and the
+    // loop back-edge needs no register rotation (a CL-deep ring costs two v_mov per sample).
+    float hc[K1Geom<CL>::RING];  // hc[t%RING] = c[t], the running sum after sample t (decode.go:234)
+    float hd[K1Geom<CL>::RING];  // hd[t%RING] = c[t] - c[t-CL]
+    uint4 row;     // the 8 IQ samples of the group about to be consumed
     uint32_t acc;  // sign bits of f, newest in bit 0 (inverted decisions)
     uint32_t prev; // acc at the previous 32-sample boundary
 };
@@ -115,7 +130,7 @@ __device__ __forceinline__ void k1_prefetch(const K1Args &a, uint8_t *smem, uint
                 g = (rl == 0) ? a.carry + t * kTileBytes + colb : g;
             }
         }
-        __builtin_amdgcn_global_load_lds((glb_ptr_t)g, (lds_ptr_t)(smem + buf_off + q * 1024), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((glb_ptr_t)g, (lds_ptr_t)(smem + buf_off + q * 1024), 16, 0, kAuxNT);
     }
 }
 
@@ -133,8 +148,8 @@ __device__ __forceinline__ uint4 k1_row_read(uint32_t lds_addr)
     return dst;
 }
 
-// Make group `grp` readable: on a tile boundary wait for the tile's DMA (issued one tile-time
-// earlier), then refill the buffer that was just drained (all its reads have returned).
+// Make group `grp` readable and read it: on a tile boundary wait for the tile's DMA (issued one
+// tile-time earlier), then refill the buffer that was just drained (all its reads have returned).
 template <int CL, bool TAIL>
 __device__ __forceinline__ uint4 k1_fetch_group(uint32_t grp, const K1Uni &U, const K1Args &a, uint32_t tiles_lds,
                                                 uint8_t *tiles, uint32_t wg, uint32_t lane, uint32_t rd_base,
@@ -144,12 +159,18 @@ __device__ __forceinline__ uint4 k1_fetch_group(uint32_t grp, const K1Uni &U, co
     const uint32_t t = grp >> 3;
     if (gt == 0) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        if (t + 1 < U.ntiles)
+        if (t + 1 < U.ntiles && AMR_K1_DIAG != 1)
             k1_prefetch<CL, TAIL>(a, tiles, wg, t + 1, ((t + 1) & 1) * kTileBuf, lane, voff_e, voff_o, rows_valid);
     }
     return k1_row_read(tiles_lds + (t & 1) * kTileBuf + rd_base + ((gt * 16) ^ rd_xor));
 }
 
+// One unrolled "body" = CL samples = CL/8 groups; the csum history registers are indexed statically.
+// Per group the instruction stream is organised by hand (sched_barrier keeps hipcc from re-interleaving
+// it into a load-wait-use chain per sample, which left the wave waiting on ~9 LDS round trips per group):
+//   1. 16 LUT gathers of the group whose IQ bytes are already in registers (L.row),
+//   2. the row read of the NEXT group (asm, with its lgkmcnt(0)): one wait covers 1. and 2.,
+//   3. 8 x (magnitude add, running sum, two differences, sign bit), no memory access.
 template <int CL, bool PRO, bool TAIL>
 __device__ __forceinline__ void k1_body(K1Lane<CL> &L, K1Uni &U, const K1Args &a, uint32_t tiles_lds,
                                         uint8_t *tiles, const float *lut, uint32_t wg, uint32_t lane, uint32_t rd_base,
@@ -160,28 +181,45 @@ __device__ __forceinline__ void k1_body(K1Lane<CL> &L, K1Uni &U, const K1Args &a
 #pragma unroll
     for (int g = 0; g < G::GPB; ++g) {
         if (U.G >= U.ngroups) return;
-        const uint4 w = k1_fetch_group<CL, TAIL>(U.G, U, a, tiles_lds, tiles, wg, lane, rd_base, rd_xor, voff_e,
-                                                 voff_o, rows_valid);
-        const uint32_t dw[4] = {w.x, w.y, w.z, w.w};
+        const uint32_t dw[4] = {L.row.x, L.row.y, L.row.z, L.row.w};
+#if AMR_K1_DIAG == 2
+        L.acc ^= dw[0] ^ dw[1] ^ dw[2] ^ dw[3];
+        if (U.G + 1 < U.ngroups)
+            L.row = k1_fetch_group<CL, TAIL>(U.G + 1, U, a, tiles_lds, tiles, wg, lane, rd_base, rd_xor, voff_e, voff_o,
+                                             rows_valid);
+#else
+        float li[8], lq[8];
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
-            const int r = g * 8 + k;
             const uint32_t v = dw[k >> 1] >> ((k & 1) * 16);
-            float m = lut[v & 0xff] + lut[(v >> 8) & 0xff];   // decode.go:222
+            li[k] = lut[v & 0xff];                             // decode.go:222
+            lq[k] = lut[(v >> 8) & 0xff];
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        if (U.G + 1 < U.ngroups)
+            L.row = k1_fetch_group<CL, TAIL>(U.G + 1, U, a, tiles_lds, tiles, wg, lane, rd_base, rd_xor, voff_e, voff_o,
+                                             rows_valid);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            constexpr int R = G::RING;
+            const int r = g * 8 + k, rp = (r + R - 1) % R, ro = (r + 8) % R;
+            float m = li[k] + lq[k];                           // decode.go:222
             if (PRO) m = (U.G * 8 + k < zlim) ? 0.0f : m;      // zero history, decode.go:144
-            L.c = L.c + m;                                     // decode.go:234
-            const float d = L.c - L.hc[r];                     // csum[i+SL]-csum[i+CL]   (decode.go:242, upper - l)
-            const float f = L.hd[r] - d;                       // (csum[i+CL]-csum[i]) - d (decode.go:242)
+            const float c = L.hc[rp] + m;                      // decode.go:234
+            const float d = c - L.hc[ro];                      // csum[i+SL]-csum[i+CL]   (decode.go:242)
+            const float f = L.hd[ro] - d;                      // (csum[i+CL]-csum[i]) - d (decode.go:242)
             L.acc = __builtin_amdgcn_alignbit(L.acc, __float_as_uint(f), 31);  // decode.go:243, inverted
-            L.hc[r] = L.c;
+            L.hc[r] = c;
             L.hd[r] = d;
         }
+#endif
         U.G += 1;
         U.og += 1;
         // Output i leaves the filter at step WARM-1+i, i.e. one step before a group boundary: at a
         // boundary acc holds outputs [32m+1 .. 32m+32]; output 32m is bit 0 of acc at the previous boundary.
         if (U.og >= 0 && (U.og & 3) == 0) {
-            if (U.og > 0)   // 64 lanes -> 256 contiguous bytes
+            if (U.og > 0 && AMR_K1_DIAG != 3)   // 64 lanes -> 256 contiguous bytes
                 qrow[((U.og >> 2) - 1) * kRows] = ~__builtin_amdgcn_alignbit(L.prev, L.acc, 1);
             L.prev = L.acc;
         }
@@ -221,8 +259,7 @@ __global__ __launch_bounds__(64, 2) void k1_demod(const K1Args a)
 
     K1Lane<CL> L;
 #pragma unroll
-    for (int r = 0; r < CL; ++r) { L.hc[r] = 0.0f; L.hd[r] = 0.0f; }
-    L.c = 0.0f;
+    for (int r = 0; r < G::RING; ++r) { L.hc[r] = 0.0f; L.hd[r] = 0.0f; }
     L.acc = 0;
     L.prev = 0;
 
@@ -233,6 +270,7 @@ __global__ __launch_bounds__(64, 2) void k1_demod(const K1Args a)
     U.ntiles = U.ngroups / 8;
 
     k1_prefetch<CL, TAIL>(a, tiles, wg, 0, 0, lane, voff_e, voff_o, rows_valid);
+    L.row = k1_fetch_group<CL, TAIL>(0, U, a, tiles_lds, tiles, wg, lane, rd_base, rd_xor, voff_e, voff_o, rows_valid);
 
     const uint32_t nbodies = (U.ngroups + G::GPB - 1) / G::GPB;
     uint32_t body = 0;
