@@ -32,9 +32,9 @@
 // times ("body").  f = d[t-CL] - (c[t] - c[t-CL]) is the reference's
 // (csum[i+CL]-csum[i]) - (csum[i+SL]-csum[i+CL]) with the same three roundings.
 //
-// Output layout ("tiled"): word w of block b is stored at
-//     qt[(b/64 + 1) * 64*WPB + w*64 + b%64],   WPB = BlockSize/32,
-// i.e. a wave's 64 lanes store 256 contiguous bytes per 32 samples.  Tile 0 of
+// Output layout ("tiled4"): word w of block b is stored at
+//     qt[(b/64 + 1) * 64*WPB + (w/4)*256 + (b%64)*4 + w%4],   WPB = BlockSize/32,
+// i.e. a lane stores 16 bytes and a wave 1 KiB per store instruction.  Tile 0 of
 // qt holds the previous batch's last rows (history for the preamble search).
 #pragma once
 #include <hip/hip_runtime.h>
@@ -75,6 +75,18 @@ struct K1Geom {
     static constexpr int GPB = RING / 8;              // 8-sample groups per unrolled body
     static constexpr int NPB = (WARM + RING - 1) / RING;  // bodies that need the zero-magnitude predicate
     static constexpr int NPT = HBA / kTileBytes;      // staging tiles that lie in the halo
+    // Output words (32 decisions each) a lane keeps in registers between flushes.  Mixing a trickle of writes
+    // into the saturated read stream costs far more than the bytes (tools/sst_bench.hip: 64 MiB written per
+    // tile step +35 % kernel time, the same bytes in a few chip-wide bursts +3 %), so the bits are held in
+    // whatever VGPRs the csum rings leave free (256 per lane at 2 waves per SIMD) and written in bursts.
+    static constexpr int NW_FREE = 256 - 2 * RING - 88;
+#ifdef AMR_K1_NW
+    static constexpr int NW = AMR_K1_NW;
+#else
+    static constexpr int NW = NW_FREE >= 64 ? 64 : NW_FREE >= 48 ? 48 : NW_FREE >= 32 ? 32 : NW_FREE >= 16 ? 16 : NW_FREE >= 8 ? 8 : 4;
+#endif
+    static constexpr int NW0 = NW > 32 ? 32 : NW;      // words in the first register vector
+    static constexpr int NW1 = NW > 32 ? NW - 32 : 4;  // words in the second (a 4-word dummy when unused)
 };
 
 // cache policy of the IQ stream: "nt" (aux bit 1).  Every byte is read exactly once, so keeping it out of the
@@ -91,20 +103,35 @@ struct K1Lane {
     // loop back-edge needs no register rotation (a CL-deep ring costs two v_mov per sample).
     float hc[K1Geom<CL>::RING];  // hc[t%RING] = c[t], the running sum after sample t (decode.go:234)
     float hd[K1Geom<CL>::RING];  // hd[t%RING] = c[t] - c[t-CL]
-    uint4 row;     // the 8 IQ samples of the group about to be consumed
+    uint4 row1;    // the 8 IQ samples of group G+1 (its LUT gathers are issued while group G is computed)
+    float li[8], lq[8];  // lut[I], lut[Q] of the 8 samples of group G (gathered one group earlier)
     uint32_t acc;  // sign bits of f, newest in bit 0 (inverted decisions)
     uint32_t prev; // acc at the previous 32-sample boundary
+    uint32_t xs;   // AMR_K1_DIAG == 3 only
+    // Finished output words not yet written.  The insert index is wave-uniform, which hipcc lowers to one
+    // v_mov under s_set_gpr_idx_on (indirect VGPR addressing); plain vector members, no arrays of vectors
+    // and no references to them, or the whole struct is demoted to scratch.
+    typedef uint32_t v4u __attribute__((ext_vector_type(4)));
+    typedef uint32_t ow0_t __attribute__((ext_vector_type(K1Geom<CL>::NW0)));
+    typedef uint32_t ow1_t __attribute__((ext_vector_type(K1Geom<CL>::NW1)));
+    ow0_t ow0;
+    ow1_t ow1;
 };
 
 struct K1Uni {       // wave-uniform state (SGPRs)
-    uint32_t G;      // 8-sample groups consumed so far
+    uint32_t G;      // 8-sample groups computed so far
+    uint32_t F;      // next group whose row will be read from LDS (runs 2 ahead of G)
+    uint32_t roff;   // LDS offset bits of group F: (F & 7) * 16 | ((F >> 3) & 1) * kTileBuf
     int32_t og;      // output groups produced so far (negative during warm-up)
     uint32_t ngroups;// total groups per lane
     uint32_t ntiles; // total staging tiles per lane
+    uint32_t wi;     // output words buffered in L.ow
+    uint32_t wdone;  // output words already written
+    uint32_t st;     // store instructions issued since the last tile DMA
 };
 
 template <int CL, bool TAIL>
-__device__ __forceinline__ void k1_prefetch(const K1Args &a, uint8_t *smem, uint32_t wg, uint32_t t, uint32_t buf_off,
+__device__ __forceinline__ void k1_prefetch(const K1Args &a, uint32_t lds_base, uint32_t wg, uint32_t t, uint32_t buf_off,
                                             uint32_t lane, uint32_t voff_e, uint32_t voff_o, uint32_t rows_valid)
 {
     using G = K1Geom<CL>;
@@ -113,6 +140,27 @@ __device__ __forceinline__ void k1_prefetch(const K1Args &a, uint8_t *smem, uint
     const uint8_t *sb = a.iq + (int64_t)wg * kRows * bs2 - G::HBA + (int64_t)t * kTileBytes;
     const uint32_t rl = lane >> 3;
     const bool carry_tile = (wg == 0) && (t < (uint32_t)G::NPT);
+    // LDS-DMA: 64 lanes x 16 bytes -> 1 KiB of LDS at M0.  Issued from inline asm on purpose: when hipcc sees an
+    // LDS-DMA in flight it guards EVERY later LDS load that may alias its target with s_waitcnt vmcnt(0), which
+    // would serialise the prefetch of tile t+1 with the consumption of tile t.  Hidden in asm, the DMA is
+    // ordered by the explicit s_waitcnt vmcnt(0) in k1_fetch_next alone, and the row reads stay ordinary loads
+    // that the compiler keeps in flight across groups.  "nt": every byte is read once.  SGPR base + 32-bit lane
+    // offset addressing keeps the per-lane state at two VGPRs.
+    if (!TAIL && !carry_tile) {
+        const uint8_t *base = sb;                                   // uniform
+        uint32_t m0v = lds_base + buf_off;
+#pragma unroll 1
+        for (int q = 0; q < 4; ++q) {                               // a rolled loop: this code sits in every group
+            asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1 nt"
+                         :: "v"(voff_e), "s"(base), "s"(m0v) : "memory", "m0");
+            base += (size_t)8 * bs2;
+            asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1 nt"
+                         :: "v"(voff_o), "s"(base), "s"(m0v + 1024) : "memory", "m0");
+            base += (size_t)8 * bs2;
+            m0v += 2048;
+        }
+        return;
+    }
 #pragma unroll
     for (int q = 0; q < 8; ++q) {
         const uint8_t *g;
@@ -125,86 +173,116 @@ __device__ __forceinline__ void k1_prefetch(const K1Args &a, uint8_t *smem, uint
         } else {
             uint32_t voff = (q & 1) ? voff_o : voff_e;
             g = sb + (size_t)(q * 8) * bs2 + voff;
-            if (carry_tile && q == 0) {
+            if (q == 0) {
                 uint32_t colb = ((lane & 7) ^ ((rl >> 1) & 7)) * 16;
                 g = (rl == 0) ? a.carry + t * kTileBytes + colb : g;
             }
         }
-        __builtin_amdgcn_global_load_lds((glb_ptr_t)g, (lds_ptr_t)(smem + buf_off + q * 1024), 16, 0, kAuxNT);
+        asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off nt"
+                     :: "v"(g), "s"(lds_base + buf_off + q * 1024) : "memory", "m0");
     }
 }
 
-// Read the 16 bytes (8 IQ samples) of one group of this lane's row.  Inline asm on purpose: hipcc
-// orders every compiler-visible LDS load behind ALL outstanding LDS-DMA (s_waitcnt vmcnt(0)), which
-// would serialise the prefetch of tile t+1 with the consumption of tile t.  The asm load is
-// invisible to that logic; correctness comes from the explicit s_waitcnt vmcnt(0) issued when a
-// buffer is first read.  The lgkmcnt wait sits in the SAME asm statement: an asynchronous asm load
-// whose wait comes later is unsafe, because the compiler may copy the destination registers (phi
-// moves, live-range splits) while the load is still in flight.
-__device__ __forceinline__ uint4 k1_row_read(uint32_t lds_addr)
-{
-    uint4 dst;
-    asm volatile("ds_read_b128 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(dst) : "v"(lds_addr) : "memory");
-    return dst;
-}
-
-// Make group `grp` readable and read it: on a tile boundary wait for the tile's DMA (issued one
-// tile-time earlier), then refill the buffer that was just drained (all its reads have returned).
+// Read the 16 bytes (8 IQ samples) of this lane's row for the next group in line (U.F) and advance.  On a tile
+// boundary first wait for the tile's DMA (issued one tile-time earlier), then refill the buffer that was
+// drained before it.  Groups past the end of the lane's stream read stale LDS bytes that nobody uses.
+// The LDS address is one v_xor: rdv = lane*128 | swizzle, U.roff = (group in tile)*16 | (tile parity)*8192.
 template <int CL, bool TAIL>
-__device__ __forceinline__ uint4 k1_fetch_group(uint32_t grp, const K1Uni &U, const K1Args &a, uint32_t tiles_lds,
-                                                uint8_t *tiles, uint32_t wg, uint32_t lane, uint32_t rd_base,
-                                                uint32_t rd_xor, uint32_t voff_e, uint32_t voff_o, uint32_t rows_valid)
+__device__ __forceinline__ uint4 k1_fetch_next(K1Uni &U, const K1Args &a, uint32_t tiles_lds, const uint8_t *tiles,
+                                               uint32_t wg, uint32_t lane, uint32_t rdv, uint32_t voff_e,
+                                               uint32_t voff_o, uint32_t rows_valid)
 {
-    const uint32_t gt = grp & 7;
-    const uint32_t t = grp >> 3;
-    if (gt == 0) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if ((U.roff & 0x70) == 0) {
+        const uint32_t t = U.F >> 3;
+        // vmcnt retires in order on gfx9 (loads and stores alike; checked by tools/dma_bench.hip), so the output
+        // stores issued after the DMA of this tile need not be waited for.
+        if (U.st == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        else if (U.st == K1Geom<CL>::NW / 4) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(K1Geom<CL>::NW / 4) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        U.st = 0;
         if (t + 1 < U.ntiles && AMR_K1_DIAG != 1)
-            k1_prefetch<CL, TAIL>(a, tiles, wg, t + 1, ((t + 1) & 1) * kTileBuf, lane, voff_e, voff_o, rows_valid);
+            k1_prefetch<CL, TAIL>(a, tiles_lds, wg, t + 1, ((t + 1) & 1) * kTileBuf, lane, voff_e, voff_o, rows_valid);
     }
-    return k1_row_read(tiles_lds + (t & 1) * kTileBuf + rd_base + ((gt * 16) ^ rd_xor));
+    const uint4 r = *reinterpret_cast<const uint4 *>(tiles + (rdv ^ U.roff));
+    U.F += 1;
+    const uint32_t nx = U.roff + 16;              // 8 groups per tile, then the other buffer:
+    U.roff = (nx & 0x70) | ((nx ^ ((nx & 0x80) << 6)) & kTileBuf);   // the carry out of bit 6 toggles the buffer bit
+    return r;
 }
 
-// One unrolled "body" = CL samples = CL/8 groups; the csum history registers are indexed statically.
-// Per group the instruction stream is organised by hand (sched_barrier keeps hipcc from re-interleaving
-// it into a load-wait-use chain per sample, which left the wave waiting on ~9 LDS round trips per group):
-//   1. 16 LUT gathers of the group whose IQ bytes are already in registers (L.row),
-//   2. the row read of the NEXT group (asm, with its lgkmcnt(0)): one wait covers 1. and 2.,
-//   3. 8 x (magnitude add, running sum, two differences, sign bit), no memory access.
-template <int CL, bool PRO, bool TAIL>
+template <int CL, int J>
+__device__ __forceinline__ void k1_flush_chunks(const K1Lane<CL> &L, typename K1Lane<CL>::v4u *dst, uint32_t count)
+{
+    using G = K1Geom<CL>;
+    if constexpr (4 * J < G::NW) {
+        if ((uint32_t)(4 * J) < count) {
+            typename K1Lane<CL>::v4u x;
+            if constexpr (4 * J < G::NW0) x = {L.ow0[4 * J], L.ow0[4 * J + 1], L.ow0[4 * J + 2], L.ow0[4 * J + 3]};
+            else x = {L.ow1[4 * J - G::NW0], L.ow1[4 * J + 1 - G::NW0], L.ow1[4 * J + 2 - G::NW0], L.ow1[4 * J + 3 - G::NW0]};
+            dst[J * kRows] = x;
+        }
+        k1_flush_chunks<CL, J + 1>(L, dst, count);
+    }
+}
+
+// Write the buffered output words: word W of row `lane` of wave-tile `wg` lives at
+//   qt[(wg+1)*64*WPB + (W>>2)*256 + lane*4 + (W&3)]   ("tiled4": a lane stores 16 bytes, a wave 1 KiB, per instruction).
+template <int CL>
+__device__ __forceinline__ void k1_flush(K1Lane<CL> &L, K1Uni &U, uint32_t *qbase, uint32_t count)
+{
+    typedef typename K1Lane<CL>::v4u v4u;
+    // uniform base (SGPRs) + 32-bit lane offset: no 64-bit per-lane pointer kept alive across the loop
+    uint8_t *ub = reinterpret_cast<uint8_t *>(qbase) + (size_t)(U.wdone >> 2) * (kRows * 16);
+    v4u *dst = reinterpret_cast<v4u *>(ub + (uint32_t)(threadIdx.x * 16));
+    k1_flush_chunks<CL, 0>(L, dst, count);
+    U.wdone += count;
+    U.wi = 0;
+    U.st += count >> 2;
+}
+
+// One unrolled "body" = RING samples = RING/8 groups; the csum history registers are indexed statically.
+// Two-stage software pipeline per group G, so that a wave never waits for the LDS and both waves of a SIMD
+// can issue VALU work back to back (a lone wave issues one VALU op per ~5 cycles, two share ~2.5):
+//   1. 16 LUT gathers for group G+1 (its IQ bytes, L.row1, arrived during group G-1),
+//   2. the row read of group G+2,
+//   3. 8 x (magnitude add, running sum, two differences, sign bit) for group G on the LUT values gathered
+//      during group G-1 -- no memory access, no wait.
+// sched_barrier keeps hipcc from re-interleaving this into a load-wait-use chain per sample.
+// PRO: bodies that overlap the warm-up (zero-magnitude predicate, no output yet); CHECK: the last, partial body.
+template <int CL, bool PRO, bool CHECK, bool TAIL>
 __device__ __forceinline__ void k1_body(K1Lane<CL> &L, K1Uni &U, const K1Args &a, uint32_t tiles_lds,
-                                        uint8_t *tiles, const float *lut, uint32_t wg, uint32_t lane, uint32_t rd_base,
-                                        uint32_t rd_xor, uint32_t zlim, uint32_t voff_e, uint32_t voff_o,
-                                        uint32_t rows_valid, uint32_t *qrow)
+                                        const uint8_t *tiles, const float *lut, uint32_t wg, uint32_t lane, uint32_t rdv,
+                                        uint32_t zlim, uint32_t voff_e, uint32_t voff_o, uint32_t rows_valid,
+                                        uint32_t *qrow)
 {
     using G = K1Geom<CL>;
 #pragma unroll
     for (int g = 0; g < G::GPB; ++g) {
-        if (U.G >= U.ngroups) return;
-        const uint32_t dw[4] = {L.row.x, L.row.y, L.row.z, L.row.w};
+        if (CHECK && U.G >= U.ngroups) return;
 #if AMR_K1_DIAG == 2
-        L.acc ^= dw[0] ^ dw[1] ^ dw[2] ^ dw[3];
-        if (U.G + 1 < U.ngroups)
-            L.row = k1_fetch_group<CL, TAIL>(U.G + 1, U, a, tiles_lds, tiles, wg, lane, rd_base, rd_xor, voff_e, voff_o,
-                                             rows_valid);
+        L.acc ^= L.row1.x ^ L.row1.y ^ L.row1.z ^ L.row1.w;
+        L.row1 = k1_fetch_next<CL, TAIL>(U, a, tiles_lds, tiles, wg, lane, rdv, voff_e, voff_o, rows_valid);
 #else
-        float li[8], lq[8];
+        const uint32_t dw[4] = {L.row1.x, L.row1.y, L.row1.z, L.row1.w};
+        float nli[8], nlq[8];
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
             const uint32_t v = dw[k >> 1] >> ((k & 1) * 16);
-            li[k] = lut[v & 0xff];                             // decode.go:222
-            lq[k] = lut[(v >> 8) & 0xff];
+#if AMR_K1_DIAG == 5   // no LUT traffic: one cheap ALU op per byte instead (wrong values, timing only)
+            nli[k] = __uint_as_float(((v & 0xff) << 15) | 0x3c000000u);
+            nlq[k] = __uint_as_float((((v >> 8) & 0xff) << 15) | 0x3c000000u);
+#else
+            nli[k] = lut[v & 0xff];                            // decode.go:222
+            nlq[k] = lut[(v >> 8) & 0xff];
+#endif
         }
-        __builtin_amdgcn_sched_barrier(0);
-        if (U.G + 1 < U.ngroups)
-            L.row = k1_fetch_group<CL, TAIL>(U.G + 1, U, a, tiles_lds, tiles, wg, lane, rd_base, rd_xor, voff_e, voff_o,
-                                             rows_valid);
+        const uint4 row2 = k1_fetch_next<CL, TAIL>(U, a, tiles_lds, tiles, wg, lane, rdv, voff_e, voff_o, rows_valid);
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
             constexpr int R = G::RING;
             const int r = g * 8 + k, rp = (r + R - 1) % R, ro = (r + 8) % R;
-            float m = li[k] + lq[k];                           // decode.go:222
+            float m = L.li[k] + L.lq[k];                       // decode.go:222
             if (PRO) m = (U.G * 8 + k < zlim) ? 0.0f : m;      // zero history, decode.go:144
             const float c = L.hc[rp] + m;                      // decode.go:234
             const float d = c - L.hc[ro];                      // csum[i+SL]-csum[i+CL]   (decode.go:242)
@@ -213,14 +291,28 @@ __device__ __forceinline__ void k1_body(K1Lane<CL> &L, K1Uni &U, const K1Args &a
             L.hc[r] = c;
             L.hd[r] = d;
         }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) { L.li[k] = nli[k]; L.lq[k] = nlq[k]; }
+        L.row1 = row2;
 #endif
         U.G += 1;
         U.og += 1;
         // Output i leaves the filter at step WARM-1+i, i.e. one step before a group boundary: at a
         // boundary acc holds outputs [32m+1 .. 32m+32]; output 32m is bit 0 of acc at the previous boundary.
-        if (U.og >= 0 && (U.og & 3) == 0) {
-            if (U.og > 0 && AMR_K1_DIAG != 3)   // 64 lanes -> 256 contiguous bytes
-                qrow[((U.og >> 2) - 1) * kRows] = ~__builtin_amdgcn_alignbit(L.prev, L.acc, 1);
+        // WARM/8 is a multiple of 8, so word boundaries are the groups with G % 4 == 0; the first one
+        // (og == 0) falls into a PRO body.
+        if ((U.og & 3) == 0 && (!PRO || U.og >= 0)) {
+            if (!PRO || U.og > 0) {
+                const uint32_t word = ~__builtin_amdgcn_alignbit(L.prev, L.acc, 1);
+#if AMR_K1_DIAG == 3
+                L.xs ^= word * 0x9e3779b9u + U.wi;   // keep the computation alive without writing the bitstream
+#endif
+                if (G::NW <= 32 || U.wi < (uint32_t)G::NW0) L.ow0[U.wi] = word;
+                else L.ow1[U.wi - G::NW0] = word;
+                U.wi += 1;
+                if (U.wi == (uint32_t)G::NW && AMR_K1_DIAG != 3) k1_flush<CL>(L, U, qrow, G::NW);
+            }
             L.prev = L.acc;
         }
     }
@@ -230,8 +322,6 @@ template <int CL, bool TAIL>
 __global__ __launch_bounds__(64, 2) void k1_demod(const K1Args a)
 {
     using G = K1Geom<CL>;
-    // Two LDS objects on purpose: with distinct objects hipcc can prove that the LUT loads do not
-    // alias the LDS-DMA destination and does not put s_waitcnt vmcnt(0) in front of them.
     __shared__ __attribute__((aligned(16))) uint8_t tiles[2 * kTileBuf];
     __shared__ __attribute__((aligned(16))) float lut[256];
     const uint32_t tiles_lds = (uint32_t)(uintptr_t)(lds_ptr_t)tiles;
@@ -252,34 +342,52 @@ __global__ __launch_bounds__(64, 2) void k1_demod(const K1Args a)
     const uint32_t voff_e = rl * bs2 + colx * 16;
     const uint32_t voff_o = rl * bs2 + (colx ^ 4) * 16;
     // consumer role: lane reads row `lane`, column gt, at the swizzled slot
-    const uint32_t rd_base = lane * kTileBytes;
-    const uint32_t rd_xor = ((lane >> 1) & 7) * 16;
+    const uint32_t rdv = lane * kTileBytes | ((lane >> 1) & 7) * 16;
     const uint32_t zlim = (a.zero_halo && b == 0) ? G::WARM : G::SKIP;
-    uint32_t *qrow = a.qt + (size_t)(wg + 1) * kRows * wpb + lane;
+    uint32_t *qrow = a.qt + (size_t)(wg + 1) * kRows * wpb;   // uniform: this wave-tile of the bitstream
 
     K1Lane<CL> L;
 #pragma unroll
     for (int r = 0; r < G::RING; ++r) { L.hc[r] = 0.0f; L.hd[r] = 0.0f; }
     L.acc = 0;
     L.prev = 0;
+    L.xs = 0;
 
     K1Uni U;
     U.G = 0;
     U.og = -(G::WARM / 8);
     U.ngroups = (G::HBA / 2 + a.block_size) / 8;
     U.ntiles = U.ngroups / 8;
+    U.wi = 0;
+    U.wdone = 0;
+    U.st = 0;
 
-    k1_prefetch<CL, TAIL>(a, tiles, wg, 0, 0, lane, voff_e, voff_o, rows_valid);
-    L.row = k1_fetch_group<CL, TAIL>(0, U, a, tiles_lds, tiles, wg, lane, rd_base, rd_xor, voff_e, voff_o, rows_valid);
+    // pipeline prologue: tile 0, the LUT values of group 0, the row of group 1
+    U.F = 0;
+    U.roff = 0;
+    k1_prefetch<CL, TAIL>(a, tiles_lds, wg, 0, 0, lane, voff_e, voff_o, rows_valid);
+    {
+        const uint4 row0 = k1_fetch_next<CL, TAIL>(U, a, tiles_lds, tiles, wg, lane, rdv, voff_e, voff_o, rows_valid);
+        const uint32_t dw[4] = {row0.x, row0.y, row0.z, row0.w};
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const uint32_t v = dw[k >> 1] >> ((k & 1) * 16);
+            L.li[k] = lut[v & 0xff];
+            L.lq[k] = lut[(v >> 8) & 0xff];
+        }
+        L.row1 = k1_fetch_next<CL, TAIL>(U, a, tiles_lds, tiles, wg, lane, rdv, voff_e, voff_o, rows_valid);
+    }
 
-    const uint32_t nbodies = (U.ngroups + G::GPB - 1) / G::GPB;
+    const uint32_t nfull = U.ngroups / G::GPB;   // whole bodies; the rest goes through the checked body
     uint32_t body = 0;
-    for (; body < (uint32_t)G::NPB && body < nbodies; ++body)
-        k1_body<CL, true, TAIL>(L, U, a, tiles_lds, tiles, lut, wg, lane, rd_base, rd_xor, zlim, voff_e, voff_o,
-                                rows_valid, qrow);
-    for (; body < nbodies; ++body)
-        k1_body<CL, false, TAIL>(L, U, a, tiles_lds, tiles, lut, wg, lane, rd_base, rd_xor, zlim, voff_e, voff_o,
-                                 rows_valid, qrow);
+    for (; body < (uint32_t)G::NPB && body < nfull; ++body)
+        k1_body<CL, true, false, TAIL>(L, U, a, tiles_lds, tiles, lut, wg, lane, rdv, zlim, voff_e, voff_o, rows_valid, qrow);
+    for (; body < nfull; ++body)
+        k1_body<CL, false, false, TAIL>(L, U, a, tiles_lds, tiles, lut, wg, lane, rdv, zlim, voff_e, voff_o, rows_valid, qrow);
+    if (U.G < U.ngroups)
+        k1_body<CL, true, true, TAIL>(L, U, a, tiles_lds, tiles, lut, wg, lane, rdv, zlim, voff_e, voff_o, rows_valid, qrow);
+    if (U.wi && AMR_K1_DIAG != 3) k1_flush<CL>(L, U, qrow, U.wi);
+    if (AMR_K1_DIAG == 3) qrow[lane * 4] = L.xs;
 }
 
 }  // namespace amr

@@ -56,6 +56,13 @@ struct K2Args {
     SearchGeom g;
 };
 
+// Index of word w (32 decisions) of tiled row R (row 64 + b = batch block b; rows 0..63 = history tile) in the
+// "tiled4" bitstream K1 writes: per 64-row tile, 4-word chunks, a row's chunk = 16 contiguous bytes.
+__device__ __forceinline__ size_t qt_index(uint64_t R, uint32_t w, uint32_t lg_wpb)
+{
+    return ((R >> 6) << (6 + lg_wpb)) + ((size_t)(w >> 2) << 8) + ((R & 63) << 2) + (w & 3);
+}
+
 // 32 stream bits starting at bit `o` (word x = o>>5, shift sh = o&31) of row `l`; LDS tile is
 // [word][65]: column 64 holds row 0 of the next tile, so a row overrun is "same word index in
 // the next column".
@@ -75,8 +82,8 @@ __global__ __launch_bounds__(256) void k2_search_dense(const K2Args a)
     uint32_t *wave_tot = lds + wpb * 65;  // [4] wave totals for the block scan
 
     const uint32_t *src = a.qt + (size_t)T * tile_words;
-    for (uint32_t i = tid; i < tile_words; i += 256) lds[(i >> 6) * 65 + (i & 63)] = src[i];
-    for (uint32_t w = tid; w < wpb; w += 256) lds[w * 65 + 64] = src[tile_words + (w << 6)];
+    for (uint32_t i = tid; i < tile_words; i += 256) lds[((i >> 8) * 4 + (i & 3)) * 65 + ((i >> 2) & 63)] = src[i];
+    for (uint32_t w = tid; w < wpb; w += 256) lds[w * 65 + 64] = src[tile_words + ((w >> 2) << 8) + (w & 3)];
     __syncthreads();
 
     uint32_t running[kMaxPre];
@@ -196,13 +203,13 @@ __global__ __launch_bounds__(256) void k2_search_fast(const K2Args a)
     {
         const uint4 *src4 = reinterpret_cast<const uint4 *>(a.qt + (size_t)T * tile_words);
         for (uint32_t i = tid; i < tile_words / 4; i += 256) {
-            const uint4 x = src4[i];
-            const uint32_t w = i >> 4, l4 = (i & 15) * 4;
-            uint32_t *d = tile + w * 65 + l4;
-            d[0] = x.x; d[1] = x.y; d[2] = x.z; d[3] = x.w;
+            const uint4 x = src4[i];                      // words 4c..4c+3 of row l
+            const uint32_t c = i >> 6, l = i & 63;
+            uint32_t *d = tile + (c * 4) * 65 + l;
+            d[0] = x.x; d[65] = x.y; d[130] = x.z; d[195] = x.w;
         }
         const uint32_t *nxt = a.qt + (size_t)(T + 1) * tile_words;
-        for (uint32_t w = tid; w < wpb; w += 256) tile[w * 65 + 64] = nxt[(size_t)w << 6];
+        for (uint32_t w = tid; w < wpb; w += 256) tile[w * 65 + 64] = nxt[((w >> 2) << 8) + (w & 3)];
     }
     __syncthreads();
 
@@ -411,7 +418,7 @@ __device__ __forceinline__ uint32_t k3_bit(const uint32_t *qt, int64_t n, const 
     const uint64_t u = (uint64_t)(n + ((int64_t)64 << g.lg_block_size));
     const uint64_t R = u >> g.lg_block_size;
     const uint32_t b = (uint32_t)u & (g.block_size - 1);
-    const uint32_t word = qt[((R >> 6) << (6 + g.lg_wpb)) + ((b >> 5) << 6) + (R & 63)];
+    const uint32_t word = qt[qt_index(R, b >> 5, g.lg_wpb)];
     return (word >> (31 - (b & 31))) & 1u;
 }
 
@@ -463,12 +470,12 @@ __global__ __launch_bounds__(1024) void k_hist_update(const HistArgs a)
         const uint32_t j = i >> a.lg_wpb, w = i & (a.wpb - 1);
         // new history row j = stream row (n_blocks - hr + j) of the batch; negative -> old history
         const int64_t srow = (int64_t)64 + a.n_blocks - a.hr + j;  // tiled row index (tile 0 rows 0..63 = old history)
-        tmp[i] = a.qt[((srow >> 6) << (6 + a.lg_wpb)) + (w << 6) + (srow & 63)];
+        tmp[i] = a.qt[qt_index((uint64_t)srow, w, a.lg_wpb)];
     }
     __syncthreads();
     for (uint32_t i = threadIdx.x; i < n; i += 1024) {
         const uint32_t j = i >> a.lg_wpb, w = i & (a.wpb - 1);
-        a.qt_next[(w << 6) + (64 - a.hr + j)] = tmp[i];
+        a.qt_next[qt_index(64 - a.hr + j, w, a.lg_wpb)] = tmp[i];
     }
 }
 
@@ -480,7 +487,7 @@ __global__ void k_untile(const uint32_t *qt, uint32_t *out, uint32_t n_blocks, u
     if (i >= n) return;
     const uint64_t R = 64 + (i >> lg_wpb);
     const uint32_t w = (uint32_t)i & ((1u << lg_wpb) - 1);
-    const uint32_t v = qt[((R >> 6) << (6 + lg_wpb)) + (w << 6) + (R & 63)];
+    const uint32_t v = qt[qt_index(R, w, lg_wpb)];
     out[i] = __builtin_bswap32(v);
 }
 
