@@ -25,6 +25,14 @@ namespace {
 
 thread_local std::string g_last_error;
 
+// AMR_DEBUG_SYNC=1: synchronise and log after every kernel (localises a faulting kernel)
+bool debug_sync() { static const bool on = getenv("AMR_DEBUG_SYNC") != nullptr; return on; }
+#define AMR_DBG(st, what)                                                                  \
+    do {                                                                                   \
+        if (debug_sync()) { fprintf(stderr, "[amr] %s ...", what); fflush(stderr);         \
+            hipError_t e_ = hipStreamSynchronize(st); fprintf(stderr, " %s\n", hipGetErrorString(e_)); } \
+    } while (0)
+
 amr_status fail(amr_status s, const char *what, hipError_t e = hipSuccess)
 {
     char buf[512];
@@ -230,14 +238,17 @@ amr_status enqueue_search(amr_handle *h, Slot &s)
                                     (int)lds2));
         hipLaunchKernelGGL(amr::k2_search_dense, dim3(s.n_tiles), dim3(256), lds2, st, k2);
     }
+    AMR_DBG(st, "k2_search");
     amr::ScanArgs sc{s.d_counts, s.d_offsets, s.d_offs_pre, s.n_tiles, n_pre};
     hipLaunchKernelGGL(amr::k2s_scan, dim3(1), dim3(1024), 0, st, sc);
+    AMR_DBG(st, "k2s_scan");
     amr::K3Args k3{};
     k3.qt = s.d_qt; k3.counts = s.d_counts; k3.offsets = s.d_offsets; k3.staging = s.d_staging;
-    k3.hit_block = s.d_hit_block; k3.hit_idx = s.d_hit_idx; k3.pkt = s.d_pkt; k3.out_cap = s.out_cap;
+    k3.hit_block = s.d_hit_block; k3.hit_idx = s.d_hit_idx; k3.pkt = s.d_pkt; k3.out_cap = s.out_cap; k3.overflow = s.d_overflow;
     k3.block_base = s.calls_base; k3.n_tiles = s.n_tiles; k3.cap = s.stage_cap; k3.g = h->sg;
     hipLaunchKernelGGL(amr::k3_slice, dim3(s.n_tiles, n_pre), dim3(256), 0, st, k3);
     HIP_TRY(hipGetLastError());
+    AMR_DBG(st, "k3_slice");
     HIP_TRY(hipEventRecord(s.ev2, st));
     HIP_TRY(hipMemcpyAsync(s.h_off, s.d_offs_pre, (n_pre + 1) * 8, hipMemcpyDeviceToHost, st));
     HIP_TRY(hipMemcpyAsync(s.h_ovf, s.d_overflow, 4, hipMemcpyDeviceToHost, st));
@@ -276,6 +287,7 @@ amr_status submit(amr_handle *h, const uint8_t *d_iq, size_t n_blocks, bool sear
     if (full) { k1.wg_first = 0; launch_k1<false>(h->geom.chip_length, dim3(full), st, k1); }
     if (rem) { k1.wg_first = full; launch_k1<true>(h->geom.chip_length, dim3(1), st, k1); }
     HIP_TRY(hipGetLastError());
+    AMR_DBG(st, "k1_demod");
     HIP_TRY(hipEventRecord(s.ev1, st));
     if (search) AMR_TRY(enqueue_search(h, s));
     else HIP_TRY(hipEventRecord(s.ev2, st));
@@ -285,6 +297,7 @@ amr_status submit(amr_handle *h, const uint8_t *d_iq, size_t n_blocks, bool sear
     amr::HistArgs ha{s.d_qt, other.d_qt, (uint32_t)n_blocks, h->hist_rows, h->sg.wpb, h->sg.lg_wpb};
     hipLaunchKernelGGL(amr::k_hist_update, dim3(1), dim3(1024), (size_t)h->hist_rows * h->sg.wpb * 4, st, ha);
     HIP_TRY(hipGetLastError());
+    AMR_DBG(st, "k_hist_update");
     HIP_TRY(hipMemcpyAsync(h->d_carry, d_iq + n_blocks * (size_t)h->geom.block_size2 - h->halo_bytes, h->halo_bytes,
                            hipMemcpyDeviceToDevice, st));
     HIP_TRY(hipEventRecord(s.ev_done, st));

@@ -407,6 +407,7 @@ struct K3Args {
     uint64_t block_base;   // call index of the first block of the batch
     uint8_t *pkt;          // [out_cap * pkt_bytes]
     uint64_t out_cap;
+    const uint32_t *overflow;   // K2's overflow word: non-zero = the host will grow a capacity and search again
     uint32_t n_tiles;
     uint32_t cap;
     SearchGeom g;
@@ -426,6 +427,9 @@ __global__ __launch_bounds__(256) void k3_slice(const K3Args a)
 {
     const SearchGeom &g = a.g;
     const uint32_t T = blockIdx.x, q = blockIdx.y;
+    // After an overflow the staging slots are incomplete (a wave whose sparse list overflowed counted hits it
+    // never emitted), so their contents must not be used as positions; the host re-runs the search anyway.
+    if (*a.overflow) return;
     const uint32_t cnt = a.counts[q * a.n_tiles + T];
     if (cnt == 0) return;
     const uint64_t off = a.offsets[q * a.n_tiles + T];
@@ -436,6 +440,7 @@ __global__ __launch_bounds__(256) void k3_slice(const K3Args a)
         const uint64_t slot = off + h;
         if (slot >= a.out_cap) continue;
         const uint32_t local = src[h];
+        if (local >= (64u << g.lg_block_size)) continue;   // defensive: never index the bitstream with a bad position
         // n relative to batch sample 0 of the first preamble bit
         const int64_t n = ((int64_t)T * 64 - 64) * (int64_t)g.block_size + local;
         if (j == 0) {
