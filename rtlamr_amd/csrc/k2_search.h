@@ -167,17 +167,21 @@ __global__ __launch_bounds__(256) void k2_search_dense(const K2Args a)
 // ---------------------------------------------------------------------------------------------
 // k2_search_fast<NPRE>: the production search.  Same result as k2_search_dense, organised for the
 // common case that hits are sparse:
-//   * lane = row (reference block) of the tile, exactly the layout K1 stored, so the tile is copied
-//     to LDS as it lies in HBM ([word][65], column 64 = row 0 of the next tile);
-//   * a wave handles 4 consecutive words (128 positions) of all 64 rows per step: the per-tap scalar
-//     work (offset, shift, preamble bit) is shared by 4 words and the 4 (5 when the window is
-//     shifted by 16 bits) LDS reads use immediate offsets;
-//   * no barrier in the search loop: non-zero result masks are appended to a small per-wave list;
-//     a per-tile exclusive scan over (row, wave) popcounts then gives every list entry its rank, and
-//     each entry is emitted by 32 lanes at once (lane b = bit b), in stream order.
+//   * lane = row (reference block) of the tile, the unit K1 computed, so the tile is laid out in LDS as
+//     [word][65] (column 64 = row 0 of the next tile) and a lane's window never leaves its column pair;
+//   * stage 1: a wave handles 4 consecutive words (128 positions) of all 64 rows per step and applies
+//     only the first D taps (D = 9 + log2 NPRE), without any early-out test: in noise 2^-D of the
+//     positions survive.  The per-tap scalar work (offset, shift, preamble bit) is shared by 4 words,
+//     the 4-5 LDS reads use immediate offsets and are issued one tap ahead of their use;
+//   * the (rare) non-zero masks go to a small per-wave list; stage 2 finishes the remaining taps on
+//     the list entries, one entry per lane, and compacts the list in place (order preserved);
+//   * a per-tile exclusive scan over (row, wave) popcounts then gives every surviving entry its rank,
+//     and each entry is emitted by 32 lanes at once (lane b = bit b), in stream order.
 // If a wave's list overflows (pathological input), bit 1 of *overflow is set and the host re-runs the
 // tile set with k2_search_dense.
-constexpr int kListCap = 256;  // (key, mask) entries per wave
+constexpr int kListCap = 448;  // (key, mask) entries per wave
+
+__device__ __forceinline__ uint32_t k2_depth(uint32_t npre) { return 9u + (npre > 2 ? 2u : npre > 1 ? 1u : 0u); }
 
 template <int NPRE>
 __global__ __launch_bounds__(256) void k2_search_fast(const K2Args a)
@@ -198,8 +202,9 @@ __global__ __launch_bounds__(256) void k2_search_fast(const K2Args a)
     uint32_t plen[NPRE];
 #pragma unroll
     for (int q = 0; q < NPRE; ++q) { pbits[q] = a.g.pre_bits[q]; plen[q] = a.g.pre_len[q]; }
+    const uint32_t D = k2_depth(NPRE) < maxL ? k2_depth(NPRE) : maxL;   // stage-1 depth
 
-    // ---- stage the tile: straight copy of the HBM layout, 16 bytes per lane per load ----
+    // ---- stage the tile: 16 bytes per lane per load (4 words of one row), transposed into [word][row] ----
     {
         const uint4 *src4 = reinterpret_cast<const uint4 *>(a.qt + (size_t)T * tile_words);
         for (uint32_t i = tid; i < tile_words / 4; i += 256) {
@@ -210,6 +215,8 @@ __global__ __launch_bounds__(256) void k2_search_fast(const K2Args a)
         }
         const uint32_t *nxt = a.qt + (size_t)(T + 1) * tile_words;
         for (uint32_t w = tid; w < wpb; w += 256) tile[w * 65 + 64] = nxt[((w >> 2) << 8) + (w & 3)];
+#pragma unroll
+        for (int q = 0; q < NPRE; ++q) cnts[q * 256 + tid] = 0;
     }
     __syncthreads();
 
@@ -219,14 +226,30 @@ __global__ __launch_bounds__(256) void k2_search_fast(const K2Args a)
     const uint32_t w_lo = (uint32_t)(lo64 < 0 ? 0 : lo64 > (int64_t)wpb ? wpb : lo64);
     const uint32_t w_hi = (uint32_t)(hi64 < 0 ? 0 : hi64 > (int64_t)wpb ? wpb : hi64);
 
-    uint32_t cnt[NPRE];
-#pragma unroll
-    for (int q = 0; q < NPRE; ++q) cnt[q] = 0;
     uint32_t list_n = 0;                                // wave-uniform
     uint32_t *mylist = lists + v * (kListCap * 2);
     const uint32_t wq = wpb >> 2;                       // words per wave
     const uint32_t *lane_tile = tile + lane;
 
+    // window words A[0..4] of tap p for the step that starts at word w0 (uniform addressing)
+    auto load_tap = [&](uint32_t w0, uint32_t p, uint32_t (&A)[5]) {
+        const uint32_t o = p * SL;
+        const uint32_t x0 = w0 + (o >> 5);
+        const uint32_t xm = x0 & wpb_mask;
+        if (xm + 5 <= wpb) {                             // all words in one row: immediate offsets
+            const uint32_t *src = lane_tile + xm * 65 + (x0 >> lg_wpb);
+#pragma unroll
+            for (int j = 0; j < 5; ++j) A[j] = src[j * 65];
+        } else {                                         // the window crosses into the next row
+#pragma unroll
+            for (int j = 0; j < 5; ++j) {
+                const uint32_t x = x0 + j;
+                A[j] = lane_tile[(x & wpb_mask) * 65 + (x >> lg_wpb)];
+            }
+        }
+    };
+
+    // ---- stage 1 ----
     for (uint32_t c = 0; c < (wq >> 2); ++c) {
         const uint32_t w0 = v * wq + 4 * c;
         uint32_t M[NPRE][4];
@@ -236,43 +259,23 @@ __global__ __launch_bounds__(256) void k2_search_fast(const K2Args a)
 #pragma unroll
             for (int q = 0; q < NPRE; ++q) M[q][j] = ok;
         }
-        for (uint32_t p = 0; p < maxL; ++p) {
-            if (p >= 8) {   // in noise all 8192 positions of a step die after ~14 taps
-                uint32_t any = 0;
-#pragma unroll
-                for (int q = 0; q < NPRE; ++q) any |= (M[q][0] | M[q][1]) | (M[q][2] | M[q][3]);
-                if (!__any(any != 0)) break;
-            }
-            const uint32_t o = p * SL;
-            const uint32_t x0 = w0 + (o >> 5);
-            const bool shifted = (o & 31) != 0;          // SL multiple of 16: shift is 0 or 16
-            const uint32_t xm = x0 & wpb_mask;
+        uint32_t An[5];
+        load_tap(w0, 0, An);
+        for (uint32_t p = 0; p < D; ++p) {
             uint32_t A[5];
-            if (xm + 5 <= wpb) {                         // all words in one row: immediate offsets
-                const uint32_t *src = lane_tile + xm * 65 + (x0 >> lg_wpb);
 #pragma unroll
-                for (int j = 0; j < 4; ++j) A[j] = src[j * 65];
-                A[4] = shifted ? src[4 * 65] : 0;
-            } else {                                     // the window crosses into the next row
-#pragma unroll
-                for (int j = 0; j < 5; ++j) {
-                    const uint32_t x = x0 + j;
-                    A[j] = lane_tile[(x & wpb_mask) * 65 + (x >> lg_wpb)];
-                }
-            }
+            for (int j = 0; j < 5; ++j) A[j] = An[j];
+            if (p + 1 < D) load_tap(w0, p + 1, An);      // one tap ahead: no wait between a tap's loads and its use
+            const bool shifted = ((p * SL) & 31) != 0;   // SL multiple of 16: shift is 0 or 16
             uint32_t W[4];
 #pragma unroll
             for (int j = 0; j < 4; ++j) W[j] = shifted ? __builtin_amdgcn_alignbit(A[j], A[j + 1], 16) : A[j];
 #pragma unroll
             for (int q = 0; q < NPRE; ++q) {
                 if (p < plen[q]) {
-                    if ((pbits[q] >> p) & 1) {
+                    const uint32_t inv = ((pbits[q] >> p) & 1) ? 0u : 0xffffffffu;
 #pragma unroll
-                        for (int j = 0; j < 4; ++j) M[q][j] &= W[j];
-                    } else {
-#pragma unroll
-                        for (int j = 0; j < 4; ++j) M[q][j] &= ~W[j];
-                    }
+                    for (int j = 0; j < 4; ++j) M[q][j] &= W[j] ^ inv;
                 }
             }
         }
@@ -291,16 +294,47 @@ __global__ __launch_bounds__(256) void k2_search_fast(const K2Args a)
                         mylist[idx * 2 + 1] = m;
                     }
                     list_n += __popcll(b);
-                    cnt[q] += __popc(m);
                 }
             }
         }
     }
 
-    // ---- ranks: exclusive scan over (row, wave) in stream order, per preamble ----
+    // ---- stage 2: remaining taps on the list entries (one per lane), compaction in place ----
+    const uint32_t n_cand = list_n < (uint32_t)kListCap ? list_n : (uint32_t)kListCap;
+    uint32_t n_keep = 0;                                // wave-uniform
+    for (uint32_t e0 = 0; e0 < n_cand; e0 += 64) {
+        const uint32_t e = e0 + lane;
+        uint32_t key = 0, m = 0;
+        if (e < n_cand) { key = mylist[e * 2]; m = mylist[e * 2 + 1]; }
+        const uint32_t q = key >> 16, l = (key >> 8) & 63, w = key & 0xff;
+        uint64_t pb = pbits[0];
+        uint32_t pl = plen[0];
 #pragma unroll
-    for (int q = 0; q < NPRE; ++q) cnts[q * 256 + lane * 4 + v] = cnt[q];
+        for (int qq = 1; qq < NPRE; ++qq)
+            if (q == (uint32_t)qq) { pb = pbits[qq]; pl = plen[qq]; }
+        for (uint32_t p = D; p < maxL; ++p) {
+            if (!__any(m != 0)) break;
+            const uint32_t o = p * SL;
+            const uint32_t x = w + (o >> 5);
+            uint32_t Wd = tile[(x & wpb_mask) * 65 + l + (x >> lg_wpb)];
+            if (o & 31) {
+                const uint32_t B = tile[((x + 1) & wpb_mask) * 65 + l + ((x + 1) >> lg_wpb)];
+                Wd = __builtin_amdgcn_alignbit(Wd, B, 16);
+            }
+            if (p < pl) m &= ((pb >> p) & 1) ? Wd : ~Wd;
+        }
+        const uint64_t b = __ballot(m != 0);
+        if (m != 0) {   // survivors move to the front, order preserved (slot <= e, earlier chunks already read)
+            const uint32_t slot = n_keep + __builtin_amdgcn_mbcnt_hi((uint32_t)(b >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)b, 0));
+            mylist[slot * 2] = key;
+            mylist[slot * 2 + 1] = m;
+            atomicAdd(&cnts[q * 256 + l * 4 + v], __popc(m));
+        }
+        n_keep += __popcll(b);
+    }
     __syncthreads();
+
+    // ---- ranks: exclusive scan over (row, wave) in stream order, per preamble ----
     uint32_t total[NPRE];
 #pragma unroll
     for (int q = 0; q < NPRE; ++q) {
@@ -320,12 +354,11 @@ __global__ __launch_bounds__(256) void k2_search_fast(const K2Args a)
         __syncthreads();
     }
 
-    // ---- emit: every list entry by 32 lanes at once, lane b = bit b (MSB first = stream order) ----
+    // ---- emit: every surviving entry by 32 lanes at once, lane b = bit b (MSB first = stream order) ----
     uint32_t run[NPRE];
 #pragma unroll
     for (int q = 0; q < NPRE; ++q) run[q] = 0;
-    const uint32_t n_emit = list_n < (uint32_t)kListCap ? list_n : (uint32_t)kListCap;
-    for (uint32_t e = 0; e < n_emit; ++e) {
+    for (uint32_t e = 0; e < n_keep; ++e) {
         const uint32_t key = __builtin_amdgcn_readfirstlane(mylist[e * 2]);
         const uint32_t m = __builtin_amdgcn_readfirstlane(mylist[e * 2 + 1]);
         const uint32_t q = key >> 16, l = (key >> 8) & 63, w = key & 0xff;
