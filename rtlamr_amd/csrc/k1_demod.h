@@ -248,7 +248,8 @@ __device__ __forceinline__ void k1_flush(K1Lane<CL> &L, K1Uni &U, uint32_t *qbas
 //   3. 8 x (magnitude add, running sum, two differences, sign bit) for group G on the LUT values gathered
 //      during group G-1 -- no memory access, no wait.
 // sched_barrier keeps hipcc from re-interleaving this into a load-wait-use chain per sample.
-// PRO: bodies that overlap the warm-up (zero-magnitude predicate, no output yet); CHECK: the last, partial body.
+// PRO: the zero-magnitude predicate of a fresh Decoder (decode.go:144), needed only by the wave that holds stream
+// block 0 while its first SymbolLength samples pass; CHECK: the last, partial body.
 template <int CL, bool PRO, bool CHECK, bool TAIL>
 __device__ __forceinline__ void k1_body(K1Lane<CL> &L, K1Uni &U, const K1Args &a, uint32_t tiles_lds,
                                         const uint8_t *tiles, const float *lut, uint32_t wg, uint32_t lane, uint32_t rdv,
@@ -300,10 +301,9 @@ __device__ __forceinline__ void k1_body(K1Lane<CL> &L, K1Uni &U, const K1Args &a
         U.og += 1;
         // Output i leaves the filter at step WARM-1+i, i.e. one step before a group boundary: at a
         // boundary acc holds outputs [32m+1 .. 32m+32]; output 32m is bit 0 of acc at the previous boundary.
-        // WARM/8 is a multiple of 8, so word boundaries are the groups with G % 4 == 0; the first one
-        // (og == 0) falls into a PRO body.
-        if ((U.og & 3) == 0 && (!PRO || U.og >= 0)) {
-            if (!PRO || U.og > 0) {
+        // WARM/8 is a multiple of 8, so word boundaries are the groups with G % 4 == 0.
+        if ((U.og & 3) == 0 && U.og >= 0) {
+            if (U.og > 0) {
                 const uint32_t word = ~__builtin_amdgcn_alignbit(L.prev, L.acc, 1);
 #if AMR_K1_DIAG == 3
                 L.xs ^= word * 0x9e3779b9u + U.wi;   // keep the computation alive without writing the bitstream
@@ -343,7 +343,11 @@ __global__ __launch_bounds__(64, 2) void k1_demod(const K1Args a)
     const uint32_t voff_o = rl * bs2 + (colx ^ 4) * 16;
     // consumer role: lane reads row `lane`, column gt, at the swizzled slot
     const uint32_t rdv = lane * kTileBytes | ((lane >> 1) & 7) * 16;
-    const uint32_t zlim = (a.zero_halo && b == 0) ? G::WARM : G::SKIP;
+    // The lane stream starts HBA bytes before the block (whole cache lines); its first SKIP samples are not
+    // part of the reference's window at all, so consumption simply starts at group SKIP/8 with all-zero rings.
+    // Only stream block 0 of a fresh Decoder needs more: its SymbolLength history samples are magnitude 0.0.
+    const bool fresh = a.zero_halo && wg == 0;
+    const uint32_t zlim = (fresh && b == 0) ? G::WARM : G::SKIP;
     uint32_t *qrow = a.qt + (size_t)(wg + 1) * kRows * wpb;   // uniform: this wave-tile of the bitstream
 
     K1Lane<CL> L;
@@ -354,8 +358,8 @@ __global__ __launch_bounds__(64, 2) void k1_demod(const K1Args a)
     L.xs = 0;
 
     K1Uni U;
-    U.G = 0;
-    U.og = -(G::WARM / 8);
+    U.G = G::SKIP / 8;
+    U.og = -(G::WARM / 8) + G::SKIP / 8;
     U.ngroups = (G::HBA / 2 + a.block_size) / 8;
     U.ntiles = U.ngroups / 8;
     U.wi = 0;
@@ -363,9 +367,14 @@ __global__ __launch_bounds__(64, 2) void k1_demod(const K1Args a)
     U.st = 0;
 
     // pipeline prologue: tile 0, the LUT values of group 0, the row of group 1
-    U.F = 0;
-    U.roff = 0;
+    U.F = G::SKIP / 8;
+    U.roff = (G::SKIP / 8) * 16;     // SKIP < 64: still inside tile 0
     k1_prefetch<CL, TAIL>(a, tiles_lds, wg, 0, 0, lane, voff_e, voff_o, rows_valid);
+    if (G::SKIP != 0) {   // consumption starts inside tile 0: do here what k1_fetch_next does on a tile boundary
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (1 < U.ntiles && AMR_K1_DIAG != 1)
+            k1_prefetch<CL, TAIL>(a, tiles_lds, wg, 1, kTileBuf, lane, voff_e, voff_o, rows_valid);
+    }
     {
         const uint4 row0 = k1_fetch_next<CL, TAIL>(U, a, tiles_lds, tiles, wg, lane, rdv, voff_e, voff_o, rows_valid);
         const uint32_t dw[4] = {row0.x, row0.y, row0.z, row0.w};
@@ -378,10 +387,11 @@ __global__ __launch_bounds__(64, 2) void k1_demod(const K1Args a)
         L.row1 = k1_fetch_next<CL, TAIL>(U, a, tiles_lds, tiles, wg, lane, rdv, voff_e, voff_o, rows_valid);
     }
 
-    const uint32_t nfull = U.ngroups / G::GPB;   // whole bodies; the rest goes through the checked body
+    const uint32_t nfull = (U.ngroups - G::SKIP / 8) / G::GPB;   // whole bodies; the rest goes through the checked body
     uint32_t body = 0;
-    for (; body < (uint32_t)G::NPB && body < nfull; ++body)
-        k1_body<CL, true, false, TAIL>(L, U, a, tiles_lds, tiles, lut, wg, lane, rdv, zlim, voff_e, voff_o, rows_valid, qrow);
+    if (fresh)
+        for (; body < (uint32_t)G::NPB && body < nfull; ++body)
+            k1_body<CL, true, false, TAIL>(L, U, a, tiles_lds, tiles, lut, wg, lane, rdv, zlim, voff_e, voff_o, rows_valid, qrow);
     for (; body < nfull; ++body)
         k1_body<CL, false, false, TAIL>(L, U, a, tiles_lds, tiles, lut, wg, lane, rdv, zlim, voff_e, voff_o, rows_valid, qrow);
     if (U.G < U.ngroups)
