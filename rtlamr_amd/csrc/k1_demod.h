@@ -46,6 +46,10 @@
 #ifndef AMR_K1_DIAG
 #define AMR_K1_DIAG 0
 #endif
+// 1: LUT gathers one group ahead of their use (32 more VGPRs), 0: gathers, row read and one wait per group
+#ifndef AMR_K1_PIPE
+#define AMR_K1_PIPE 0   // measured on MI355X (SCM chip 72, 1 GiB): 0.231 ms without, 0.239 ms with (and 40 fewer free VGPRs)
+#endif
 
 namespace amr {
 
@@ -79,11 +83,10 @@ struct K1Geom {
     // into the saturated read stream costs far more than the bytes (tools/sst_bench.hip: 64 MiB written per
     // tile step +35 % kernel time, the same bytes in a few chip-wide bursts +3 %), so the bits are held in
     // whatever VGPRs the csum rings leave free (256 per lane at 2 waves per SIMD) and written in bursts.
-    static constexpr int NW_FREE = 256 - 2 * RING - 88;
 #ifdef AMR_K1_NW
     static constexpr int NW = AMR_K1_NW;
 #else
-    static constexpr int NW = NW_FREE >= 64 ? 64 : NW_FREE >= 48 ? 48 : NW_FREE >= 32 ? 32 : NW_FREE >= 16 ? 16 : NW_FREE >= 8 ? 8 : 4;
+    static constexpr int NW = AMR_K1_PIPE ? (RING <= 80 ? 8 : 4) : (RING <= 80 ? 32 : RING <= 88 ? 16 : 4);
 #endif
     static constexpr int NW0 = NW > 32 ? 32 : NW;      // words in the first register vector
     static constexpr int NW1 = NW > 32 ? NW - 32 : 4;  // words in the second (a 4-word dummy when unused)
@@ -265,6 +268,7 @@ __device__ __forceinline__ void k1_body(K1Lane<CL> &L, K1Uni &U, const K1Args &a
         L.row1 = k1_fetch_next<CL, TAIL>(U, a, tiles_lds, tiles, wg, lane, rdv, voff_e, voff_o, rows_valid);
 #else
         const uint32_t dw[4] = {L.row1.x, L.row1.y, L.row1.z, L.row1.w};
+#if AMR_K1_PIPE
         float nli[8], nlq[8];
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
@@ -279,6 +283,17 @@ __device__ __forceinline__ void k1_body(K1Lane<CL> &L, K1Uni &U, const K1Args &a
         }
         const uint4 row2 = k1_fetch_next<CL, TAIL>(U, a, tiles_lds, tiles, wg, lane, rdv, voff_e, voff_o, rows_valid);
         __builtin_amdgcn_sched_barrier(0);
+#else
+        // L.row1 holds group G itself here (the prologue fetched one group less): gather, fetch G+1, one wait
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const uint32_t v = dw[k >> 1] >> ((k & 1) * 16);
+            L.li[k] = lut[v & 0xff];                           // decode.go:222
+            L.lq[k] = lut[(v >> 8) & 0xff];
+        }
+        const uint4 row2 = k1_fetch_next<CL, TAIL>(U, a, tiles_lds, tiles, wg, lane, rdv, voff_e, voff_o, rows_valid);
+        __builtin_amdgcn_sched_barrier(0);
+#endif
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
             constexpr int R = G::RING;
@@ -293,8 +308,10 @@ __device__ __forceinline__ void k1_body(K1Lane<CL> &L, K1Uni &U, const K1Args &a
             L.hd[r] = d;
         }
         __builtin_amdgcn_sched_barrier(0);
+#if AMR_K1_PIPE
 #pragma unroll
         for (int k = 0; k < 8; ++k) { L.li[k] = nli[k]; L.lq[k] = nlq[k]; }
+#endif
         L.row1 = row2;
 #endif
         U.G += 1;
@@ -375,6 +392,9 @@ __global__ __launch_bounds__(64, 2) void k1_demod(const K1Args a)
         if (1 < U.ntiles && AMR_K1_DIAG != 1)
             k1_prefetch<CL, TAIL>(a, tiles_lds, wg, 1, kTileBuf, lane, voff_e, voff_o, rows_valid);
     }
+#if !AMR_K1_PIPE
+    L.row1 = k1_fetch_next<CL, TAIL>(U, a, tiles_lds, tiles, wg, lane, rdv, voff_e, voff_o, rows_valid);
+#else
     {
         const uint4 row0 = k1_fetch_next<CL, TAIL>(U, a, tiles_lds, tiles, wg, lane, rdv, voff_e, voff_o, rows_valid);
         const uint32_t dw[4] = {row0.x, row0.y, row0.z, row0.w};
@@ -386,6 +406,7 @@ __global__ __launch_bounds__(64, 2) void k1_demod(const K1Args a)
         }
         L.row1 = k1_fetch_next<CL, TAIL>(U, a, tiles_lds, tiles, wg, lane, rdv, voff_e, voff_o, rows_valid);
     }
+#endif
 
     const uint32_t nfull = (U.ngroups - G::SKIP / 8) / G::GPB;   // whole bodies; the rest goes through the checked body
     uint32_t body = 0;
