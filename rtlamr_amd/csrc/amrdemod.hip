@@ -206,7 +206,7 @@ amr_status ensure_capacity(amr_handle *h, Slot &s, size_t n_blocks)
 }
 
 // K2 + K2s + K3 for the batch held by slot s (may be re-run after a capacity overflow).
-amr_status enqueue_search(amr_handle *h, Slot &s)
+amr_status enqueue_search(amr_handle *h, Slot &s, bool rerun = false)
 {
     hipStream_t st = h->stream;
     const uint32_t n_pre = h->sg.n_pre;
@@ -221,7 +221,8 @@ amr_status enqueue_search(amr_handle *h, Slot &s)
     k2.n_lo = -(int64_t)h->geom.packet_length;
     k2.n_hi = (int64_t)s.n_blocks * bs - (int64_t)h->geom.packet_length;
     k2.g = h->sg;
-    HIP_TRY(hipMemsetAsync(s.d_overflow, 0, 4, st));
+    // the overflow word is zeroed by the previous batch's k_hist_update; only a re-run has to do it here
+    if (rerun) HIP_TRY(hipMemsetAsync(s.d_overflow, 0, 4, st));
     if (!h->dense_search && n_pre <= 4) {
         const size_t lds2 = amr::k2_fast_lds_bytes(h->sg.wpb, (int)n_pre);
 #define AMR_K2_CASE(N)                                                                                           \
@@ -239,7 +240,7 @@ amr_status enqueue_search(amr_handle *h, Slot &s)
         hipLaunchKernelGGL(amr::k2_search_dense, dim3(s.n_tiles), dim3(256), lds2, st, k2);
     }
     AMR_DBG(st, "k2_search");
-    amr::ScanArgs sc{s.d_counts, s.d_offsets, s.d_offs_pre, s.n_tiles, n_pre};
+    amr::ScanArgs sc{s.d_counts, s.d_offsets, s.d_offs_pre, s.n_tiles, n_pre, s.h_off, s.h_ovf, s.d_overflow};
     hipLaunchKernelGGL(amr::k2s_scan, dim3(1), dim3(1024), 0, st, sc);
     AMR_DBG(st, "k2s_scan");
     amr::K3Args k3{};
@@ -250,8 +251,6 @@ amr_status enqueue_search(amr_handle *h, Slot &s)
     HIP_TRY(hipGetLastError());
     AMR_DBG(st, "k3_slice");
     HIP_TRY(hipEventRecord(s.ev2, st));
-    HIP_TRY(hipMemcpyAsync(s.h_off, s.d_offs_pre, (n_pre + 1) * 8, hipMemcpyDeviceToHost, st));
-    HIP_TRY(hipMemcpyAsync(s.h_ovf, s.d_overflow, 4, hipMemcpyDeviceToHost, st));
     return AMR_OK;
 }
 
@@ -294,12 +293,11 @@ amr_status submit(amr_handle *h, const uint8_t *d_iq, size_t n_blocks, bool sear
 
     // state carried to the next batch (decode.go:165-166): last rows of this slot's bitstream become the
     // history tile of the OTHER slot (where the next batch runs); last HBA bytes of IQ become the carry
-    amr::HistArgs ha{s.d_qt, other.d_qt, (uint32_t)n_blocks, h->hist_rows, h->sg.wpb, h->sg.lg_wpb};
+    amr::HistArgs ha{s.d_qt, other.d_qt, (uint32_t)n_blocks, h->hist_rows, h->sg.wpb, h->sg.lg_wpb,
+                     d_iq + n_blocks * (size_t)h->geom.block_size2 - h->halo_bytes, h->d_carry, h->halo_bytes, other.d_overflow};
     hipLaunchKernelGGL(amr::k_hist_update, dim3(1), dim3(1024), (size_t)h->hist_rows * h->sg.wpb * 4, st, ha);
     HIP_TRY(hipGetLastError());
     AMR_DBG(st, "k_hist_update");
-    HIP_TRY(hipMemcpyAsync(h->d_carry, d_iq + n_blocks * (size_t)h->geom.block_size2 - h->halo_bytes, h->halo_bytes,
-                           hipMemcpyDeviceToDevice, st));
     HIP_TRY(hipEventRecord(s.ev_done, st));
     h->zero_halo = false;
     if (search) h->calls_done += n_blocks;
@@ -345,7 +343,7 @@ amr_status collect(amr_handle *h, amr_result *res)
             }
             if (!rerun) break;
             // the slot's bitstream is intact until the slot is reused, so the search can simply run again
-            AMR_TRY(enqueue_search(h, s));
+            AMR_TRY(enqueue_search(h, s, true));
             HIP_TRY(hipStreamSynchronize(h->stream));
         }
         if (total > s.host_cap) {
@@ -510,6 +508,7 @@ amr_status amr_create(const amr_protocol *protos, int32_t n_protos, int32_t devi
         if (e == hipSuccess) e = hipEventCreateWithFlags(&sl.ev_done, hipEventDisableTiming);
         if (e == hipSuccess) e = hipMalloc((void **)&sl.d_offs_pre, (AMR_MAX_PREAMBLES + 1) * 8);
         if (e == hipSuccess) e = hipMalloc((void **)&sl.d_overflow, 4);
+        if (e == hipSuccess) e = hipMemset(sl.d_overflow, 0, 4);
         if (e == hipSuccess) e = hipHostMalloc((void **)&sl.h_off, (AMR_MAX_PREAMBLES + 1) * 8, hipHostMallocDefault);
         if (e == hipSuccess) e = hipHostMalloc((void **)&sl.h_ovf, 4, hipHostMallocDefault);
     }

@@ -401,6 +401,11 @@ struct ScanArgs {
     uint64_t *offs_pre;  // [n_pre+1]
     uint32_t n_tiles;
     uint32_t n_pre;
+    // what the host needs to size / accept the result, written straight into pinned host memory (no D2H copies
+    // on the compute stream): the per-preamble bases and K2's overflow word
+    uint64_t *h_offs_pre;       // [n_pre+1]
+    uint32_t *h_overflow;
+    const uint32_t *overflow;
 };
 
 __global__ __launch_bounds__(1024) void k2s_scan(const ScanArgs a)
@@ -423,10 +428,10 @@ __global__ __launch_bounds__(1024) void k2s_scan(const ScanArgs a)
     uint64_t run = tid ? part[tid - 1] : 0;
     for (uint32_t i = lo; i < hi; ++i) {
         a.offsets[i] = run;
-        if (i % a.n_tiles == 0) a.offs_pre[i / a.n_tiles] = run;
+        if (i % a.n_tiles == 0) { a.offs_pre[i / a.n_tiles] = run; a.h_offs_pre[i / a.n_tiles] = run; }
         run += a.counts[i];
     }
-    if (tid == 1023) a.offs_pre[a.n_pre] = part[1023];
+    if (tid == 1023) { a.offs_pre[a.n_pre] = part[1023]; a.h_offs_pre[a.n_pre] = part[1023]; *a.h_overflow = *a.overflow; }
 }
 
 // K3: move each tile's hits to their final slot and slice the packets.
@@ -498,11 +503,20 @@ struct HistArgs {
     uint32_t n_blocks;  // rows in the batch just processed
     uint32_t hr;        // history rows kept = ceil(PL/BS) (<= 63)
     uint32_t wpb, lg_wpb;
+    // the other per-batch state, folded into this launch: the IQ halo of the next batch's block 0 (last HBA stream
+    // bytes, decode.go:165) and the reset of the overflow word the next batch's search will use
+    const uint8_t *carry_src;
+    uint8_t *carry_dst;
+    uint32_t carry_bytes;   // multiple of 16
+    uint32_t *ovf_next;
 };
 
 __global__ __launch_bounds__(1024) void k_hist_update(const HistArgs a)
 {
     extern __shared__ uint32_t tmp[];  // hr*wpb words
+    if (threadIdx.x < a.carry_bytes / 16)
+        reinterpret_cast<uint4 *>(a.carry_dst)[threadIdx.x] = reinterpret_cast<const uint4 *>(a.carry_src)[threadIdx.x];
+    if (threadIdx.x == 1023) *a.ovf_next = 0;
     const uint32_t n = a.hr << a.lg_wpb;
     for (uint32_t i = threadIdx.x; i < n; i += 1024) {
         const uint32_t j = i >> a.lg_wpb, w = i & (a.wpb - 1);
