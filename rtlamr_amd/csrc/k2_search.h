@@ -472,26 +472,49 @@ __global__ __launch_bounds__(256) void k3_slice(const K3Args a)
     if (cnt == 0) return;
     const uint64_t off = a.offsets[q * a.n_tiles + T];
     const uint32_t *src = a.staging + ((size_t)T * g.n_pre + q) * a.cap;
-    const uint32_t work = cnt * g.pkt_bytes;
-    for (uint32_t i = threadIdx.x; i < work; i += 256) {
-        const uint32_t h = i / g.pkt_bytes, j = i % g.pkt_bytes;
+    // One lane = one hit.  A real packet yields a run of adjacent hit positions, which sit in neighbouring
+    // lanes: for every symbol p the lanes of a wave then read the same one or two bitstream words (one cache
+    // line), and each lane writes its packet as a contiguous byte string next to its neighbour's.
+    for (uint32_t h = threadIdx.x; h < cnt; h += 256) {
         const uint64_t slot = off + h;
         if (slot >= a.out_cap) continue;
         const uint32_t local = src[h];
         if (local >= (64u << g.lg_block_size)) continue;   // defensive: never index the bitstream with a bad position
         // n relative to batch sample 0 of the first preamble bit
         const int64_t n = ((int64_t)T * 64 - 64) * (int64_t)g.block_size + local;
-        if (j == 0) {
-            const uint64_t pos = (uint64_t)(n + g.packet_length);
-            a.hit_block[slot] = a.block_base + (pos >> g.lg_block_size);
-            a.hit_idx[slot] = (uint32_t)pos & (g.block_size - 1);
+        const uint64_t pos = (uint64_t)(n + g.packet_length);
+        a.hit_block[slot] = a.block_base + (pos >> g.lg_block_size);
+        a.hit_idx[slot] = (uint32_t)pos & (g.block_size - 1);
+        uint8_t *out = a.pkt + slot * g.pkt_bytes;
+        // 32 symbols per round: the 32 word loads are independent and all in flight together (the bitstream is
+        // larger than the L2, a load costs ~1 us; one dependent round per byte would serialise twelve of them)
+        for (uint32_t p0 = 0; p0 < g.packet_symbols; p0 += 32) {
+            uint32_t wv[32];
+#pragma unroll
+            for (uint32_t k = 0; k < 32; ++k) {
+                const uint32_t p = p0 + k < g.packet_symbols ? p0 + k : g.packet_symbols - 1;
+                const uint64_t u = (uint64_t)(n + (int64_t)p * g.symbol_length + ((int64_t)64 << g.lg_block_size));
+                wv[k] = a.qt[qt_index(u >> g.lg_block_size, ((uint32_t)u & (g.block_size - 1)) >> 5, g.lg_wpb)];
+            }
+            uint32_t bits = 0;
+#pragma unroll
+            for (uint32_t k = 0; k < 32; ++k) {
+                const uint32_t p = p0 + k < g.packet_symbols ? p0 + k : g.packet_symbols - 1;
+                const uint32_t b = (uint32_t)(n + (int64_t)p * g.symbol_length) & 31u;   // BlockSize is a multiple of 32
+                bits = (bits << 1) | ((wv[k] >> (31 - b)) & 1u);
+            }
+            // bits holds symbols p0..p0+31, first symbol in bit 31: bytes p0/8 .. p0/8+3 (MSB first, decode.go:363-366)
+#pragma unroll
+            for (uint32_t j = 0; j < 4; ++j) {
+                const uint32_t bj = p0 / 8 + j;
+                if (bj < g.pkt_bytes) {
+                    uint32_t byte = (bits >> (24 - 8 * j)) & 0xffu;
+                    const uint32_t valid = g.packet_symbols - bj * 8;     // symbols that exist in this byte
+                    if (valid < 8) byte >>= (8 - valid);                  // PacketSymbols % 8 != 0: right-aligned like Go's shift-in
+                    out[bj] = (uint8_t)byte;
+                }
+            }
         }
-        uint32_t byte = 0;
-        for (uint32_t k = 0; k < 8; ++k) {
-            const uint32_t p = j * 8 + k;
-            if (p < g.packet_symbols) byte = (byte << 1) | k3_bit(a.qt, n + (int64_t)p * g.symbol_length, g);
-        }
-        a.pkt[slot * g.pkt_bytes + j] = (uint8_t)byte;
     }
 }
 
