@@ -168,6 +168,12 @@ size_t amr_prime_blocks(const amr_handle *h);
  * (decode.go:259-265): n_blocks*BlockSize/8 bytes.
  */
 amr_status amr_copy_quantized(amr_handle *h, uint8_t *out, size_t out_bytes);
+/*
+ * Device-side timing.  A HIP event on the stream costs a ~5 us bubble, so none is recorded unless asked for:
+ * level 0 = none (default), 1 = K1 start/stop (demod_ms), 2 = also the search (search_ms, total_ms).
+ * amr_get_timing returns the numbers of the last collected batch (AMR_EINVAL when the level was 0).
+ */
+amr_status amr_set_timing(amr_handle *h, int32_t level);
 amr_status amr_get_timing(const amr_handle *h, amr_timing *out);
 const char *amr_strerror(amr_status s);
 const char *amr_last_error(void);

@@ -6,6 +6,7 @@
 // GPU.  There is NO CPU fallback: without a gfx950 device amr_create fails
 // with AMR_ENODEV.
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 
 #include <algorithm>
 #include <cmath>
@@ -81,7 +82,10 @@ struct Slot {
     uint64_t *h_off = nullptr;    // [AMR_MAX_PREAMBLES+1]
     uint32_t *h_ovf = nullptr;
     uint64_t *h_block = nullptr; uint32_t *h_idx = nullptr; uint8_t *h_pkt = nullptr; uint64_t host_cap = 0;
-    hipEvent_t ev0 = nullptr, ev1 = nullptr, ev2 = nullptr, ev_done = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr, ev_s = nullptr, ev2 = nullptr;   // K1 start/stop, K2 start, K3 stop (timing levels 1/2)
+    uint64_t *h_done = nullptr;   // pinned, coherent: the batch's last kernel stores the batch ticket here
+    uint64_t ticket = 0;          // value that marks the batch in flight as complete
+    int timed = 0;                // timing level the batch in flight was submitted with
     // the batch in flight
     bool pending = false, search = false;
     const uint8_t *d_iq = nullptr;
@@ -102,6 +106,8 @@ struct amr_handle {
     hipStream_t own_stream = nullptr, stream = nullptr, copy_stream = nullptr;
     bool timing_valid = false;
     amr_timing timing{};
+    int timing_level = 0;
+    uint64_t next_ticket = 1;
 
     float *d_lut = nullptr;
     uint8_t *d_carry = nullptr;
@@ -147,11 +153,13 @@ amr_status host_realloc(T *&p, size_t count)
         if (s_ != AMR_OK) return s_;           \
     } while (0)
 
+// Timing events ride on the kernel dispatches themselves (hipExtLaunchKernelGGL start/stop events): a separate
+// hipEventRecord costs a ~6 us bubble on the stream each, four of them per batch were 6 % of a 1 GiB step.
 template <bool TAIL>
-void launch_k1(int cl, dim3 grid, hipStream_t st, const amr::K1Args &a)
+void launch_k1(int cl, dim3 grid, hipStream_t st, const amr::K1Args &a, hipEvent_t start, hipEvent_t stop)
 {
     switch (cl) {
-#define AMR_K1_CASE(N) case N: hipLaunchKernelGGL((amr::k1_demod<N, TAIL>), grid, dim3(64), 0, st, a); break;
+#define AMR_K1_CASE(N) case N: hipExtLaunchKernelGGL((amr::k1_demod<N, TAIL>), grid, dim3(64), 0, st, start, stop, 0, a); break;
         AMR_K1_CASE(8) AMR_K1_CASE(32) AMR_K1_CASE(40) AMR_K1_CASE(48) AMR_K1_CASE(56)
         AMR_K1_CASE(64) AMR_K1_CASE(72) AMR_K1_CASE(80) AMR_K1_CASE(88) AMR_K1_CASE(96)
 #undef AMR_K1_CASE
@@ -221,6 +229,7 @@ amr_status enqueue_search(amr_handle *h, Slot &s, bool rerun = false)
     k2.n_lo = -(int64_t)h->geom.packet_length;
     k2.n_hi = (int64_t)s.n_blocks * bs - (int64_t)h->geom.packet_length;
     k2.g = h->sg;
+    const bool t2 = s.timed >= 2;
     // the overflow word is zeroed by the previous batch's k_hist_update; only a re-run has to do it here
     if (rerun) HIP_TRY(hipMemsetAsync(s.d_overflow, 0, 4, st));
     if (!h->dense_search && n_pre <= 4) {
@@ -229,7 +238,7 @@ amr_status enqueue_search(amr_handle *h, Slot &s, bool rerun = false)
     case N:                                                                                                      \
         HIP_TRY(hipFuncSetAttribute((const void *)amr::k2_search_fast<N>, hipFuncAttributeMaxDynamicSharedMemorySize, \
                                     (int)lds2));                                                                 \
-        hipLaunchKernelGGL(amr::k2_search_fast<N>, dim3(s.n_tiles), dim3(256), lds2, st, k2);                    \
+        hipExtLaunchKernelGGL(amr::k2_search_fast<N>, dim3(s.n_tiles), dim3(256), lds2, st, t2 ? s.ev_s : nullptr, nullptr, 0, k2); \
         break;
         switch (n_pre) { AMR_K2_CASE(1) AMR_K2_CASE(2) AMR_K2_CASE(3) AMR_K2_CASE(4) }
 #undef AMR_K2_CASE
@@ -237,7 +246,7 @@ amr_status enqueue_search(amr_handle *h, Slot &s, bool rerun = false)
         const size_t lds2 = ((size_t)h->sg.wpb * 65 + 8) * 4;
         HIP_TRY(hipFuncSetAttribute((const void *)amr::k2_search_dense, hipFuncAttributeMaxDynamicSharedMemorySize,
                                     (int)lds2));
-        hipLaunchKernelGGL(amr::k2_search_dense, dim3(s.n_tiles), dim3(256), lds2, st, k2);
+        hipExtLaunchKernelGGL(amr::k2_search_dense, dim3(s.n_tiles), dim3(256), lds2, st, t2 ? s.ev_s : nullptr, nullptr, 0, k2);
     }
     AMR_DBG(st, "k2_search");
     amr::ScanArgs sc{s.d_counts, s.d_offsets, s.d_offs_pre, s.n_tiles, n_pre, s.h_off, s.h_ovf, s.d_overflow};
@@ -247,10 +256,9 @@ amr_status enqueue_search(amr_handle *h, Slot &s, bool rerun = false)
     k3.qt = s.d_qt; k3.counts = s.d_counts; k3.offsets = s.d_offsets; k3.staging = s.d_staging;
     k3.hit_block = s.d_hit_block; k3.hit_idx = s.d_hit_idx; k3.pkt = s.d_pkt; k3.out_cap = s.out_cap; k3.overflow = s.d_overflow;
     k3.block_base = s.calls_base; k3.n_tiles = s.n_tiles; k3.cap = s.stage_cap; k3.g = h->sg;
-    hipLaunchKernelGGL(amr::k3_slice, dim3(s.n_tiles, n_pre), dim3(256), 0, st, k3);
+    hipExtLaunchKernelGGL(amr::k3_slice, dim3(s.n_tiles, n_pre), dim3(256), 0, st, nullptr, t2 ? s.ev2 : nullptr, 0, k3);
     HIP_TRY(hipGetLastError());
     AMR_DBG(st, "k3_slice");
-    HIP_TRY(hipEventRecord(s.ev2, st));
     return AMR_OK;
 }
 
@@ -282,29 +290,46 @@ amr_status submit(amr_handle *h, const uint8_t *d_iq, size_t n_blocks, bool sear
     k1.block_size = bs;
     k1.zero_halo = h->zero_halo ? 1u : 0u;
 
-    HIP_TRY(hipEventRecord(s.ev0, st));
-    if (full) { k1.wg_first = 0; launch_k1<false>(h->geom.chip_length, dim3(full), st, k1); }
-    if (rem) { k1.wg_first = full; launch_k1<true>(h->geom.chip_length, dim3(1), st, k1); }
+    s.timed = h->timing_level;
+    hipEvent_t e0 = s.timed ? s.ev0 : nullptr, e1 = s.timed ? s.ev1 : nullptr;
+    if (full) { k1.wg_first = 0; launch_k1<false>(h->geom.chip_length, dim3(full), st, k1, e0, rem ? nullptr : e1); }
+    if (rem) { k1.wg_first = full; launch_k1<true>(h->geom.chip_length, dim3(1), st, k1, full ? nullptr : e0, e1); }
     HIP_TRY(hipGetLastError());
     AMR_DBG(st, "k1_demod");
-    HIP_TRY(hipEventRecord(s.ev1, st));
     if (search) AMR_TRY(enqueue_search(h, s));
-    else HIP_TRY(hipEventRecord(s.ev2, st));
 
     // state carried to the next batch (decode.go:165-166): last rows of this slot's bitstream become the
     // history tile of the OTHER slot (where the next batch runs); last HBA bytes of IQ become the carry
     amr::HistArgs ha{s.d_qt, other.d_qt, (uint32_t)n_blocks, h->hist_rows, h->sg.wpb, h->sg.lg_wpb,
-                     d_iq + n_blocks * (size_t)h->geom.block_size2 - h->halo_bytes, h->d_carry, h->halo_bytes, other.d_overflow};
+                     d_iq + n_blocks * (size_t)h->geom.block_size2 - h->halo_bytes, h->d_carry, h->halo_bytes, other.d_overflow,
+                     s.h_done, s.ticket = h->next_ticket++};
     hipLaunchKernelGGL(amr::k_hist_update, dim3(1), dim3(1024), (size_t)h->hist_rows * h->sg.wpb * 4, st, ha);
     HIP_TRY(hipGetLastError());
     AMR_DBG(st, "k_hist_update");
-    HIP_TRY(hipEventRecord(s.ev_done, st));
     h->zero_halo = false;
     if (search) h->calls_done += n_blocks;
     s.pending = true;
     h->n_pending++;
     h->next_slot ^= 1;
     return AMR_OK;
+}
+
+// Completion of a batch = its last kernel stored the batch ticket into pinned host memory.  No event on the
+// stream (each costs a ~5 us bubble); the stream is polled now and then so that a device fault ends the wait.
+amr_status wait_done(amr_handle *h, Slot &s)
+{
+    for (uint64_t spin = 0;; ++spin) {
+        if (__atomic_load_n(s.h_done, __ATOMIC_ACQUIRE) >= s.ticket) return AMR_OK;
+        if ((spin & 0x3ff) == 0x3ff) {
+            hipError_t e = hipStreamQuery(h->stream);
+            if (e == hipSuccess) {   // everything submitted has run: the ticket must be there now
+                if (__atomic_load_n(s.h_done, __ATOMIC_ACQUIRE) >= s.ticket) return AMR_OK;
+                return fail(AMR_EHIP, "batch finished without publishing its ticket");
+            }
+            if (e != hipErrorNotReady) return fail(AMR_EHIP, "hipStreamQuery", e);
+        }
+        __builtin_ia32_pause();
+    }
 }
 
 // Wait for the oldest batch in flight, grow capacities / re-run the search if it overflowed, read back hits.
@@ -315,7 +340,7 @@ amr_status collect(amr_handle *h, amr_result *res)
     const int si = (h->n_pending == 2) ? h->next_slot : (h->next_slot ^ 1);
     Slot &s = h->slot[si];
     const uint32_t n_pre = h->sg.n_pre;
-    HIP_TRY(hipEventSynchronize(s.ev_done));
+    AMR_TRY(wait_done(h, s));
     uint64_t total = 0;
     if (s.search) {
         for (int attempt = 0;; ++attempt) {
@@ -362,9 +387,13 @@ amr_status collect(amr_handle *h, amr_result *res)
         }
     }
     float a = 0, b = 0, c = 0;
-    if (hipEventElapsedTime(&a, s.ev0, s.ev1) == hipSuccess && hipEventElapsedTime(&b, s.ev1, s.ev2) == hipSuccess &&
-        hipEventElapsedTime(&c, s.ev0, s.ev2) == hipSuccess) {
-        h->timing = amr_timing{a, b, c};
+    h->timing_valid = false;
+    if (s.timed && hipEventSynchronize(s.ev1) == hipSuccess && hipEventElapsedTime(&a, s.ev0, s.ev1) == hipSuccess) {
+        if (s.timed >= 2 && s.search && hipEventSynchronize(s.ev2) == hipSuccess &&
+            hipEventElapsedTime(&b, s.ev_s, s.ev2) == hipSuccess && hipEventElapsedTime(&c, s.ev0, s.ev2) == hipSuccess)
+            h->timing = amr_timing{a, b, c};
+        else
+            h->timing = amr_timing{a, 0.f, a};
         h->timing_valid = true;
     }
     s.pending = false;
@@ -505,7 +534,9 @@ amr_status amr_create(const amr_protocol *protos, int32_t n_protos, int32_t devi
         if (e == hipSuccess) e = hipEventCreate(&sl.ev0);
         if (e == hipSuccess) e = hipEventCreate(&sl.ev1);
         if (e == hipSuccess) e = hipEventCreate(&sl.ev2);
-        if (e == hipSuccess) e = hipEventCreateWithFlags(&sl.ev_done, hipEventDisableTiming);
+        if (e == hipSuccess) e = hipEventCreate(&sl.ev_s);
+        if (e == hipSuccess) e = hipHostMalloc((void **)&sl.h_done, 8, hipHostMallocCoherent);
+        if (e == hipSuccess) *sl.h_done = 0;
         if (e == hipSuccess) e = hipMalloc((void **)&sl.d_offs_pre, (AMR_MAX_PREAMBLES + 1) * 8);
         if (e == hipSuccess) e = hipMalloc((void **)&sl.d_overflow, 4);
         if (e == hipSuccess) e = hipMemset(sl.d_overflow, 0, 4);
@@ -535,7 +566,8 @@ amr_status amr_destroy(amr_handle *h)
         for (void *p : dp) if (p) (void)hipFree(p);
         void *hp[] = {sl.h_off, sl.h_ovf, sl.h_block, sl.h_idx, sl.h_pkt};
         for (void *p : hp) if (p) (void)hipHostFree(p);
-        hipEvent_t evs[] = {sl.ev0, sl.ev1, sl.ev2, sl.ev_done};
+        hipEvent_t evs[] = {sl.ev0, sl.ev1, sl.ev_s, sl.ev2};
+        if (sl.h_done) (void)hipHostFree(sl.h_done);
         for (hipEvent_t ev : evs) if (ev) (void)hipEventDestroy(ev);
     }
     if (h->own_stream) (void)hipStreamDestroy(h->own_stream);
@@ -663,6 +695,13 @@ amr_status amr_copy_quantized(amr_handle *h, uint8_t *out, size_t out_bytes)
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipMemcpyAsync(out, h->d_untile, words * 4, hipMemcpyDeviceToHost, h->stream));
     HIP_TRY(hipStreamSynchronize(h->stream));
+    return AMR_OK;
+}
+
+amr_status amr_set_timing(amr_handle *h, int32_t level)
+{
+    if (!h || level < 0 || level > 2) return fail(AMR_EINVAL, "timing level must be 0, 1 or 2");
+    h->timing_level = level;
     return AMR_OK;
 }
 

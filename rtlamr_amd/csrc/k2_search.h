@@ -532,6 +532,9 @@ struct HistArgs {
     uint8_t *carry_dst;
     uint32_t carry_bytes;   // multiple of 16
     uint32_t *ovf_next;
+    // completion ticket of the batch, stored to pinned host memory by the last thread of this last kernel
+    uint64_t *done_flag;
+    uint64_t done_value;
 };
 
 __global__ __launch_bounds__(1024) void k_hist_update(const HistArgs a)
@@ -552,6 +555,9 @@ __global__ __launch_bounds__(1024) void k_hist_update(const HistArgs a)
         const uint32_t j = i >> a.lg_wpb, w = i & (a.wpb - 1);
         a.qt_next[qt_index(64 - a.hr + j, w, a.lg_wpb)] = tmp[i];
     }
+    __syncthreads();
+    // every earlier kernel of the batch has completed (same stream); the host polls this word
+    if (threadIdx.x == 0) __hip_atomic_store(a.done_flag, a.done_value, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
 // Tests: tiled rows 64.. -> linear MSB-first byte stream (decode.go:259-265 packing).

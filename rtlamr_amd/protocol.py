@@ -353,6 +353,10 @@ class Decoder:
         _lib.check(_lib.lib().amr_copy_quantized(h, out.ctypes.data, out.size), "amr_copy_quantized")
         return out
 
+    def set_timing(self, level: int) -> None:
+        """0 = no timing events (default), 1 = K1 only, 2 = K1 and search; an event costs ~5 us on the stream."""
+        _lib.check(_lib.lib().amr_set_timing(self._require(), level), "amr_set_timing")
+
     def timing(self):
         t = _lib.AmrTiming()
         _lib.check(_lib.lib().amr_get_timing(self._require(), C.byref(t)), "amr_get_timing")
