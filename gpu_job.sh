@@ -4,5 +4,5 @@ cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out
 timeout 900 python -m pytest tests -m gpu -q -x -s > gpurun_out/pytest_gpu.log 2>&1
 echo "pytest rc=$?" >> gpurun_out/pytest_gpu.log
-timeout 600 python bench.py --steps 10 --warmup 2 > gpurun_out/bench.log 2>&1
+timeout 600 python bench.py > gpurun_out/bench.log 2>&1
 echo "bench rc=$?" >> gpurun_out/bench.log

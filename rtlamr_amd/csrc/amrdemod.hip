@@ -77,11 +77,13 @@ struct Slot {
     uint64_t *d_offs_pre = nullptr;                        // [n_pre+1] + overflow word behind it
     uint32_t *d_overflow = nullptr;
     uint32_t *d_staging = nullptr; size_t staging_tiles = 0; uint32_t stage_cap = 1024;
-    uint64_t *d_hit_block = nullptr; uint32_t *d_hit_idx = nullptr; uint8_t *d_pkt = nullptr; uint64_t out_cap = 0;
+    // result of a batch, packed: [hit_block u64 x n | hit_idx u32 x n | pkt bytes x n], n = total hits, so that
+    // ONE device-to-host copy of (12 + pkt_bytes) * n bytes brings it over
+    uint8_t *d_out = nullptr; uint64_t out_cap = 0;
     // pinned host mirrors
     uint64_t *h_off = nullptr;    // [AMR_MAX_PREAMBLES+1]
     uint32_t *h_ovf = nullptr;
-    uint64_t *h_block = nullptr; uint32_t *h_idx = nullptr; uint8_t *h_pkt = nullptr; uint64_t host_cap = 0;
+    uint8_t *h_out = nullptr; uint64_t host_cap = 0;
     hipEvent_t ev0 = nullptr, ev1 = nullptr, ev_s = nullptr, ev2 = nullptr;   // K1 start/stop, K2 start, K3 stop (timing levels 1/2)
     uint64_t *h_done = nullptr;   // pinned, coherent: the batch's last kernel stores the batch ticket here
     uint64_t ticket = 0;          // value that marks the batch in flight as complete
@@ -206,9 +208,7 @@ amr_status ensure_capacity(amr_handle *h, Slot &s, size_t n_blocks)
     }
     if (s.out_cap == 0) {
         s.out_cap = 1 << 16;
-        AMR_TRY(dev_realloc(s.d_hit_block, s.out_cap));
-        AMR_TRY(dev_realloc(s.d_hit_idx, s.out_cap));
-        AMR_TRY(dev_realloc(s.d_pkt, s.out_cap * h->sg.pkt_bytes));
+        AMR_TRY(dev_realloc(s.d_out, s.out_cap * (12 + h->sg.pkt_bytes)));
     }
     return AMR_OK;
 }
@@ -254,7 +254,7 @@ amr_status enqueue_search(amr_handle *h, Slot &s, bool rerun = false)
     AMR_DBG(st, "k2s_scan");
     amr::K3Args k3{};
     k3.qt = s.d_qt; k3.counts = s.d_counts; k3.offsets = s.d_offsets; k3.staging = s.d_staging;
-    k3.hit_block = s.d_hit_block; k3.hit_idx = s.d_hit_idx; k3.pkt = s.d_pkt; k3.out_cap = s.out_cap; k3.overflow = s.d_overflow;
+    k3.out = s.d_out; k3.offs_pre = s.d_offs_pre; k3.out_cap = s.out_cap; k3.overflow = s.d_overflow;
     k3.block_base = s.calls_base; k3.n_tiles = s.n_tiles; k3.cap = s.stage_cap; k3.g = h->sg;
     hipExtLaunchKernelGGL(amr::k3_slice, dim3(s.n_tiles, n_pre), dim3(256), 0, st, nullptr, t2 ? s.ev2 : nullptr, 0, k3);
     HIP_TRY(hipGetLastError());
@@ -361,9 +361,7 @@ amr_status collect(amr_handle *h, amr_result *res)
                 while (nc < total) nc *= 2;
                 s.out_cap = nc;
                 HIP_TRY(hipStreamSynchronize(h->stream));
-                AMR_TRY(dev_realloc(s.d_hit_block, s.out_cap));
-                AMR_TRY(dev_realloc(s.d_hit_idx, s.out_cap));
-                AMR_TRY(dev_realloc(s.d_pkt, s.out_cap * h->sg.pkt_bytes));
+                AMR_TRY(dev_realloc(s.d_out, s.out_cap * (12 + h->sg.pkt_bytes)));
                 rerun = true;
             }
             if (!rerun) break;
@@ -374,15 +372,11 @@ amr_status collect(amr_handle *h, amr_result *res)
         if (total > s.host_cap) {
             uint64_t nc = s.host_cap ? s.host_cap : (1 << 16);
             while (nc < total) nc *= 2;
-            AMR_TRY(host_realloc(s.h_block, nc));
-            AMR_TRY(host_realloc(s.h_idx, nc));
-            AMR_TRY(host_realloc(s.h_pkt, nc * h->sg.pkt_bytes));
+            AMR_TRY(host_realloc(s.h_out, nc * (12 + h->sg.pkt_bytes)));
             s.host_cap = nc;
         }
         if (total) {   // on the copy stream: overlaps the next batch's kernels
-            HIP_TRY(hipMemcpyAsync(s.h_block, s.d_hit_block, total * 8, hipMemcpyDeviceToHost, h->copy_stream));
-            HIP_TRY(hipMemcpyAsync(s.h_idx, s.d_hit_idx, total * 4, hipMemcpyDeviceToHost, h->copy_stream));
-            HIP_TRY(hipMemcpyAsync(s.h_pkt, s.d_pkt, total * h->sg.pkt_bytes, hipMemcpyDeviceToHost, h->copy_stream));
+            HIP_TRY(hipMemcpyAsync(s.h_out, s.d_out, total * (12 + h->sg.pkt_bytes), hipMemcpyDeviceToHost, h->copy_stream));
             HIP_TRY(hipStreamSynchronize(h->copy_stream));
         }
     }
@@ -407,9 +401,9 @@ amr_status collect(amr_handle *h, amr_result *res)
             res->pkt_bytes = h->sg.pkt_bytes;
             res->n_hits = total;
             res->preamble_offset = h->r_off.data();
-            res->hit_block = s.h_block;
-            res->hit_idx = s.h_idx;
-            res->pkt = s.h_pkt;
+            res->hit_block = reinterpret_cast<const uint64_t *>(s.h_out);
+            res->hit_idx = reinterpret_cast<const uint32_t *>(s.h_out + total * 8);
+            res->pkt = s.h_out + total * 12;
         }
     }
     return AMR_OK;
@@ -561,10 +555,9 @@ amr_status amr_destroy(amr_handle *h)
     void *ptrs[] = {h->d_lut, h->d_carry, h->d_iq, h->d_untile};
     for (void *p : ptrs) if (p) (void)hipFree(p);
     for (Slot &sl : h->slot) {
-        void *dp[] = {sl.d_qt, sl.d_counts, sl.d_offsets, sl.d_offs_pre, sl.d_overflow, sl.d_staging, sl.d_hit_block,
-                      sl.d_hit_idx, sl.d_pkt};
+        void *dp[] = {sl.d_qt, sl.d_counts, sl.d_offsets, sl.d_offs_pre, sl.d_overflow, sl.d_staging, sl.d_out};
         for (void *p : dp) if (p) (void)hipFree(p);
-        void *hp[] = {sl.h_off, sl.h_ovf, sl.h_block, sl.h_idx, sl.h_pkt};
+        void *hp[] = {sl.h_off, sl.h_ovf, sl.h_out};
         for (void *p : hp) if (p) (void)hipHostFree(p);
         hipEvent_t evs[] = {sl.ev0, sl.ev1, sl.ev_s, sl.ev2};
         if (sl.h_done) (void)hipHostFree(sl.h_done);

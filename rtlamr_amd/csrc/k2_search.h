@@ -440,11 +440,12 @@ struct K3Args {
     const uint32_t *counts;
     const uint64_t *offsets;
     const uint32_t *staging;
-    uint64_t *hit_block;   // [out_cap] call index = block_base + (pos >> lg BS), pos = n + PacketLength
-    uint32_t *hit_idx;     // [out_cap] idx = pos & (BS-1)  (Data.Idx, decode.go:371)
-    uint64_t block_base;   // call index of the first block of the batch
-    uint8_t *pkt;          // [out_cap * pkt_bytes]
-    uint64_t out_cap;
+    // packed result [hit_block u64 x n | hit_idx u32 x n | pkt x n], n = offs_pre[n_pre] (total hits):
+    //   hit_block = block_base + (pos >> lg BS), pos = n + PacketLength;  hit_idx = pos & (BS-1)  (Data.Idx, decode.go:371)
+    uint8_t *out;
+    const uint64_t *offs_pre;   // [n_pre+1] from k2s_scan
+    uint64_t block_base;        // call index of the first block of the batch
+    uint64_t out_cap;           // hits the buffer holds
     const uint32_t *overflow;   // K2's overflow word: non-zero = the host will grow a capacity and search again
     uint32_t n_tiles;
     uint32_t cap;
@@ -470,6 +471,11 @@ __global__ __launch_bounds__(256) void k3_slice(const K3Args a)
     if (*a.overflow) return;
     const uint32_t cnt = a.counts[q * a.n_tiles + T];
     if (cnt == 0) return;
+    const uint64_t total = a.offs_pre[g.n_pre];
+    if (total > a.out_cap) return;   // the host grows the buffer and searches again
+    uint64_t *hit_block = reinterpret_cast<uint64_t *>(a.out);
+    uint32_t *hit_idx = reinterpret_cast<uint32_t *>(a.out + total * 8);
+    uint8_t *pkt = a.out + total * 12;
     const uint64_t off = a.offsets[q * a.n_tiles + T];
     const uint32_t *src = a.staging + ((size_t)T * g.n_pre + q) * a.cap;
     // One lane = one hit.  A real packet yields a run of adjacent hit positions, which sit in neighbouring
@@ -477,15 +483,14 @@ __global__ __launch_bounds__(256) void k3_slice(const K3Args a)
     // line), and each lane writes its packet as a contiguous byte string next to its neighbour's.
     for (uint32_t h = threadIdx.x; h < cnt; h += 256) {
         const uint64_t slot = off + h;
-        if (slot >= a.out_cap) continue;
         const uint32_t local = src[h];
         if (local >= (64u << g.lg_block_size)) continue;   // defensive: never index the bitstream with a bad position
         // n relative to batch sample 0 of the first preamble bit
         const int64_t n = ((int64_t)T * 64 - 64) * (int64_t)g.block_size + local;
         const uint64_t pos = (uint64_t)(n + g.packet_length);
-        a.hit_block[slot] = a.block_base + (pos >> g.lg_block_size);
-        a.hit_idx[slot] = (uint32_t)pos & (g.block_size - 1);
-        uint8_t *out = a.pkt + slot * g.pkt_bytes;
+        hit_block[slot] = a.block_base + (pos >> g.lg_block_size);
+        hit_idx[slot] = (uint32_t)pos & (g.block_size - 1);
+        uint8_t *out = pkt + slot * g.pkt_bytes;
         // 32 symbols per round: the 32 word loads are independent and all in flight together (the bitstream is
         // larger than the L2, a load costs ~1 us; one dependent round per byte would serialise twelve of them)
         for (uint32_t p0 = 0; p0 < g.packet_symbols; p0 += 32) {
