@@ -478,46 +478,51 @@ __global__ __launch_bounds__(256) void k3_slice(const K3Args a)
     uint8_t *pkt = a.out + total * 12;
     const uint64_t off = a.offsets[q * a.n_tiles + T];
     const uint32_t *src = a.staging + ((size_t)T * g.n_pre + q) * a.cap;
-    // One lane = one hit.  A real packet yields a run of adjacent hit positions, which sit in neighbouring
-    // lanes: for every symbol p the lanes of a wave then read the same one or two bitstream words (one cache
-    // line), and each lane writes its packet as a contiguous byte string next to its neighbour's.
-    for (uint32_t h = threadIdx.x; h < cnt; h += 256) {
+    // One lane = 32 symbols of one hit (rounds = ceil(PacketSymbols/32) lanes per hit; rounds-major so that the lanes
+    // of a wave hold neighbouring hits).  A real packet yields a run of adjacent hit positions: for every symbol
+    // the lanes of a wave then read the same one or two bitstream words (one cache line).  The 32 word loads of a
+    // lane are independent and all in flight together -- the bitstream is larger than the L2, a load costs ~1 us.
+    const uint32_t rounds = (g.packet_symbols + 31) >> 5;
+    for (uint32_t i = threadIdx.x; i < cnt * rounds; i += 256) {
+        const uint32_t r = i / cnt, h = i - r * cnt;
         const uint64_t slot = off + h;
         const uint32_t local = src[h];
         if (local >= (64u << g.lg_block_size)) continue;   // defensive: never index the bitstream with a bad position
         // n relative to batch sample 0 of the first preamble bit
         const int64_t n = ((int64_t)T * 64 - 64) * (int64_t)g.block_size + local;
-        const uint64_t pos = (uint64_t)(n + g.packet_length);
-        hit_block[slot] = a.block_base + (pos >> g.lg_block_size);
-        hit_idx[slot] = (uint32_t)pos & (g.block_size - 1);
+        if (r == 0) {
+            const uint64_t pos = (uint64_t)(n + g.packet_length);
+            hit_block[slot] = a.block_base + (pos >> g.lg_block_size);
+            hit_idx[slot] = (uint32_t)pos & (g.block_size - 1);
+        }
         uint8_t *out = pkt + slot * g.pkt_bytes;
-        // 32 symbols per round: the 32 word loads are independent and all in flight together (the bitstream is
-        // larger than the L2, a load costs ~1 us; one dependent round per byte would serialise twelve of them)
-        for (uint32_t p0 = 0; p0 < g.packet_symbols; p0 += 32) {
-            uint32_t wv[32];
+        const uint32_t p0 = r * 32;
+        // 32-bit tile-local arithmetic: bit position v = local + p*SL counts from row 0 of tile T (it may run a few
+        // rows into tile T+1); the word of v is at tile_base + (row>>6)*tile_words + (w>>2)*256 + (row&63)*4 + (w&3)
+        const uint32_t *tbase = a.qt + ((size_t)T << (6 + g.lg_wpb));
+        const uint32_t lg_bs = g.lg_block_size, bs_mask = g.block_size - 1, lg_tw = 6 + g.lg_wpb;
+        const uint32_t last = g.packet_symbols - 1;
+        uint32_t wv[32], sh[32];
 #pragma unroll
-            for (uint32_t k = 0; k < 32; ++k) {
-                const uint32_t p = p0 + k < g.packet_symbols ? p0 + k : g.packet_symbols - 1;
-                const uint64_t u = (uint64_t)(n + (int64_t)p * g.symbol_length + ((int64_t)64 << g.lg_block_size));
-                wv[k] = a.qt[qt_index(u >> g.lg_block_size, ((uint32_t)u & (g.block_size - 1)) >> 5, g.lg_wpb)];
-            }
-            uint32_t bits = 0;
+        for (uint32_t k = 0; k < 32; ++k) {
+            const uint32_t p = p0 + k < g.packet_symbols ? p0 + k : last;
+            const uint32_t v = local + p * g.symbol_length;
+            const uint32_t row = v >> lg_bs, w = (v & bs_mask) >> 5;
+            wv[k] = tbase[((row >> 6) << lg_tw) + ((w >> 2) << 8) + ((row & 63) << 2) + (w & 3)];
+            sh[k] = 31 - (v & 31);
+        }
+        uint32_t bits = 0;
 #pragma unroll
-            for (uint32_t k = 0; k < 32; ++k) {
-                const uint32_t p = p0 + k < g.packet_symbols ? p0 + k : g.packet_symbols - 1;
-                const uint32_t b = (uint32_t)(n + (int64_t)p * g.symbol_length) & 31u;   // BlockSize is a multiple of 32
-                bits = (bits << 1) | ((wv[k] >> (31 - b)) & 1u);
-            }
-            // bits holds symbols p0..p0+31, first symbol in bit 31: bytes p0/8 .. p0/8+3 (MSB first, decode.go:363-366)
+        for (uint32_t k = 0; k < 32; ++k) bits = (bits << 1) | ((wv[k] >> sh[k]) & 1u);
+        // bits holds symbols p0..p0+31, first symbol in bit 31: bytes p0/8 .. p0/8+3 (MSB first, decode.go:363-366)
 #pragma unroll
-            for (uint32_t j = 0; j < 4; ++j) {
-                const uint32_t bj = p0 / 8 + j;
-                if (bj < g.pkt_bytes) {
-                    uint32_t byte = (bits >> (24 - 8 * j)) & 0xffu;
-                    const uint32_t valid = g.packet_symbols - bj * 8;     // symbols that exist in this byte
-                    if (valid < 8) byte >>= (8 - valid);                  // PacketSymbols % 8 != 0: right-aligned like Go's shift-in
-                    out[bj] = (uint8_t)byte;
-                }
+        for (uint32_t j = 0; j < 4; ++j) {
+            const uint32_t bj = p0 / 8 + j;
+            if (bj < g.pkt_bytes) {
+                uint32_t byte = (bits >> (24 - 8 * j)) & 0xffu;
+                const uint32_t valid = g.packet_symbols - bj * 8;     // symbols that exist in this byte
+                if (valid < 8) byte >>= (8 - valid);                  // PacketSymbols % 8 != 0: right-aligned like Go's shift-in
+                out[bj] = (uint8_t)byte;
             }
         }
     }
