@@ -12,4 +12,4 @@ timeout 200 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $O/pmc_write -o pmc --o
 timeout 200 rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_SCA SQ_INSTS_VALU -d $O/pmc_sq_a -o pmc --output-format csv -- $B > $O/pmc_sq_a.log 2>&1
 timeout 200 rocprofv3 --kernel-trace --pmc SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR GRBM_GUI_ACTIVE -d $O/pmc_sq_b -o pmc --output-format csv -- $B > $O/pmc_sq_b.log 2>&1
 $B > $O/bench_unprofiled.log 2>&1
-python $R/bench.py --steps 10 --warmup 2 > $O/bench_line.log 2>&1
+python $R/bench.py > $O/bench_line.log 2>&1
