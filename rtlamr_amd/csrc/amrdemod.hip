@@ -233,15 +233,19 @@ amr_status enqueue_search(amr_handle *h, Slot &s, bool rerun = false)
     // the overflow word is zeroed by the previous batch's k_hist_update; only a re-run has to do it here
     if (rerun) HIP_TRY(hipMemsetAsync(s.d_overflow, 0, 4, st));
     if (!h->dense_search && n_pre <= 4) {
-        const size_t lds2 = amr::k2_fast_lds_bytes(h->sg.wpb, (int)n_pre);
-#define AMR_K2_CASE(N)                                                                                           \
-    case N:                                                                                                      \
-        HIP_TRY(hipFuncSetAttribute((const void *)amr::k2_search_fast<N>, hipFuncAttributeMaxDynamicSharedMemorySize, \
-                                    (int)lds2));                                                                 \
-        hipExtLaunchKernelGGL(amr::k2_search_fast<N>, dim3(s.n_tiles), dim3(256), lds2, st, t2 ? s.ev_s : nullptr, nullptr, 0, k2); \
-        break;
+        const int nwv = h->sg.wpb >= 32 ? 8 : 4;
+        const size_t lds2 = amr::k2_fast_lds_bytes(h->sg.wpb, (int)n_pre, nwv);
+#define AMR_K2_LAUNCH(N, W)                                                                                          \
+    do {                                                                                                             \
+        HIP_TRY(hipFuncSetAttribute((const void *)amr::k2_search_fast<N, W>, hipFuncAttributeMaxDynamicSharedMemorySize, \
+                                    (int)lds2));                                                                     \
+        hipExtLaunchKernelGGL((amr::k2_search_fast<N, W>), dim3(s.n_tiles), dim3(64 * W), lds2, st, t2 ? s.ev_s : nullptr, \
+                              nullptr, 0, k2);                                                                       \
+    } while (0)
+#define AMR_K2_CASE(N) case N: if (nwv == 8) AMR_K2_LAUNCH(N, 8); else AMR_K2_LAUNCH(N, 4); break;
         switch (n_pre) { AMR_K2_CASE(1) AMR_K2_CASE(2) AMR_K2_CASE(3) AMR_K2_CASE(4) }
 #undef AMR_K2_CASE
+#undef AMR_K2_LAUNCH
     } else {
         const size_t lds2 = ((size_t)h->sg.wpb * 65 + 8) * 4;
         HIP_TRY(hipFuncSetAttribute((const void *)amr::k2_search_dense, hipFuncAttributeMaxDynamicSharedMemorySize,

@@ -183,20 +183,27 @@ constexpr int kListCap = 448;  // (key, mask) entries per wave
 
 __device__ __forceinline__ uint32_t k2_depth(uint32_t npre) { return 9u + (npre > 2 ? 2u : npre > 1 ? 1u : 0u); }
 
-template <int NPRE>
-__global__ __launch_bounds__(256) void k2_search_fast(const K2Args a)
+// NWV waves share one tile (8 when a row has >= 32 words: 24 waves per CU hide the LDS latency of the tap loop,
+// which is what bounds this kernel; 4 for the 512-sample blocks of chip length 8).
+template <int NPRE, int NWV>
+__global__ __launch_bounds__(64 * NWV) void k2_search_fast(const K2Args a)
 {
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
-    const uint32_t T = blockIdx.x, tid = threadIdx.x, lane = tid & 63, v = tid >> 6;
+    const uint32_t T = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
+    // the wave index is wave-uniform, but hipcc cannot know that of tid >> 6: without readfirstlane the whole
+    // window addressing below is done per lane in VALU and its branches become exec-masked double execution
+    const uint32_t v = __builtin_amdgcn_readfirstlane(tid >> 6);
     const uint32_t wpb = a.g.wpb, lg_wpb = a.g.lg_wpb, wpb_mask = wpb - 1;
     const uint32_t lg_bs = a.g.lg_block_size;
     const uint32_t SL = a.g.symbol_length, maxL = a.g.max_pre_len;
     const uint32_t tile_words = 64u << lg_wpb;
     uint32_t *tile = lds;                              // [wpb][65]
-    uint32_t *lists = tile + wpb * 65;                 // [4][kListCap][2]
-    uint32_t *cnts = lists + 4 * kListCap * 2;         // [NPRE][256], index row*4+wave
-    uint32_t *bases = cnts + NPRE * 256;               // [NPRE][256]
-    uint32_t *wtot = bases + NPRE * 256;               // [4]
+    constexpr int NT = 64 * NWV;                       // threads
+    constexpr int LCAP = kListCap * 4 / NWV;           // list entries per wave: the candidates split with the words
+    uint32_t *lists = tile + wpb * 65;                 // [NWV][LCAP][2]
+    uint32_t *cnts = lists + 4 * kListCap * 2;         // [NPRE][NT], index row*NWV+wave
+    uint32_t *bases = cnts + NPRE * NT;                // [NPRE][NT]
+    uint32_t *wtot = bases + NPRE * NT;                // [NWV]
 
     uint64_t pbits[NPRE];
     uint32_t plen[NPRE];
@@ -207,16 +214,16 @@ __global__ __launch_bounds__(256) void k2_search_fast(const K2Args a)
     // ---- stage the tile: 16 bytes per lane per load (4 words of one row), transposed into [word][row] ----
     {
         const uint4 *src4 = reinterpret_cast<const uint4 *>(a.qt + (size_t)T * tile_words);
-        for (uint32_t i = tid; i < tile_words / 4; i += 256) {
+        for (uint32_t i = tid; i < tile_words / 4; i += NT) {
             const uint4 x = src4[i];                      // words 4c..4c+3 of row l
             const uint32_t c = i >> 6, l = i & 63;
             uint32_t *d = tile + (c * 4) * 65 + l;
             d[0] = x.x; d[65] = x.y; d[130] = x.z; d[195] = x.w;
         }
         const uint32_t *nxt = a.qt + (size_t)(T + 1) * tile_words;
-        for (uint32_t w = tid; w < wpb; w += 256) tile[w * 65 + 64] = nxt[((w >> 2) << 8) + (w & 3)];
+        for (uint32_t w = tid; w < wpb; w += NT) tile[w * 65 + 64] = nxt[((w >> 2) << 8) + (w & 3)];
 #pragma unroll
-        for (int q = 0; q < NPRE; ++q) cnts[q * 256 + tid] = 0;
+        for (int q = 0; q < NPRE; ++q) cnts[q * NT + tid] = 0;
     }
     __syncthreads();
 
@@ -227,8 +234,8 @@ __global__ __launch_bounds__(256) void k2_search_fast(const K2Args a)
     const uint32_t w_hi = (uint32_t)(hi64 < 0 ? 0 : hi64 > (int64_t)wpb ? wpb : hi64);
 
     uint32_t list_n = 0;                                // wave-uniform
-    uint32_t *mylist = lists + v * (kListCap * 2);
-    const uint32_t wq = wpb >> 2;                       // words per wave
+    uint32_t *mylist = lists + v * (LCAP * 2);
+    const uint32_t wq = wpb / NWV;                      // words per wave
     const uint32_t *lane_tile = tile + lane;
 
     // window words A[0..4] of tap p for the step that starts at word w0 (uniform addressing)
@@ -250,7 +257,10 @@ __global__ __launch_bounds__(256) void k2_search_fast(const K2Args a)
     };
 
     // ---- stage 1 ----
-    for (uint32_t c = 0; c < (wq >> 2); ++c) {
+#ifndef AMR_K2_DIAG
+#define AMR_K2_DIAG 0   // developer diagnostics: 1 = no search at all (staging, barriers, scan only), 2 = stage 1 only
+#endif
+    for (uint32_t c = 0; c < (AMR_K2_DIAG == 1 ? 0u : (wq >> 2)); ++c) {
         const uint32_t w0 = v * wq + 4 * c;
         uint32_t M[NPRE][4];
 #pragma unroll
@@ -259,17 +269,16 @@ __global__ __launch_bounds__(256) void k2_search_fast(const K2Args a)
 #pragma unroll
             for (int q = 0; q < NPRE; ++q) M[q][j] = ok;
         }
-        uint32_t An[5];
-        load_tap(w0, 0, An);
-        for (uint32_t p = 0; p < D; ++p) {
-            uint32_t A[5];
-#pragma unroll
-            for (int j = 0; j < 5; ++j) A[j] = An[j];
-            if (p + 1 < D) load_tap(w0, p + 1, An);      // one tap ahead: no wait between a tap's loads and its use
-            const bool shifted = ((p * SL) & 31) != 0;   // SL multiple of 16: shift is 0 or 16
+        // one tap: W = the 4 windows (plain or 16-bit funnel shift, a wave-uniform choice), M &= W ^ inv
+        auto apply_tap = [&](uint32_t p, const uint32_t (&A)[5]) {
             uint32_t W[4];
+            if ((p * SL) & 31) {                         // SL multiple of 16: shift is 0 or 16
 #pragma unroll
-            for (int j = 0; j < 4; ++j) W[j] = shifted ? __builtin_amdgcn_alignbit(A[j], A[j + 1], 16) : A[j];
+                for (int j = 0; j < 4; ++j) W[j] = __builtin_amdgcn_alignbit(A[j], A[j + 1], 16);
+            } else {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) W[j] = A[j];
+            }
 #pragma unroll
             for (int q = 0; q < NPRE; ++q) {
                 if (p < plen[q]) {
@@ -277,6 +286,17 @@ __global__ __launch_bounds__(256) void k2_search_fast(const K2Args a)
 #pragma unroll
                     for (int j = 0; j < 4; ++j) M[q][j] &= W[j] ^ inv;
                 }
+            }
+        };
+        // two taps per iteration on ping-pong buffers: the loads of tap p+1 are in flight while tap p is applied
+        uint32_t A0[5], A1[5];
+        load_tap(w0, 0, A0);
+        for (uint32_t p = 0; p < D; p += 2) {
+            if (p + 1 < D) load_tap(w0, p + 1, A1);
+            apply_tap(p, A0);
+            if (p + 1 < D) {
+                if (p + 2 < D) load_tap(w0, p + 2, A0);
+                apply_tap(p + 1, A1);
             }
         }
         // record the (rare) non-zero masks
@@ -289,7 +309,7 @@ __global__ __launch_bounds__(256) void k2_search_fast(const K2Args a)
                 if (b) {
                     const uint32_t idx = list_n + __builtin_amdgcn_mbcnt_hi((uint32_t)(b >> 32),
                                                                             __builtin_amdgcn_mbcnt_lo((uint32_t)b, 0));
-                    if (m != 0 && idx < (uint32_t)kListCap) {
+                    if (m != 0 && idx < (uint32_t)LCAP) {
                         mylist[idx * 2] = ((uint32_t)q << 16) | (lane << 8) | (w0 + j);
                         mylist[idx * 2 + 1] = m;
                     }
@@ -300,7 +320,7 @@ __global__ __launch_bounds__(256) void k2_search_fast(const K2Args a)
     }
 
     // ---- stage 2: remaining taps on the list entries (one per lane), compaction in place ----
-    const uint32_t n_cand = list_n < (uint32_t)kListCap ? list_n : (uint32_t)kListCap;
+    const uint32_t n_cand = AMR_K2_DIAG == 2 ? 0u : (list_n < (uint32_t)LCAP ? list_n : (uint32_t)LCAP);
     uint32_t n_keep = 0;                                // wave-uniform
     for (uint32_t e0 = 0; e0 < n_cand; e0 += 64) {
         const uint32_t e = e0 + lane;
@@ -328,7 +348,7 @@ __global__ __launch_bounds__(256) void k2_search_fast(const K2Args a)
             const uint32_t slot = n_keep + __builtin_amdgcn_mbcnt_hi((uint32_t)(b >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)b, 0));
             mylist[slot * 2] = key;
             mylist[slot * 2 + 1] = m;
-            atomicAdd(&cnts[q * 256 + l * 4 + v], __popc(m));
+            atomicAdd(&cnts[q * NT + l * NWV + v], __popc(m));
         }
         n_keep += __popcll(b);
     }
@@ -338,7 +358,7 @@ __global__ __launch_bounds__(256) void k2_search_fast(const K2Args a)
     uint32_t total[NPRE];
 #pragma unroll
     for (int q = 0; q < NPRE; ++q) {
-        const uint32_t val = cnts[q * 256 + tid];
+        const uint32_t val = cnts[q * NT + tid];
         uint32_t inc = val;
 #pragma unroll
         for (int d = 1; d < 64; d <<= 1) {
@@ -349,8 +369,11 @@ __global__ __launch_bounds__(256) void k2_search_fast(const K2Args a)
         __syncthreads();
         uint32_t base = 0;
         for (uint32_t u = 0; u < v; ++u) base += wtot[u];
-        total[q] = wtot[0] + wtot[1] + wtot[2] + wtot[3];
-        bases[q * 256 + tid] = base + inc - val;
+        uint32_t tot = 0;
+#pragma unroll
+        for (int u = 0; u < NWV; ++u) tot += wtot[u];
+        total[q] = tot;
+        bases[q * NT + tid] = base + inc - val;
         __syncthreads();
     }
 
@@ -366,7 +389,7 @@ __global__ __launch_bounds__(256) void k2_search_fast(const K2Args a)
 #pragma unroll
         for (int qq = 0; qq < NPRE; ++qq)
             if (q == (uint32_t)qq) r = __builtin_amdgcn_readlane(run[qq], l);
-        const uint32_t base = bases[q * 256 + l * 4 + v] + r;
+        const uint32_t base = bases[q * NT + l * NWV + v] + r;
         if (lane < 32 && ((m >> (31 - lane)) & 1)) {
             const uint32_t before = lane ? __popc(m >> (32 - lane)) : 0;
             const uint32_t rank = base + before;
@@ -385,12 +408,12 @@ __global__ __launch_bounds__(256) void k2_search_fast(const K2Args a)
             if (total[q] > a.cap) atomicOr(a.overflow, 1u);
         }
     }
-    if (lane == 0 && list_n > (uint32_t)kListCap) atomicOr(a.overflow, 2u);
+    if (lane == 0 && list_n > (uint32_t)LCAP) atomicOr(a.overflow, 2u);
 }
 
-inline size_t k2_fast_lds_bytes(uint32_t wpb, int npre)
+inline size_t k2_fast_lds_bytes(uint32_t wpb, int npre, int nwv)
 {
-    return ((size_t)wpb * 65 + 4 * kListCap * 2 + 2 * (size_t)npre * 256 + 8) * 4;
+    return ((size_t)wpb * 65 + 4 * kListCap * 2 + 2 * (size_t)npre * 64 * nwv + 8) * 4;
 }
 
 // K2s: exclusive scan of counts[n_pre*n_tiles] (preamble-major) -> offsets, plus
