@@ -150,6 +150,14 @@ amr_status amr_submit_device(amr_handle *h, const void *d_iq, size_t n_blocks);
 amr_status amr_collect(amr_handle *h, amr_result *res);
 
 /*
+ * Device-side view of the result amr_collect / amr_decode_* returned last: the packed buffer
+ * [hit_block u64 x n | hit_idx u32 x n | pkt x n] in device memory, for consumers that stay on the GPU
+ * (the multi-GPU hit gather sends the first 12*n bytes over RCCL without a host round trip).
+ * Valid until the second amr_submit_device after that collect.
+ */
+amr_status amr_result_device(const amr_handle *h, const void **d_packed, uint64_t *n_hits);
+
+/*
  * Multi-GPU sharding: feed the ceil(PacketLength/BlockSize)+1
  * blocks that precede a shard so its magnitude / quantized history equals what
  * a single decoder would hold, without reporting hits or advancing the block

@@ -125,6 +125,7 @@ struct amr_handle {
     uint64_t calls_done = 0, block_base = 0;
     size_t last_n_blocks = 0;
     std::vector<uint64_t> r_off;
+    uint64_t last_total = 0;
 };
 
 namespace {
@@ -400,6 +401,7 @@ amr_status collect(amr_handle *h, amr_result *res)
         h->last_slot = si;
         h->last_n_blocks = s.n_blocks;
         h->r_off.assign(s.h_off, s.h_off + n_pre + 1);
+        h->last_total = total;
         if (res) {
             res->n_preambles = n_pre;
             res->pkt_bytes = h->sg.pkt_bytes;
@@ -651,6 +653,15 @@ amr_status amr_collect(amr_handle *h, amr_result *res)
 {
     if (!h) return fail(AMR_EINVAL, "null argument");
     return collect(h, res);
+}
+
+amr_status amr_result_device(const amr_handle *h, const void **d_packed, uint64_t *n_hits)
+{
+    if (!h || !d_packed || !n_hits) return fail(AMR_EINVAL, "null argument");
+    if (h->last_slot < 0) return fail(AMR_EINVAL, "no batch collected yet");
+    *d_packed = h->slot[h->last_slot].d_out;
+    *n_hits = h->last_total;
+    return AMR_OK;
 }
 
 size_t amr_halo_bytes(const amr_handle *h) { return h ? h->halo_bytes : 0; }

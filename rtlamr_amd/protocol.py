@@ -274,6 +274,13 @@ class Decoder:
         n_blocks, first = self._inflight.pop(0)
         return self._collect(res, n_blocks, first, copy)
 
+    def result_device(self):
+        """(device pointer, n_hits) of the packed result [hit_block u64 x n | hit_idx u32 x n | pkt x n] of the
+        batch collected last; valid until the second submit after that collect."""
+        p, n = C.c_void_p(), C.c_uint64()
+        _lib.check(_lib.lib().amr_result_device(self._require(), C.byref(p), C.byref(n)), "amr_result_device")
+        return int(p.value or 0), int(n.value)
+
     def run_parsers(self, br: BatchResult) -> List[List[Message]]:
         """decode.go:177-187 for every block of the batch: per preamble, Slice -> []Data -> each parser."""
         first = br.first_block

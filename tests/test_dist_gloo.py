@@ -94,3 +94,50 @@ def test_gather_handles_empty_rank(tmp_path):
     port = 31500 + (os.getpid() % 2000)
     mp.spawn(_w_empty, args=(2, port, str(tmp_path)), nprocs=2, join=True)
     assert np.load(os.path.join(str(tmp_path), "g.npy")).tolist() == [[0, 5, 7], [1, 6, 8]]
+
+
+def _w_gatherer(rank, world, port, out):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    tdist.init_process_group("gloo", rank=rank, world_size=world)
+    from rtlamr_amd import dist
+    from rtlamr_amd.protocol import BatchResult
+    g = dist.HitGatherer(2)
+    got = []
+    for step in range(4):   # more steps than buffer sets; growing hit counts force a re-negotiation
+        n0, n1 = 3 + step * (rank + 1) * 700, 2 + step
+        blk = np.arange(n0 + n1, dtype=np.uint64) + 1000 * rank + step
+        idx = (np.arange(n0 + n1, dtype=np.uint32) * 7 + rank) % 4096
+        br = BatchResult(8, 0, np.array([0, n0, n0 + n1], np.uint64), blk, idx, np.zeros((n0 + n1, 12), np.uint8))
+        if step == 0:
+            g.negotiate(len(idx))
+        fits = g.post(br)                 # always posts: collectives stay in lockstep
+        import torch
+        t = torch.tensor([1 if fits else 0])
+        tdist.all_reduce(t, op=tdist.ReduceOp.MIN)
+        if int(t.item()) == 0:            # some rank was truncated: everybody re-negotiates and posts again
+            g.negotiate(len(idx))
+            assert g.post(br)
+        res = g.result()
+        if rank == 0:
+            got.append(res)
+    if rank == 0:
+        np.save(os.path.join(out, "hg.npy"), np.concatenate(got))
+    tdist.destroy_process_group()
+
+
+def test_hit_gatherer_async_fixed_capacity(tmp_path):
+    """rtlamr_amd.dist.HitGatherer on gloo/CPU tensors: header + records of every rank arrive on rank 0, across
+    buffer-set reuse and a capacity re-negotiation."""
+    port = 33500 + (os.getpid() % 2000)
+    mp.spawn(_w_gatherer, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    got = np.load(os.path.join(str(tmp_path), "hg.npy"))
+    want = []
+    for step in range(4):
+        for rank in range(2):
+            n0, n1 = 3 + step * (rank + 1) * 700, 2 + step
+            blk = np.arange(n0 + n1, dtype=np.int64) + 1000 * rank + step
+            idx = (np.arange(n0 + n1, dtype=np.int64) * 7 + rank) % 4096
+            pid = np.concatenate([np.zeros(n0, np.int64), np.ones(n1, np.int64)])
+            want.append(np.stack([pid, blk, idx], axis=1))
+    assert np.array_equal(got, np.concatenate(want))
