@@ -150,6 +150,17 @@ amr_status amr_submit_device(amr_handle *h, const void *d_iq, size_t n_blocks);
 amr_status amr_collect(amr_handle *h, amr_result *res);
 
 /*
+ * The same pipeline for input in HOST memory (file replay, many-SDR aggregation; the caller the reference
+ * has is Receiver.Run, main.go:156-235): the batch is copied to a per-slot device buffer on a transfer
+ * stream, the kernels wait for that copy only, so the host-to-device transfer of batch i+1 overlaps the
+ * kernels of batch i.  iq must stay untouched until the batch is collected; memory from amr_host_alloc
+ * (pinned) makes the copy a true DMA -- pageable memory works but is staged by the runtime.
+ */
+amr_status amr_submit_host(amr_handle *h, const uint8_t *iq, size_t iq_bytes, size_t n_blocks);
+amr_status amr_host_alloc(size_t bytes, void **ptr);
+amr_status amr_host_free(void *ptr);
+
+/*
  * Device-side view of the result amr_collect / amr_decode_* returned last: the packed buffer
  * [hit_block u64 x n | hit_idx u32 x n | pkt x n] in device memory, for consumers that stay on the GPU
  * (the multi-GPU hit gather sends the first 12*n bytes over RCCL without a host round trip).

@@ -15,7 +15,7 @@ AMR_OK, AMR_EINVAL, AMR_ENOMEM, AMR_EHIP, AMR_ENODEV, AMR_EOVERFLOW = 0, -1, -2,
 # every symbol include/amrdemod.h declares (checked by tests/test_abi.py)
 SYMBOLS = [
     "amr_create", "amr_destroy", "amr_reset", "amr_get_geometry", "amr_preamble_id", "amr_get_mag_lut",
-    "amr_set_stream", "amr_set_block_base", "amr_decode_batch", "amr_decode_batch_device", "amr_submit_device", "amr_collect", "amr_result_device", "amr_prime",
+    "amr_set_stream", "amr_set_block_base", "amr_decode_batch", "amr_decode_batch_device", "amr_submit_device", "amr_collect", "amr_submit_host", "amr_host_alloc", "amr_host_free", "amr_result_device", "amr_prime",
     "amr_halo_bytes", "amr_prime_blocks", "amr_copy_quantized", "amr_set_timing", "amr_get_timing", "amr_strerror",
     "amr_last_error", "amr_describe", "amr_dev_alloc", "amr_dev_free", "amr_dev_upload", "amr_dev_download",
     "amr_dev_sync", "amr_synth_noise", "amr_synth_plant",
@@ -94,6 +94,9 @@ def lib() -> C.CDLL:
     L.amr_prime_blocks.argtypes = [vp]
     L.amr_prime_blocks.restype = C.c_size_t
     L.amr_copy_quantized.argtypes = [vp, vp, C.c_size_t]
+    L.amr_submit_host.argtypes = [vp, C.c_void_p, C.c_size_t, C.c_size_t]
+    L.amr_host_alloc.argtypes = [C.c_size_t, C.POINTER(C.c_void_p)]
+    L.amr_host_free.argtypes = [C.c_void_p]
     L.amr_result_device.argtypes = [vp, C.POINTER(C.c_void_p), C.POINTER(C.c_uint64)]
     L.amr_set_timing.argtypes = [vp, C.c_int32]
     L.amr_get_timing.argtypes = [vp, C.POINTER(AmrTiming)]

@@ -84,6 +84,8 @@ struct Slot {
     uint64_t *h_off = nullptr;    // [AMR_MAX_PREAMBLES+1]
     uint32_t *h_ovf = nullptr;
     uint8_t *h_out = nullptr; uint64_t host_cap = 0;
+    uint8_t *d_iq_stage = nullptr; size_t iq_stage_cap = 0;   // device copy of a host-resident batch (amr_submit_host)
+    hipEvent_t ev_h2d = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr, ev_s = nullptr, ev2 = nullptr;   // K1 start/stop, K2 start, K3 stop (timing levels 1/2)
     uint64_t *h_done = nullptr;   // pinned, coherent: the batch's last kernel stores the batch ticket here
     uint64_t ticket = 0;          // value that marks the batch in flight as complete
@@ -105,7 +107,7 @@ struct amr_handle {
     uint32_t halo_bytes = 0;   // HBA: aligned halo K1 reads before a block
     uint32_t hist_rows = 0;    // ceil(PL/BS)
 
-    hipStream_t own_stream = nullptr, stream = nullptr, copy_stream = nullptr;
+    hipStream_t own_stream = nullptr, stream = nullptr, copy_stream = nullptr, h2d_stream = nullptr;
     bool timing_valid = false;
     amr_timing timing{};
     int timing_level = 0;
@@ -529,12 +531,14 @@ amr_status amr_create(const amr_protocol *protos, int32_t n_protos, int32_t devi
     hipError_t e = hipSetDevice(device_id);
     if (e == hipSuccess) e = hipStreamCreateWithFlags(&h->own_stream, hipStreamNonBlocking);
     if (e == hipSuccess) e = hipStreamCreateWithFlags(&h->copy_stream, hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipStreamCreateWithFlags(&h->h2d_stream, hipStreamNonBlocking);
     h->stream = h->own_stream;
     for (Slot &sl : h->slot) {
         if (e == hipSuccess) e = hipEventCreate(&sl.ev0);
         if (e == hipSuccess) e = hipEventCreate(&sl.ev1);
         if (e == hipSuccess) e = hipEventCreate(&sl.ev2);
         if (e == hipSuccess) e = hipEventCreate(&sl.ev_s);
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&sl.ev_h2d, hipEventDisableTiming);
         if (e == hipSuccess) e = hipHostMalloc((void **)&sl.h_done, 8, hipHostMallocCoherent);
         if (e == hipSuccess) *sl.h_done = 0;
         if (e == hipSuccess) e = hipMalloc((void **)&sl.d_offs_pre, (AMR_MAX_PREAMBLES + 1) * 8);
@@ -561,7 +565,8 @@ amr_status amr_destroy(amr_handle *h)
     void *ptrs[] = {h->d_lut, h->d_carry, h->d_iq, h->d_untile};
     for (void *p : ptrs) if (p) (void)hipFree(p);
     for (Slot &sl : h->slot) {
-        void *dp[] = {sl.d_qt, sl.d_counts, sl.d_offsets, sl.d_offs_pre, sl.d_overflow, sl.d_staging, sl.d_out};
+        void *dp[] = {sl.d_qt, sl.d_counts, sl.d_offsets, sl.d_offs_pre, sl.d_overflow, sl.d_staging, sl.d_out, sl.d_iq_stage};
+        if (sl.ev_h2d) (void)hipEventDestroy(sl.ev_h2d);
         for (void *p : dp) if (p) (void)hipFree(p);
         void *hp[] = {sl.h_off, sl.h_ovf, sl.h_out};
         for (void *p : hp) if (p) (void)hipHostFree(p);
@@ -571,6 +576,7 @@ amr_status amr_destroy(amr_handle *h)
     }
     if (h->own_stream) (void)hipStreamDestroy(h->own_stream);
     if (h->copy_stream) (void)hipStreamDestroy(h->copy_stream);
+    if (h->h2d_stream) (void)hipStreamDestroy(h->h2d_stream);
     delete h;
     return AMR_OK;
 }
@@ -647,6 +653,39 @@ amr_status amr_submit_device(amr_handle *h, const void *d_iq, size_t n_blocks)
 {
     if (!h || !d_iq) return fail(AMR_EINVAL, "null argument");
     return submit(h, (const uint8_t *)d_iq, n_blocks, true);
+}
+
+amr_status amr_submit_host(amr_handle *h, const uint8_t *iq, size_t iq_bytes, size_t n_blocks)
+{
+    if (!h || !iq) return fail(AMR_EINVAL, "null argument");
+    const size_t need = n_blocks * (size_t)h->geom.block_size2;
+    if (iq_bytes < need) return fail(AMR_EINVAL, "short input (the Go decoder panics here, decode.go:222)");
+    if (n_blocks == 0) return fail(AMR_EINVAL, "n_blocks out of range");
+    if (h->n_pending >= 2) return fail(AMR_EINVAL, "two batches already in flight: call amr_collect first");
+    HIP_TRY(hipSetDevice(h->device));
+    Slot &s = h->slot[h->next_slot];   // the slot submit() is about to use; its previous batch has been collected
+    if (need > s.iq_stage_cap) {
+        AMR_TRY(dev_realloc(s.d_iq_stage, need));
+        s.iq_stage_cap = need;
+    }
+    HIP_TRY(hipMemcpyAsync(s.d_iq_stage, iq, need, hipMemcpyHostToDevice, h->h2d_stream));
+    HIP_TRY(hipEventRecord(s.ev_h2d, h->h2d_stream));
+    HIP_TRY(hipStreamWaitEvent(h->stream, s.ev_h2d, 0));
+    return submit(h, s.d_iq_stage, n_blocks, true);
+}
+
+amr_status amr_host_alloc(size_t bytes, void **ptr)
+{
+    if (!ptr || bytes == 0) return fail(AMR_EINVAL, "null argument");
+    hipError_t e = hipHostMalloc(ptr, bytes, hipHostMallocDefault);
+    if (e != hipSuccess) return fail(AMR_ENOMEM, "hipHostMalloc", e);
+    return AMR_OK;
+}
+
+amr_status amr_host_free(void *ptr)
+{
+    if (ptr) HIP_TRY(hipHostFree(ptr));
+    return AMR_OK;
 }
 
 amr_status amr_collect(amr_handle *h, amr_result *res)

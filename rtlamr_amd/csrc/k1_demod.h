@@ -148,17 +148,19 @@ __device__ __forceinline__ void k1_prefetch(const K1Args &a, uint32_t lds_base, 
     // would serialise the prefetch of tile t+1 with the consumption of tile t.  Hidden in asm, the DMA is
     // ordered by the explicit s_waitcnt vmcnt(0) in k1_fetch_next alone, and the row reads stay ordinary loads
     // that the compiler keeps in flight across groups.  "nt": every byte is read once.  SGPR base + 32-bit lane
-    // offset addressing keeps the per-lane state at two VGPRs.
+    // offset addressing keeps the per-lane state at two VGPRs.  The asm overwrites M0 (hipcc does not accept it as a
+    // clobber): nothing else here keeps a value in M0 across statements -- gfx9 DS instructions do not read it and
+    // hipcc's own s_set_gpr_idx_on/off pairs are self-contained.
     if (!TAIL && !carry_tile) {
         const uint8_t *base = sb;                                   // uniform
         uint32_t m0v = lds_base + buf_off;
 #pragma unroll 1
         for (int q = 0; q < 4; ++q) {                               // a rolled loop: this code sits in every group
             asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1 nt"
-                         :: "v"(voff_e), "s"(base), "s"(m0v) : "memory", "m0");
+                         :: "v"(voff_e), "s"(base), "s"(m0v) : "memory");
             base += (size_t)8 * bs2;
             asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1 nt"
-                         :: "v"(voff_o), "s"(base), "s"(m0v + 1024) : "memory", "m0");
+                         :: "v"(voff_o), "s"(base), "s"(m0v + 1024) : "memory");
             base += (size_t)8 * bs2;
             m0v += 2048;
         }
@@ -182,7 +184,7 @@ __device__ __forceinline__ void k1_prefetch(const K1Args &a, uint32_t lds_base, 
             }
         }
         asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off nt"
-                     :: "v"(g), "s"(lds_base + buf_off + q * 1024) : "memory", "m0");
+                     :: "v"(g), "s"(lds_base + buf_off + q * 1024) : "memory");
     }
 }
 

@@ -267,6 +267,17 @@ class Decoder:
         self._inflight.append((n_blocks, self._calls + self._block_base))
         self._calls += n_blocks
 
+    def submit_host(self, iq: np.ndarray) -> None:
+        """Pipelined form for host-resident input (whole blocks, uint8, contiguous): the H2D copy runs on its own
+        stream and overlaps the previous batch's kernels.  iq must stay untouched until the batch is collected;
+        pinned_buffer() memory makes the copy a true DMA."""
+        iq = np.ascontiguousarray(iq, dtype=np.uint8).reshape(-1)
+        n_blocks = iq.size // self.Cfg.BlockSize2
+        _lib.check(_lib.lib().amr_submit_host(self._require(), iq.ctypes.data, iq.size, n_blocks), "amr_submit_host")
+        self._inflight.append((n_blocks, self._calls + self._block_base))
+        self._keep = getattr(self, "_keep", [])[-1:] + [iq]   # keep the last two inputs alive
+        self._calls += n_blocks
+
     def collect(self, copy: bool = True) -> BatchResult:
         """Result of the oldest submitted batch."""
         res = _lib.AmrResult()
@@ -378,6 +389,27 @@ class Decoder:
         buf = C.create_string_buffer(256)
         _lib.check(_lib.lib().amr_describe(self._require(), buf, 256), "amr_describe")
         return buf.value.decode()
+
+
+class PinnedBuffer:
+    """uint8 numpy view of page-locked host memory (amr_host_alloc); free() or let it be garbage collected."""
+
+    def __init__(self, nbytes: int):
+        self._p = C.c_void_p()
+        _lib.check(_lib.lib().amr_host_alloc(nbytes, C.byref(self._p)), "amr_host_alloc")
+        self.array = np.ctypeslib.as_array((C.c_uint8 * nbytes).from_address(self._p.value))
+
+    def free(self) -> None:
+        if self._p is not None and self._p.value:
+            self.array = None
+            _lib.lib().amr_host_free(self._p)
+            self._p = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
 
 
 def new_decoder(device_id: int = 0) -> Decoder:

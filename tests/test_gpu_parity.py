@@ -193,3 +193,38 @@ def test_pathological_hit_density_grows_capacities():
         assert len(g[1]) > 100000
     finally:
         dec.close()
+
+
+def test_replay_file_equals_block_by_block_loop(tmp_path):
+    """rtlamr_amd.replay (large host batches through amr_submit_host, three rotating pinned buffers) must print what
+    the unchanged main.go loop prints: Decode one block at a time, drop a message whose digest the previous block
+    already produced (main.go:235-292)."""
+    from rtlamr_amd import replay
+    protos, chip = ["scm", "idm"], 72
+    one = util.make_decoder(protos, chip)
+    bs, bs2 = one.Cfg.BlockSize, one.Cfg.BlockSize2
+    n_blocks = 150
+    iq, pkts = util.synth_stream(protos, chip, n_blocks, bs, seed=41, n_packets=10, edge_every=2)
+    path = tmp_path / "capture.bin"
+    with open(path, "wb") as f:
+        f.write(iq.tobytes())
+        f.write(b"\x7f" * 1000)            # a partial trailing block is dropped
+    want, prev = [], set()
+    for k in range(n_blocks):
+        cur = set()
+        for m in one.Decode(iq[k * bs2:(k + 1) * bs2]):
+            key = (m.MsgType(), m.MeterType(), m.MeterID(), bytes(m.Checksum()))
+            cur.add(key)
+            if key not in prev:
+                want.append((k, key))
+        prev = cur
+    one.close()
+    assert len(want) >= len(pkts) - 1
+    dec = util.make_decoder(protos, chip)
+    try:
+        with open(path, "rb") as f:
+            got = [(k, (m.MsgType(), m.MeterType(), m.MeterID(), bytes(m.Checksum())))
+                   for k, m in replay.replay(dec, f, batch_blocks=37)]
+    finally:
+        dec.close()
+    assert got == want
