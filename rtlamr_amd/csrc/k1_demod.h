@@ -123,8 +123,9 @@ struct K1Lane {
 
 struct K1Uni {       // wave-uniform state (SGPRs)
     uint32_t G;      // 8-sample groups computed so far
-    uint32_t F;      // next group whose row will be read from LDS (runs 2 ahead of G)
-    uint32_t roff;   // LDS offset bits of group F: (F & 7) * 16 | ((F >> 3) & 1) * kTileBuf
+    uint32_t tcur;   // tile of the next row read
+    uint32_t roff;   // LDS offset bits of the next row read: (group in tile) * 16 | (tile parity) * kTileBuf
+    uint32_t wc;     // steady state: groups until the next output word completes, minus 1
     int32_t og;      // output groups produced so far (negative during warm-up)
     uint32_t ngroups;// total groups per lane
     uint32_t ntiles; // total staging tiles per lane
@@ -192,13 +193,17 @@ __device__ __forceinline__ void k1_prefetch(const K1Args &a, uint32_t lds_base, 
 // boundary first wait for the tile's DMA (issued one tile-time earlier), then refill the buffer that was
 // drained before it.  Groups past the end of the lane's stream read stale LDS bytes that nobody uses.
 // The LDS address is one v_xor: rdv = lane*128 | swizzle, U.roff = (group in tile)*16 | (tile parity)*8192.
+// Every wave-instruction costs the wave an issue slot of ~4.5 cycles and K1 is issue-bound (tools/dma_bench4.hip:
+// time grows linearly with the instruction count per group), so the common path is 4 scalar ops.
 template <int CL, bool TAIL>
 __device__ __forceinline__ uint4 k1_fetch_next(K1Uni &U, const K1Args &a, uint32_t tiles_lds, const uint8_t *tiles,
                                                uint32_t wg, uint32_t lane, uint32_t rdv, uint32_t voff_e,
                                                uint32_t voff_o, uint32_t rows_valid)
 {
-    if ((U.roff & 0x70) == 0) {
-        const uint32_t t = U.F >> 3;
+    if ((U.roff & 0x70) == 0) {                   // first group of a tile (rare path; the wrap of roff happens here too)
+        U.roff = (U.roff ^ ((U.roff & 0x80) << 6)) & (kTileBuf | 0x70);   // carry out of the group bits toggles the buffer
+        const uint32_t t = U.tcur;
+        U.tcur = t + 1;
         // vmcnt retires in order on gfx9 (loads and stores alike; checked by tools/dma_bench.hip), so the output
         // stores issued after the DMA of this tile need not be waited for.
         if (U.st == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -209,9 +214,7 @@ __device__ __forceinline__ uint4 k1_fetch_next(K1Uni &U, const K1Args &a, uint32
             k1_prefetch<CL, TAIL>(a, tiles_lds, wg, t + 1, ((t + 1) & 1) * kTileBuf, lane, voff_e, voff_o, rows_valid);
     }
     const uint4 r = *reinterpret_cast<const uint4 *>(tiles + (rdv ^ U.roff));
-    U.F += 1;
-    const uint32_t nx = U.roff + 16;              // 8 groups per tile, then the other buffer:
-    U.roff = (nx & 0x70) | ((nx ^ ((nx & 0x80) << 6)) & kTileBuf);   // the carry out of bit 6 toggles the buffer bit
+    U.roff += 16;                                 // 8 groups per tile; bit 7 set = wrapped, fixed up on the rare path
     return r;
 }
 
@@ -255,7 +258,9 @@ __device__ __forceinline__ void k1_flush(K1Lane<CL> &L, K1Uni &U, uint32_t *qbas
 // sched_barrier keeps hipcc from re-interleaving this into a load-wait-use chain per sample.
 // PRO: the zero-magnitude predicate of a fresh Decoder (decode.go:144), needed only by the wave that holds stream
 // block 0 while its first SymbolLength samples pass; CHECK: the last, partial body.
-template <int CL, bool PRO, bool CHECK, bool TAIL>
+// MODE 2 (PRO): the zero-magnitude predicate of a fresh Decoder; MODE 1: warm-up bookkeeping (no output before the
+// window is full); MODE 0: steady state -- word completion is a down-counter, nothing else is tracked per group.
+template <int CL, int MODE, bool CHECK, bool TAIL>
 __device__ __forceinline__ void k1_body(K1Lane<CL> &L, K1Uni &U, const K1Args &a, uint32_t tiles_lds,
                                         const uint8_t *tiles, const float *lut, uint32_t wg, uint32_t lane, uint32_t rdv,
                                         uint32_t zlim, uint32_t voff_e, uint32_t voff_o, uint32_t rows_valid,
@@ -264,6 +269,7 @@ __device__ __forceinline__ void k1_body(K1Lane<CL> &L, K1Uni &U, const K1Args &a
     using G = K1Geom<CL>;
 #pragma unroll
     for (int g = 0; g < G::GPB; ++g) {
+        constexpr bool PRO = MODE == 2;
         if (CHECK && U.G >= U.ngroups) return;
 #if AMR_K1_DIAG == 2
         L.acc ^= L.row1.x ^ L.row1.y ^ L.row1.z ^ L.row1.w;
@@ -316,22 +322,28 @@ __device__ __forceinline__ void k1_body(K1Lane<CL> &L, K1Uni &U, const K1Args &a
 #endif
         L.row1 = row2;
 #endif
-        U.G += 1;
-        U.og += 1;
-        // Output i leaves the filter at step WARM-1+i, i.e. one step before a group boundary: at a
-        // boundary acc holds outputs [32m+1 .. 32m+32]; output 32m is bit 0 of acc at the previous boundary.
-        // WARM/8 is a multiple of 8, so word boundaries are the groups with G % 4 == 0.
-        if ((U.og & 3) == 0 && U.og >= 0) {
-            if (U.og > 0) {
-                const uint32_t word = ~__builtin_amdgcn_alignbit(L.prev, L.acc, 1);
+        bool word_done;
+        if (MODE == 0 && !CHECK) {
+            word_done = U.wc == 0;
+            U.wc = word_done ? 3 : U.wc - 1;
+        } else {
+            U.G += 1;
+            U.og += 1;
+            // Output i leaves the filter at step WARM-1+i, i.e. one step before a group boundary: at a
+            // boundary acc holds outputs [32m+1 .. 32m+32]; output 32m is bit 0 of acc at the previous boundary.
+            // WARM/8 is a multiple of 8, so word boundaries are the groups with og % 4 == 0.
+            word_done = (U.og & 3) == 0 && U.og > 0;
+            if (U.og == 0) L.prev = L.acc;
+        }
+        if (word_done) {
+            const uint32_t word = ~__builtin_amdgcn_alignbit(L.prev, L.acc, 1);
 #if AMR_K1_DIAG == 3
-                L.xs ^= word * 0x9e3779b9u + U.wi;   // keep the computation alive without writing the bitstream
+            L.xs ^= word * 0x9e3779b9u + U.wi;   // keep the computation alive without writing the bitstream
 #endif
-                if (G::NW <= 32 || U.wi < (uint32_t)G::NW0) L.ow0[U.wi] = word;
-                else L.ow1[U.wi - G::NW0] = word;
-                U.wi += 1;
-                if (U.wi == (uint32_t)G::NW && AMR_K1_DIAG != 3) k1_flush<CL>(L, U, qrow, G::NW);
-            }
+            if (G::NW <= 32 || U.wi < (uint32_t)G::NW0) L.ow0[U.wi] = word;
+            else L.ow1[U.wi - G::NW0] = word;
+            U.wi += 1;
+            if (U.wi == (uint32_t)G::NW && AMR_K1_DIAG != 3) k1_flush<CL>(L, U, qrow, G::NW);
             L.prev = L.acc;
         }
     }
@@ -386,10 +398,12 @@ __global__ __launch_bounds__(64, 2) void k1_demod(const K1Args a)
     U.st = 0;
 
     // pipeline prologue: tile 0, the LUT values of group 0, the row of group 1
-    U.F = G::SKIP / 8;
+    U.tcur = 0;
+    U.wc = 0;
     U.roff = (G::SKIP / 8) * 16;     // SKIP < 64: still inside tile 0
     k1_prefetch<CL, TAIL>(a, tiles_lds, wg, 0, 0, lane, voff_e, voff_o, rows_valid);
     if (G::SKIP != 0) {   // consumption starts inside tile 0: do here what k1_fetch_next does on a tile boundary
+        U.tcur = 1;
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         if (1 < U.ntiles && AMR_K1_DIAG != 1)
             k1_prefetch<CL, TAIL>(a, tiles_lds, wg, 1, kTileBuf, lane, voff_e, voff_o, rows_valid);
@@ -410,15 +424,24 @@ __global__ __launch_bounds__(64, 2) void k1_demod(const K1Args a)
     }
 #endif
 
+    // bodies: [predicate bodies of a fresh stream's wave 0] [warm-up bodies until output flows] [steady] [partial]
     const uint32_t nfull = (U.ngroups - G::SKIP / 8) / G::GPB;   // whole bodies; the rest goes through the checked body
     uint32_t body = 0;
     if (fresh)
         for (; body < (uint32_t)G::NPB && body < nfull; ++body)
-            k1_body<CL, true, false, TAIL>(L, U, a, tiles_lds, tiles, lut, wg, lane, rdv, zlim, voff_e, voff_o, rows_valid, qrow);
+            k1_body<CL, 2, false, TAIL>(L, U, a, tiles_lds, tiles, lut, wg, lane, rdv, zlim, voff_e, voff_o, rows_valid, qrow);
+    for (; body < nfull && U.og <= 0; ++body)
+        k1_body<CL, 1, false, TAIL>(L, U, a, tiles_lds, tiles, lut, wg, lane, rdv, zlim, voff_e, voff_o, rows_valid, qrow);
+    U.wc = 3 - ((uint32_t)U.og & 3);          // og > 0 here (or no steady body runs): next word after 4 - og%4 groups
     for (; body < nfull; ++body)
-        k1_body<CL, false, false, TAIL>(L, U, a, tiles_lds, tiles, lut, wg, lane, rdv, zlim, voff_e, voff_o, rows_valid, qrow);
+        k1_body<CL, 0, false, TAIL>(L, U, a, tiles_lds, tiles, lut, wg, lane, rdv, zlim, voff_e, voff_o, rows_valid, qrow);
+    {   // the steady bodies did not count groups: re-derive the counters the checked body needs
+        const uint32_t done = G::SKIP / 8 + body * G::GPB;
+        U.og += (int32_t)(done - U.G);
+        U.G = done;
+    }
     if (U.G < U.ngroups)
-        k1_body<CL, true, true, TAIL>(L, U, a, tiles_lds, tiles, lut, wg, lane, rdv, zlim, voff_e, voff_o, rows_valid, qrow);
+        k1_body<CL, 1, true, TAIL>(L, U, a, tiles_lds, tiles, lut, wg, lane, rdv, zlim, voff_e, voff_o, rows_valid, qrow);
     if (U.wi && AMR_K1_DIAG != 3) k1_flush<CL>(L, U, qrow, U.wi);
     if (AMR_K1_DIAG == 3) qrow[lane * 4] = L.xs;
 }
