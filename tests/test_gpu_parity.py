@@ -228,3 +228,55 @@ def test_replay_file_equals_block_by_block_loop(tmp_path):
     finally:
         dec.close()
     assert got == want
+
+
+def test_torch_tensor_input_on_torch_stream():
+    """PyTorch as plumbing: IQ lives in a torch uint8 CUDA tensor, the decoder runs on a torch stream
+    (amr_set_stream) and consumes tensor.data_ptr() without a copy; result == the host-input path."""
+    import ctypes as C
+    import torch
+    from rtlamr_amd import _lib
+    protos, chip = ["scm"], 72
+    dec = util.make_decoder(protos, chip)
+    try:
+        iq, _ = util.synth_stream(protos, chip, 200, dec.Cfg.BlockSize, seed=77, n_packets=9)
+        want = util.gpu_run(dec, iq)
+        dec.reset()
+        st = torch.cuda.Stream()
+        with torch.cuda.stream(st):
+            t = torch.from_numpy(iq).to("cuda", non_blocking=True)      # produced on `st` ...
+            _lib.check(_lib.lib().amr_set_stream(dec._require(), C.c_void_p(st.cuda_stream)), "amr_set_stream")
+            br = dec.decode_batch_device(t.data_ptr(), 200)              # ... and consumed on `st`: ordered, no sync
+        q = dec.quantized_packed()
+        h = np.concatenate([np.stack([np.full(len(b), p, np.int64), b.astype(np.int64), i.astype(np.int64)], axis=1)
+                            for p in range(dec.n_preambles) for b, i, _ in [br.for_preamble(p)]])
+        assert np.array_equal(q, want[0]) and np.array_equal(h, want[1])
+        _lib.check(_lib.lib().amr_set_stream(dec._require(), None), "amr_set_stream")
+    finally:
+        dec.close()
+
+
+def test_error_paths_return_status_not_crash():
+    """Short input is AMR_EINVAL (the Go decoder panics, decode.go:222); a third submit without collect is refused;
+    illegal chip lengths are refused at create (flags.go:127-132)."""
+    import rtlamr_amd as ra
+    from rtlamr_amd import _lib
+    dec = util.make_decoder(["scm"], 72)
+    try:
+        with pytest.raises(IndexError):
+            dec.decode_batch(np.zeros(100, np.uint8))
+        res = _lib.AmrResult()
+        rc = _lib.lib().amr_decode_batch(dec._require(), np.zeros(8192, np.uint8).ctypes.data, 8192, 2, res)
+        assert rc == _lib.AMR_EINVAL
+        buf = ra.protocol.PinnedBuffer(4 * dec.Cfg.BlockSize2)
+        buf.array[:] = 127
+        dec.submit_host(buf.array)
+        dec.submit_host(buf.array)
+        with pytest.raises(_lib.AmrError):
+            dec.submit_host(buf.array)
+        dec.collect(); dec.collect()
+        buf.free()
+    finally:
+        dec.close()
+    with pytest.raises(Exception):
+        util.make_decoder(["scm"], 78)
