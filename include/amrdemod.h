@@ -88,6 +88,12 @@ typedef struct amr_result {
     const uint64_t *hit_block;        /* [n_hits] */
     const uint32_t *hit_idx;          /* [n_hits] */
     const uint8_t *pkt;               /* [n_hits * pkt_bytes] */
+    /*
+     * r900 second stage (amr_r900_enable): for every hit of the r900 preamble, in the order of that preamble's
+     * hits, the 42 base-6 digits r900.Parser.Parse reads from its quantized buffer (r900.go:187-193).
+     */
+    int32_t r900_preamble;            /* preamble id the digits belong to, -1 = not enabled */
+    const uint8_t *r900_digits;       /* [(off[r900_preamble+1]-off[r900_preamble]) * 42] */
 } amr_result;
 
 /* Timing of the last batch, measured with HIP events on the handle's stream. */
@@ -118,6 +124,13 @@ amr_status amr_get_geometry(const amr_handle *h, amr_geometry *out);
 int32_t amr_preamble_id(const amr_handle *h, int32_t proto_index);
 /* The float32 magnitude table, NewMagLUT (decode.go:209-216): 256 floats. */
 amr_status amr_get_mag_lut(const amr_handle *h, float *out256);
+
+/*
+ * The r900 parser's second matched filter (r900/r900.go:82-150) on the GPU, evaluated at the preamble hits only.
+ * proto_index = registration index of the r900 parser's entry; its preamble's hits then carry 42 digits each
+ * (amr_result.r900_digits).  Call after amr_create, before the first batch.
+ */
+amr_status amr_r900_enable(amr_handle *h, int32_t proto_index);
 
 /* Run on a caller-owned HIP stream (hipStream_t passed as void*); NULL = the handle's own stream. */
 amr_status amr_set_stream(amr_handle *h, void *hip_stream);

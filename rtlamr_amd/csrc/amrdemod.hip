@@ -20,6 +20,7 @@
 #include "amrdemod.h"
 #include "k1_demod.h"
 #include "k2_search.h"
+#include "k4_r900.h"
 #include "synth.h"
 
 namespace {
@@ -84,6 +85,7 @@ struct Slot {
     uint64_t *h_off = nullptr;    // [AMR_MAX_PREAMBLES+1]
     uint32_t *h_ovf = nullptr;
     uint8_t *h_out = nullptr; uint64_t host_cap = 0;
+    uint8_t *d_r900 = nullptr; uint8_t *h_r900 = nullptr; uint64_t r900_host_cap = 0;   // [out_cap][42] digits (r900 enabled)
     uint8_t *d_iq_stage = nullptr; size_t iq_stage_cap = 0;   // device copy of a host-resident batch (amr_submit_host)
     hipEvent_t ev_h2d = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr, ev_s = nullptr, ev2 = nullptr;   // K1 start/stop, K2 start, K3 stop (timing levels 1/2)
@@ -96,6 +98,8 @@ struct Slot {
     size_t n_blocks = 0;
     uint32_t n_tiles = 0;
     uint64_t calls_base = 0;
+    uint32_t iqhist_valid = 0;    // real samples in the IQ history this batch sees (r900)
+    int iqhist_buf = 0;           // which history buffer it reads
 };
 
 struct amr_handle {
@@ -128,6 +132,11 @@ struct amr_handle {
     size_t last_n_blocks = 0;
     std::vector<uint64_t> r_off;
     uint64_t last_total = 0;
+    // r900 second stage: the preamble id, and the PL samples of IQ that precede the next batch (two buffers, alternating)
+    int r900_pid = -1;
+    uint8_t *d_iqhist[3] = {nullptr, nullptr, nullptr};   // three, rotating: a batch in flight keeps its own for a re-run
+    int iqhist_cur = 0;
+    uint32_t iqhist_valid = 0;
 };
 
 namespace {
@@ -212,6 +221,7 @@ amr_status ensure_capacity(amr_handle *h, Slot &s, size_t n_blocks)
     if (s.out_cap == 0) {
         s.out_cap = 1 << 16;
         AMR_TRY(dev_realloc(s.d_out, s.out_cap * (12 + h->sg.pkt_bytes)));
+        if (h->r900_pid >= 0) AMR_TRY(dev_realloc(s.d_r900, s.out_cap * amr::kR900Digits));
     }
     return AMR_OK;
 }
@@ -266,6 +276,19 @@ amr_status enqueue_search(amr_handle *h, Slot &s, bool rerun = false)
     hipExtLaunchKernelGGL(amr::k3_slice, dim3(s.n_tiles, n_pre), dim3(256), 0, st, nullptr, t2 ? s.ev2 : nullptr, 0, k3);
     HIP_TRY(hipGetLastError());
     AMR_DBG(st, "k3_slice");
+    if (h->r900_pid >= 0) {
+        amr::K4Args k4{};
+        k4.iq = s.d_iq; k4.hist = h->d_iqhist[s.iqhist_buf]; k4.lut = h->d_lut; k4.out_packed = s.d_out;
+        k4.offs_pre = s.d_offs_pre; k4.digits = s.d_r900; k4.cap = s.out_cap; k4.block_base = s.calls_base;
+        k4.n_pre = n_pre; k4.pid = (uint32_t)h->r900_pid; k4.hist_valid = s.iqhist_valid;
+        k4.block_size = bs; k4.lg_block_size = h->sg.lg_block_size; k4.packet_length = (uint32_t)h->geom.packet_length;
+        k4.preamble_length = (uint32_t)h->geom.preamble_length; k4.symbol_length = (uint32_t)h->geom.symbol_length;
+        k4.chip_length = (uint32_t)h->geom.chip_length;
+        // the hit count is only known on the device: one 64-lane block per 64 possible hits, the surplus exits at once
+        hipLaunchKernelGGL(amr::k4_r900_digits, dim3((unsigned)((s.out_cap + 63) / 64)), dim3(64), 0, st, k4);
+        HIP_TRY(hipGetLastError());
+        AMR_DBG(st, "k4_r900_digits");
+    }
     return AMR_OK;
 }
 
@@ -287,6 +310,8 @@ amr_status submit(amr_handle *h, const uint8_t *d_iq, size_t n_blocks, bool sear
     s.n_tiles = (uint32_t)((n_blocks + 63) / 64) + 1;
     s.search = search;
     s.calls_base = h->calls_done + h->block_base;
+    s.iqhist_valid = h->iqhist_valid;
+    s.iqhist_buf = h->iqhist_cur;
 
     amr::K1Args k1{};
     k1.iq = d_iq;
@@ -305,6 +330,16 @@ amr_status submit(amr_handle *h, const uint8_t *d_iq, size_t n_blocks, bool sear
     AMR_DBG(st, "k1_demod");
     if (search) AMR_TRY(enqueue_search(h, s));
 
+    if (h->r900_pid >= 0) {   // the PL samples that precede the next batch (r900.go:168-170 keeps them as magnitudes)
+        const uint64_t n_batch = (uint64_t)n_blocks * bs;
+        const int nxt = (h->iqhist_cur + 1) % 3;
+        amr::IqHistArgs ih{d_iq, h->d_iqhist[h->iqhist_cur], h->d_iqhist[nxt], n_batch, (uint32_t)h->geom.packet_length};
+        hipLaunchKernelGGL(amr::k_iqhist_update, dim3(32), dim3(256), 0, st, ih);
+        HIP_TRY(hipGetLastError());
+        h->iqhist_cur = nxt;
+        const uint64_t v = (uint64_t)h->iqhist_valid + n_batch;
+        h->iqhist_valid = (uint32_t)std::min<uint64_t>(v, (uint64_t)h->geom.packet_length);
+    }
     // state carried to the next batch (decode.go:165-166): last rows of this slot's bitstream become the
     // history tile of the OTHER slot (where the next batch runs); last HBA bytes of IQ become the carry
     amr::HistArgs ha{s.d_qt, other.d_qt, (uint32_t)n_blocks, h->hist_rows, h->sg.wpb, h->sg.lg_wpb,
@@ -369,6 +404,7 @@ amr_status collect(amr_handle *h, amr_result *res)
                 s.out_cap = nc;
                 HIP_TRY(hipStreamSynchronize(h->stream));
                 AMR_TRY(dev_realloc(s.d_out, s.out_cap * (12 + h->sg.pkt_bytes)));
+                if (h->r900_pid >= 0) AMR_TRY(dev_realloc(s.d_r900, s.out_cap * amr::kR900Digits));
                 rerun = true;
             }
             if (!rerun) break;
@@ -384,6 +420,16 @@ amr_status collect(amr_handle *h, amr_result *res)
         }
         if (total) {   // on the copy stream: overlaps the next batch's kernels
             HIP_TRY(hipMemcpyAsync(s.h_out, s.d_out, total * (12 + h->sg.pkt_bytes), hipMemcpyDeviceToHost, h->copy_stream));
+            if (h->r900_pid >= 0) {
+                const uint64_t nr = s.h_off[h->r900_pid + 1] - s.h_off[h->r900_pid];
+                if (nr > s.r900_host_cap) {
+                    uint64_t nc = s.r900_host_cap ? s.r900_host_cap : 1024;
+                    while (nc < nr) nc *= 2;
+                    AMR_TRY(host_realloc(s.h_r900, nc * amr::kR900Digits));
+                    s.r900_host_cap = nc;
+                }
+                if (nr) HIP_TRY(hipMemcpyAsync(s.h_r900, s.d_r900, nr * amr::kR900Digits, hipMemcpyDeviceToHost, h->copy_stream));
+            }
             HIP_TRY(hipStreamSynchronize(h->copy_stream));
         }
     }
@@ -412,6 +458,8 @@ amr_status collect(amr_handle *h, amr_result *res)
             res->hit_block = reinterpret_cast<const uint64_t *>(s.h_out);
             res->hit_idx = reinterpret_cast<const uint32_t *>(s.h_out + total * 8);
             res->pkt = s.h_out + total * 12;
+            res->r900_preamble = h->r900_pid;
+            res->r900_digits = h->r900_pid >= 0 ? s.h_r900 : nullptr;
         }
     }
     return AMR_OK;
@@ -562,10 +610,11 @@ amr_status amr_destroy(amr_handle *h)
     (void)hipSetDevice(h->device);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
     if (h->copy_stream) (void)hipStreamSynchronize(h->copy_stream);
-    void *ptrs[] = {h->d_lut, h->d_carry, h->d_iq, h->d_untile};
+    void *ptrs[] = {h->d_lut, h->d_carry, h->d_iq, h->d_untile, h->d_iqhist[0], h->d_iqhist[1], h->d_iqhist[2]};
     for (void *p : ptrs) if (p) (void)hipFree(p);
     for (Slot &sl : h->slot) {
-        void *dp[] = {sl.d_qt, sl.d_counts, sl.d_offsets, sl.d_offs_pre, sl.d_overflow, sl.d_staging, sl.d_out, sl.d_iq_stage};
+        void *dp[] = {sl.d_qt, sl.d_counts, sl.d_offsets, sl.d_offs_pre, sl.d_overflow, sl.d_staging, sl.d_out, sl.d_iq_stage, sl.d_r900};
+        if (sl.h_r900) (void)hipHostFree(sl.h_r900);
         if (sl.ev_h2d) (void)hipEventDestroy(sl.ev_h2d);
         for (void *p : dp) if (p) (void)hipFree(p);
         void *hp[] = {sl.h_off, sl.h_ovf, sl.h_out};
@@ -592,6 +641,7 @@ amr_status amr_reset(amr_handle *h)
     h->zero_halo = true;
     h->calls_done = 0;
     h->last_n_blocks = 0;
+    h->iqhist_valid = 0;
     return AMR_OK;
 }
 
@@ -612,6 +662,23 @@ amr_status amr_get_mag_lut(const amr_handle *h, float *out256)
 {
     if (!h || !out256) return fail(AMR_EINVAL, "null argument");
     memcpy(out256, h->lut, sizeof h->lut);
+    return AMR_OK;
+}
+
+amr_status amr_r900_enable(amr_handle *h, int32_t proto_index)
+{
+    if (!h || proto_index < 0 || (size_t)proto_index >= h->proto_pid.size()) return fail(AMR_EINVAL, "bad protocol index");
+    if (h->calls_done != 0 || h->n_pending != 0) return fail(AMR_EINVAL, "amr_r900_enable: call before the first batch");
+    HIP_TRY(hipSetDevice(h->device));
+    h->r900_pid = h->proto_pid[(size_t)proto_index];
+    const size_t bytes = 2 * (size_t)h->geom.packet_length;
+    for (uint8_t *&p : h->d_iqhist) {
+        if (!p) AMR_TRY(dev_realloc(p, bytes));
+        HIP_TRY(hipMemset(p, 0, bytes));
+    }
+    for (Slot &sl : h->slot)
+        if (sl.out_cap && !sl.d_r900) AMR_TRY(dev_realloc(sl.d_r900, sl.out_cap * amr::kR900Digits));
+    h->iqhist_valid = 0;
     return AMR_OK;
 }
 

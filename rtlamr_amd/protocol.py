@@ -59,6 +59,7 @@ class Data:
     Idx: int = 0
     Bits: str = ""
     Bytes: bytes = b""
+    Digits: Optional[np.ndarray] = None   # r900 only: the 42 base-6 digits of this hit (r900.go:187-193), from the GPU
 
 
 def new_data(data: bytes) -> Data:
@@ -121,6 +122,8 @@ class BatchResult:
     hit_block: np.ndarray        # uint64 [n]
     hit_idx: np.ndarray          # uint32 [n]
     pkt: np.ndarray              # uint8 [n, pkt_bytes]
+    r900_preamble: int = -1      # preamble id whose hits carry digits, -1 = none
+    r900_digits: Optional[np.ndarray] = None   # uint8 [hits of that preamble, 42]
 
     def for_preamble(self, pid: int):
         lo, hi = int(self.preamble_offset[pid]), int(self.preamble_offset[pid + 1])
@@ -188,6 +191,8 @@ class Decoder:
         self.n_preambles = g.n_preambles
         for i, p in enumerate(self._parsers):
             self._pid_of_preamble[p.Cfg().Preamble] = L.amr_preamble_id(h, i)
+            if getattr(p, "NEEDS_R900_DIGITS", False):   # r900-type parser: its second matched filter runs on the GPU
+                _lib.check(L.amr_r900_enable(h, i), "amr_r900_enable")
 
     def close(self) -> None:
         if self._handle is not None:
@@ -237,7 +242,14 @@ class Decoder:
             blk = np.zeros(0, np.uint64)
             idx = np.zeros(0, np.uint32)
             pkt = np.zeros((0, int(res.pkt_bytes)), np.uint8)
-        return BatchResult(n_blocks, first_block, off, blk, idx, pkt)
+        rp = int(res.r900_preamble)
+        dg = None
+        if rp >= 0:
+            nr = int(off[rp + 1] - off[rp])
+            dg = np.ctypeslib.as_array(res.r900_digits, shape=(nr, 42)) if nr else np.zeros((0, 42), np.uint8)
+            if copy and nr:
+                dg = dg.copy()
+        return BatchResult(n_blocks, first_block, off, blk, idx, pkt, rp, dg)
 
     def decode_batch(self, iq) -> BatchResult:
         """n = len(iq)//BlockSize2 consecutive Decode calls (decode.go:163-172 + Search/Slice), no parsers."""
@@ -297,7 +309,9 @@ class Decoder:
         first = br.first_block
         out: List[List[Message]] = [[] for _ in range(br.n_blocks)]
         for pre in self._preamble_strs:
-            blk, idx, pkt = br.for_preamble(self._pid_of_preamble[pre])
+            pid = self._pid_of_preamble[pre]
+            blk, idx, pkt = br.for_preamble(pid)
+            digits = br.r900_digits if pid == br.r900_preamble else None
             if len(blk) == 0:
                 per_block = {}
             else:
@@ -313,6 +327,8 @@ class Decoder:
                     for i in range(s, e):
                         d = new_data(pkt[i].tobytes())
                         d.Idx = int(idx[i])
+                        if digits is not None:
+                            d.Digits = digits[i]
                         pkts.append(d)
                 elif not any(getattr(p, "ALWAYS_PARSE", False) for p in self._preambles[pre]):
                     continue

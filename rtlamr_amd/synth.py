@@ -112,3 +112,24 @@ def device_fill(device_id: int, d_ptr: int, n_samples: int, seed: int, first_sam
         _lib.check(L.amr_synth_plant(device_id, C.c_void_p(d_ptr), n_samples, first_sample, chip_length, len(packets),
                                      start.ctypes.data, bits.ctypes.data, n_bits, stride, di.ctypes.data,
                                      dq.ctypes.data), "amr_synth_plant")
+
+
+def plant_chips(iq: np.ndarray, start: int, chips: Sequence[int], chip_length: int, d_i: int, d_q: int,
+                first_sample: int = 0) -> None:
+    """OOK burst given chip by chip (1 = carrier on for chip_length samples): what plant() does for Manchester
+    bits, for symbol alphabets that are not Manchester (r900's six 4-chip symbols, r900.go:104-110)."""
+    n_samples = iq.size // 2
+    high = np.repeat(np.asarray(chips, bool), chip_length)
+    pos = start + np.flatnonzero(high) - first_sample
+    pos = pos[(pos >= 0) & (pos < n_samples)]
+    iq[2 * pos] = np.clip(iq[2 * pos].astype(np.int32) + d_i, 0, 255).astype(np.uint8)
+    iq[2 * pos + 1] = np.clip(iq[2 * pos + 1].astype(np.int32) + d_q, 0, 255).astype(np.uint8)
+
+
+def r900_chips(preamble: str, symbols: Sequence[int]) -> List[int]:
+    """Chips of one r900 burst: Manchester preamble (bit 1 = high,low) followed by the 6-ary payload symbols."""
+    from .parsers.r900 import symbols_to_chips
+    chips: List[int] = []
+    for b in preamble:
+        chips.extend((1, 0) if b == "1" else (0, 1))
+    return chips + symbols_to_chips(symbols)

@@ -29,7 +29,7 @@ def test_struct_layouts_match_header():
     assert C.sizeof(_lib.AmrGeometry) == 13 * 4
     assert C.sizeof(_lib.AmrProtocol) == 8 + 4 * 4
     assert C.sizeof(_lib.AmrTiming) == 12
-    assert C.sizeof(_lib.AmrResult) == 4 + 4 + 8 + 4 * 8
+    assert C.sizeof(_lib.AmrResult) == 4 + 4 + 8 + 4 * 8 + 8 + 8   # + r900_preamble (padded) + r900_digits
 
 
 def test_strerror_and_argument_checks(amr_lib):
