@@ -355,3 +355,43 @@ long orc_decode_stream(orc_decoder *d, const uint8_t *iq, long n_blocks, int mod
     free(cnt); free(idx); free(pb);
     return total;
 }
+
+/* ------------------------------------------------------------------------------------------------
+ * r900 second stage -- literal restatement of r900/r900.go:82-150 (Parser.filter) and of the buffer
+ * handling at the top of Parser.Parse (r900.go:168-170).  State lives in the caller-provided arrays:
+ *   signal[BufferLength], csum[BufferLength+1], quantized[BufferLength]  (r900.go:162-165, zero-initialised).
+ * Call once per Decode call, after orc_decode, like Parse is (decode.go:185-187).
+ */
+static float absf32(float x) { return x < 0 ? -x : x; }   /* r900.go:152-157 */
+
+void orc_r900_filter(const orc_decoder *d, float *signal, float *csum, uint8_t *quantized)
+{
+    int bs = d->block_size, pl = d->packet_length, sl = d->symbol_length, bl = d->buffer_length;
+    memmove(signal, signal + bs, (size_t)(bl - bs) * sizeof(float));          /* :168 copy(p.signal, p.signal[BlockSize:]) */
+    memcpy(signal + pl, d->signal + sl, (size_t)bs * sizeof(float));          /* :169-170 */
+
+    float sum = 0;                                                            /* :96-100 */
+    for (int idx = 0; idx < bl; idx++) {
+        sum += signal[idx];
+        csum[idx + 1] = sum;
+    }
+    int cl = d->chip_length, cl2 = cl * 2, cl3 = cl * 3, cl4 = cl * 4;        /* :112-116 */
+    int limit = bl - cl4;
+    for (int idx = 0; idx < limit; idx++) {                                   /* :121-149 */
+        float c0 = csum[idx];
+        float c1 = csum[idx + cl] + csum[idx + cl];
+        float c2 = csum[idx + cl2] + csum[idx + cl2];
+        float c3 = csum[idx + cl3] + csum[idx + cl3];
+        float c4 = csum[idx + cl4];
+        float a0 = c2 - c4 - c0;
+        float a1 = c1 - c2 + c3 - c4 - c0;
+        float a2 = c1 - c3 + c4 - c0;
+        float max_abs = absf32(a0);
+        uint8_t argmax = 0;
+        if (absf32(a1) > max_abs) { max_abs = absf32(a1); argmax = 1; }
+        if (absf32(a2) > max_abs) { max_abs = absf32(a2); argmax = 2; }
+        float v[3] = {a0, a1, a2};
+        quantized[idx] = argmax;
+        if (v[argmax] > 0) quantized[idx] += 3;
+    }
+}

@@ -73,6 +73,8 @@ def lib():
         L.orc_decode_stream.argtypes = [C.c_void_p, C.c_void_p, C.c_long, C.c_int, C.c_void_p,
                                         C.c_void_p, C.c_void_p, C.c_long]
         L.orc_decode_stream.restype = C.c_long
+        L.orc_r900_filter.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.orc_r900_filter.restype = None
         _lib = L
     return _lib
 
@@ -161,6 +163,22 @@ class OracleDecoder:
         if total > hits_cap:
             raise OverflowError(f"{total} hits > cap {hits_cap}")
         return q, hits[:total].copy(), hb[:total].copy()
+
+
+class R900Filter:
+    """r900.Parser's buffers + filter (r900.go:82-150, 160-170), literal C restatement (decode_oracle.c)."""
+
+    def __init__(self, dec: OracleDecoder):
+        self.dec = dec
+        bl = dec.geom.buffer_length
+        self.signal = np.zeros(bl, np.float32)
+        self.csum = np.zeros(bl + 1, np.float32)
+        self.quantized = np.zeros(bl, np.uint8)
+
+    def step(self) -> np.ndarray:
+        """Call after every OracleDecoder.decode (Parse runs once per Decode call); returns p.quantized."""
+        lib().orc_r900_filter(self.dec._h, self.signal.ctypes.data, self.csum.ctypes.data, self.quantized.ctypes.data)
+        return self.quantized
 
 
 def next_power_of_2(v: int) -> int:

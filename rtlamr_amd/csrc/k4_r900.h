@@ -95,23 +95,46 @@ __global__ __launch_bounds__(64) void k4_r900_digits(const K4Args a)
         const uint32_t o = __shfl_xor(wave_last, d);
         wave_last = o > wave_last ? o : wave_last;
     }
-    for (uint32_t j8 = j0 & ~7u; j8 < wave_last; j8 += 8) {
-        if (j8 >= last) continue;              // this lane is done; others in the wave may not be
-        const int64_t nb = n0 + j8;            // batch-relative sample of the chunk
-        const uint4 w = nb >= 0 ? *reinterpret_cast<const uint4 *>(a.iq + 2 * nb)
-                                : *reinterpret_cast<const uint4 *>(a.hist + 2 * ((int64_t)PL + nb));
-        const uint32_t dw[4] = {w.x, w.y, w.z, w.w};
+    // The walk.  Chip boundaries are CL samples apart, so in ANY window of CL consecutive samples a lane meets exactly
+    // one of its own; the lanes of a wave meet theirs at different samples (adjacent hits), which would run the
+    // record() body -- under a one-lane mask -- for almost every sample.  Instead a boundary is only CAPTURED when it
+    // passes (two predicated moves) and all lanes record together once per CL samples.  32 samples per round, the four
+    // 16-byte loads issued together.
+    const uint32_t chunks_per_epoch = CL >> 3;       // every legal chip length is a multiple of 8
+    uint32_t cc = 0;
+    float cap = 0.f;
+    bool pending = false;
+    for (uint32_t j32 = j0 & ~31u; j32 < wave_last; j32 += 32) {
+        uint4 w[4];
 #pragma unroll
-        for (int s = 0; s < 8; ++s) {
-            const uint32_t j = j8 + s;
-            const uint32_t v = dw[s >> 1] >> ((s & 1) * 16);
-            const float mag = lut[v & 0xff] + lut[(v >> 8) & 0xff];       // decode.go:222
-            if (j >= j0 && j < last) {
-                sum += mag;                                               // r900.go:97-99
-                if (j + 1 == next_pt) record(sum);
+        for (int q = 0; q < 4; ++q) {
+            const int64_t nb = n0 + j32 + 8 * q;     // batch-relative sample of the chunk; chunks past `last` are not used
+            const bool need = active && j32 + 8 * q < last && j32 + 8 * q + 8 > j0;
+            w[q] = !need ? make_uint4(0, 0, 0, 0)
+                 : nb >= 0 ? *reinterpret_cast<const uint4 *>(a.iq + 2 * nb)
+                           : *reinterpret_cast<const uint4 *>(a.hist + 2 * ((int64_t)PL + nb));
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const uint32_t dw[4] = {w[q].x, w[q].y, w[q].z, w[q].w};
+#pragma unroll
+            for (int s = 0; s < 8; ++s) {
+                const uint32_t j = j32 + 8 * q + s;
+                const uint32_t v = dw[s >> 1] >> ((s & 1) * 16);
+                const float mag = lut[v & 0xff] + lut[(v >> 8) & 0xff];       // decode.go:222
+                const bool in = j >= j0 && j < last;
+                sum = in ? sum + mag : sum;                                   // r900.go:97-99
+                const bool at = in && j + 1 == next_pt;
+                cap = at ? sum : cap;
+                pending = pending || at;
+            }
+            if (++cc == chunks_per_epoch) {          // wave-uniform
+                cc = 0;
+                if (pending) { record(cap); pending = false; }
             }
         }
     }
+    if (pending) record(cap);
 }
 
 // The last PL samples that precede the next batch: new[i] = sample (i - PL + n_batch) of the batch just processed,

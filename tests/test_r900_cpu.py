@@ -58,3 +58,29 @@ def test_oracle_recovers_planted_r900_bursts():
         if m is not None:
             got.add(m.ID)
     assert got == set(mids)
+
+
+def test_numpy_oracle_equals_literal_c_filter():
+    """oracle/r900_oracle.py (digits at the hits only) against the literal C restatement of Parser.filter, which
+    quantizes the whole buffer on every call as the reference does."""
+    from oracle.oracle import OracleDecoder, R900Filter
+    chip = 72
+    o = OracleDecoder(["r900"], chip)
+    g = o.geom
+    pre = r900_oracle.PROTOCOLS["r900"][0]
+    burst = (64 + 168) * chip
+    iq = _stream_with_bursts(chip, 12, g.block_size, pre, [424242, 99], 21, [3000, 6 * g.block_size - burst // 2])
+    hits, digits = r900_oracle.digits_for_stream(["r900"], chip, iq)
+    assert len(hits) > 50
+    flt = R900Filter(o)
+    pid = o.preamble_ids[0]
+    row = 0
+    for k in range(12):
+        res = o.decode(iq[k * g.block_size2:(k + 1) * g.block_size2])
+        q = flt.step()
+        for idx in res[pid][0]:
+            payload = int(idx) + g.preamble_length - g.symbol_length
+            want = q[payload + np.arange(42) * 4 * chip]
+            assert tuple(hits[row]) == (k, int(idx)) and np.array_equal(digits[row], want)
+            row += 1
+    assert row == len(hits)
