@@ -181,7 +181,10 @@ __global__ __launch_bounds__(256) void k2_search_dense(const K2Args a)
 // tile set with k2_search_dense.
 constexpr int kListCap = 448;  // (key, mask) entries per wave
 
-__device__ __forceinline__ uint32_t k2_depth(uint32_t npre) { return 9u + (npre > 2 ? 2u : npre > 1 ? 1u : 0u); }
+#ifndef AMR_K2_DEPTH
+#define AMR_K2_DEPTH 9
+#endif
+__device__ __forceinline__ uint32_t k2_depth(uint32_t npre) { return (uint32_t)AMR_K2_DEPTH + (npre > 2 ? 2u : npre > 1 ? 1u : 0u); }
 
 // NWV waves share one tile (8 when a row has >= 32 words: 24 waves per CU hide the LDS latency of the tap loop,
 // which is what bounds this kernel; 4 for the 512-sample blocks of chip length 8).
