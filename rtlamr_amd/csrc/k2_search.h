@@ -169,7 +169,7 @@ __global__ __launch_bounds__(256) void k2_search_dense(const K2Args a)
 // common case that hits are sparse:
 //   * lane = row (reference block) of the tile, the unit K1 computed, so the tile is laid out in LDS as
 //     [word][65] (column 64 = row 0 of the next tile) and a lane's window never leaves its column pair;
-//   * stage 1: a wave handles 4 consecutive words (128 positions) of all 64 rows per step and applies
+//   * stage 1: a wave handles 8 consecutive words (256 positions; 4 with the 4-wave variant) of all 64 rows per step and applies
 //     only the first D taps (D = 9 + log2 NPRE), without any early-out test: in noise 2^-D of the
 //     positions survive.  The per-tap scalar work (offset, shift, preamble bit) is shared by 4 words,
 //     the 4-5 LDS reads use immediate offsets and are issued one tap ahead of their use;
@@ -202,6 +202,7 @@ __global__ __launch_bounds__(64 * NWV) void k2_search_fast(const K2Args a)
     const uint32_t tile_words = 64u << lg_wpb;
     uint32_t *tile = lds;                              // [wpb][65]
     constexpr int NT = 64 * NWV;                       // threads
+    constexpr int JW = NWV == 8 ? 8 : 4;               // words per lane per stage-1 step: the per-tap scalar work is shared by JW words
     constexpr int LCAP = kListCap * 4 / NWV;           // list entries per wave: the candidates split with the words
     uint32_t *lists = tile + wpb * 65;                 // [NWV][LCAP][2]
     uint32_t *cnts = lists + 4 * kListCap * 2;         // [NPRE][NT], index row*NWV+wave
@@ -242,17 +243,17 @@ __global__ __launch_bounds__(64 * NWV) void k2_search_fast(const K2Args a)
     const uint32_t *lane_tile = tile + lane;
 
     // window words A[0..4] of tap p for the step that starts at word w0 (uniform addressing)
-    auto load_tap = [&](uint32_t w0, uint32_t p, uint32_t (&A)[5]) {
+    auto load_tap = [&](uint32_t w0, uint32_t p, uint32_t (&A)[JW + 1]) {
         const uint32_t o = p * SL;
         const uint32_t x0 = w0 + (o >> 5);
         const uint32_t xm = x0 & wpb_mask;
-        if (xm + 5 <= wpb) {                             // all words in one row: immediate offsets
+        if (xm + JW + 1 <= wpb) {                        // all words in one row: immediate offsets
             const uint32_t *src = lane_tile + xm * 65 + (x0 >> lg_wpb);
 #pragma unroll
-            for (int j = 0; j < 5; ++j) A[j] = src[j * 65];
+            for (int j = 0; j < JW + 1; ++j) A[j] = src[j * 65];
         } else {                                         // the window crosses into the next row
 #pragma unroll
-            for (int j = 0; j < 5; ++j) {
+            for (int j = 0; j < JW + 1; ++j) {
                 const uint32_t x = x0 + j;
                 A[j] = lane_tile[(x & wpb_mask) * 65 + (x >> lg_wpb)];
             }
@@ -263,36 +264,36 @@ __global__ __launch_bounds__(64 * NWV) void k2_search_fast(const K2Args a)
 #ifndef AMR_K2_DIAG
 #define AMR_K2_DIAG 0   // developer diagnostics: 1 = no search at all (staging, barriers, scan only), 2 = stage 1 only
 #endif
-    for (uint32_t c = 0; c < (AMR_K2_DIAG == 1 ? 0u : (wq >> 2)); ++c) {
-        const uint32_t w0 = v * wq + 4 * c;
-        uint32_t M[NPRE][4];
+    for (uint32_t c = 0; c < (AMR_K2_DIAG == 1 ? 0u : wq / JW); ++c) {
+        const uint32_t w0 = v * wq + JW * c;
+        uint32_t M[NPRE][JW];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
+        for (int j = 0; j < JW; ++j) {
             const uint32_t ok = (w0 + j >= w_lo && w0 + j < w_hi) ? 0xffffffffu : 0u;
 #pragma unroll
             for (int q = 0; q < NPRE; ++q) M[q][j] = ok;
         }
         // one tap: W = the 4 windows (plain or 16-bit funnel shift, a wave-uniform choice), M &= W ^ inv
-        auto apply_tap = [&](uint32_t p, const uint32_t (&A)[5]) {
-            uint32_t W[4];
+        auto apply_tap = [&](uint32_t p, const uint32_t (&A)[JW + 1]) {
+            uint32_t W[JW];
             if ((p * SL) & 31) {                         // SL multiple of 16: shift is 0 or 16
 #pragma unroll
-                for (int j = 0; j < 4; ++j) W[j] = __builtin_amdgcn_alignbit(A[j], A[j + 1], 16);
+                for (int j = 0; j < JW; ++j) W[j] = __builtin_amdgcn_alignbit(A[j], A[j + 1], 16);
             } else {
 #pragma unroll
-                for (int j = 0; j < 4; ++j) W[j] = A[j];
+                for (int j = 0; j < JW; ++j) W[j] = A[j];
             }
 #pragma unroll
             for (int q = 0; q < NPRE; ++q) {
                 if (p < plen[q]) {
                     const uint32_t inv = ((pbits[q] >> p) & 1) ? 0u : 0xffffffffu;
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) M[q][j] &= W[j] ^ inv;
+                    for (int j = 0; j < JW; ++j) M[q][j] &= W[j] ^ inv;
                 }
             }
         };
         // two taps per iteration on ping-pong buffers: the loads of tap p+1 are in flight while tap p is applied
-        uint32_t A0[5], A1[5];
+        uint32_t A0[JW + 1], A1[JW + 1];
         load_tap(w0, 0, A0);
         for (uint32_t p = 0; p < D; p += 2) {
             if (p + 1 < D) load_tap(w0, p + 1, A1);
@@ -306,7 +307,7 @@ __global__ __launch_bounds__(64 * NWV) void k2_search_fast(const K2Args a)
 #pragma unroll
         for (int q = 0; q < NPRE; ++q) {
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
+            for (int j = 0; j < JW; ++j) {
                 const uint32_t m = M[q][j];
                 const uint64_t b = __ballot(m != 0);
                 if (b) {
