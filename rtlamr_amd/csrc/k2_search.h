@@ -188,7 +188,7 @@ __device__ __forceinline__ uint32_t k2_depth(uint32_t npre) { return (uint32_t)A
 
 // NWV waves share one tile (8 when a row has >= 32 words: 24 waves per CU hide the LDS latency of the tap loop,
 // which is what bounds this kernel; 4 for the 512-sample blocks of chip length 8).
-template <int NPRE, int NWV>
+template <int NPRE, int NWV, int JW>
 __global__ __launch_bounds__(64 * NWV) void k2_search_fast(const K2Args a)
 {
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
@@ -202,7 +202,7 @@ __global__ __launch_bounds__(64 * NWV) void k2_search_fast(const K2Args a)
     const uint32_t tile_words = 64u << lg_wpb;
     uint32_t *tile = lds;                              // [wpb][65]
     constexpr int NT = 64 * NWV;                       // threads
-    constexpr int JW = NWV == 8 ? 8 : 4;               // words per lane per stage-1 step: the per-tap scalar work is shared by JW words
+    // JW = words per lane per stage-1 step: the per-tap scalar work is shared by JW words (8; 4 for 512-sample blocks)
     constexpr int LCAP = kListCap * 4 / NWV;           // list entries per wave: the candidates split with the words
     uint32_t *lists = tile + wpb * 65;                 // [NWV][LCAP][2]
     uint32_t *cnts = lists + 4 * kListCap * 2;         // [NPRE][NT], index row*NWV+wave
