@@ -98,6 +98,7 @@ struct Slot {
     size_t n_blocks = 0;
     uint32_t n_tiles = 0;
     uint64_t calls_base = 0;
+    bool dense = false;           // searched with the dense kernel from the start (dense_hold)
     uint32_t iqhist_valid = 0;    // real samples in the IQ history this batch sees (r900)
     int iqhist_buf = 0;           // which history buffer it reads
 };
@@ -120,7 +121,9 @@ struct amr_handle {
     float *d_lut = nullptr;
     uint8_t *d_carry = nullptr;
     bool zero_halo = true;
-    bool dense_search = false;   // set when the sparse-list search overflowed once
+    bool dense_search = false;   // test hook (AMR_DENSE_SEARCH): always use the fallback search kernel
+    int dense_streak = 0;        // consecutive batches whose sparse lists overflowed; >= 4: stay dense for a while
+    int dense_hold = 0;          // batches left in which the dense kernel is used straight away
     uint8_t *d_iq = nullptr;      size_t iq_cap = 0;       // staging for host input
     uint32_t *d_untile = nullptr; size_t untile_words = 0;
 
@@ -227,7 +230,7 @@ amr_status ensure_capacity(amr_handle *h, Slot &s, size_t n_blocks)
 }
 
 // K2 + K2s + K3 for the batch held by slot s (may be re-run after a capacity overflow).
-amr_status enqueue_search(amr_handle *h, Slot &s, bool rerun = false)
+amr_status enqueue_search(amr_handle *h, Slot &s, bool rerun = false, bool dense = false)
 {
     hipStream_t st = h->stream;
     const uint32_t n_pre = h->sg.n_pre;
@@ -245,7 +248,7 @@ amr_status enqueue_search(amr_handle *h, Slot &s, bool rerun = false)
     const bool t2 = s.timed >= 2;
     // the overflow word is zeroed by the previous batch's k_hist_update; only a re-run has to do it here
     if (rerun) HIP_TRY(hipMemsetAsync(s.d_overflow, 0, 4, st));
-    if (!h->dense_search && n_pre <= 4) {
+    if (!h->dense_search && !dense && n_pre <= 4) {
         const int nwv = h->sg.wpb >= 32 ? 8 : 4;
         const size_t lds2 = amr::k2_fast_lds_bytes(h->sg.wpb, (int)n_pre, nwv);
 #define AMR_K2_LAUNCH(N, W, J)                                                                                        \
@@ -332,7 +335,9 @@ amr_status submit(amr_handle *h, const uint8_t *d_iq, size_t n_blocks, bool sear
     if (rem) { k1.wg_first = full; launch_k1<true>(h->geom.chip_length, dim3(1), st, k1, full ? nullptr : e0, e1); }
     HIP_TRY(hipGetLastError());
     AMR_DBG(st, "k1_demod");
-    if (search) AMR_TRY(enqueue_search(h, s));
+    s.dense = h->dense_hold > 0;
+    if (s.dense) h->dense_hold--;
+    if (search) AMR_TRY(enqueue_search(h, s, false, s.dense));
 
     if (h->r900_pid >= 0) {   // the PL samples that precede the next batch (r900.go:168-170 keeps them as magnitudes)
         const uint64_t n_batch = (uint64_t)n_blocks * bs;
@@ -388,13 +393,17 @@ amr_status collect(amr_handle *h, amr_result *res)
     const uint32_t n_pre = h->sg.n_pre;
     AMR_TRY(wait_done(h, s));
     uint64_t total = 0;
+    bool use_dense = s.dense;
     if (s.search) {
         for (int attempt = 0;; ++attempt) {
             const uint32_t ovf = *s.h_ovf;
             total = s.h_off[n_pre];
             if (attempt > 8) return fail(AMR_EOVERFLOW, "hit capacity could not be grown");
             bool rerun = false;
-            if (ovf & 2u) { h->dense_search = true; rerun = true; }   // sparse hit list overflowed: dense kernel
+            // sparse hit list overflowed (e.g. the zero history of a fresh stream matches r900's 16 leading zeros):
+            // this batch is searched again with the dense kernel; the next one starts sparse again unless
+            // overflows keep coming
+            if (ovf & 2u) { use_dense = true; rerun = true; }
             if (ovf & 1u) {   // a tile found more hits than its staging slot holds
                 s.stage_cap *= 8;
                 const uint64_t lim = (uint64_t)64 * h->geom.block_size;
@@ -413,8 +422,13 @@ amr_status collect(amr_handle *h, amr_result *res)
             }
             if (!rerun) break;
             // the slot's bitstream is intact until the slot is reused, so the search can simply run again
-            AMR_TRY(enqueue_search(h, s, true));
+            AMR_TRY(enqueue_search(h, s, true, use_dense));
             HIP_TRY(hipStreamSynchronize(h->stream));
+        }
+        if (use_dense && !s.dense) {
+            if (++h->dense_streak >= 4) { h->dense_hold = 32; h->dense_streak = 0; }
+        } else if (!use_dense) {
+            h->dense_streak = 0;
         }
         if (total > s.host_cap) {
             uint64_t nc = s.host_cap ? s.host_cap : (1 << 16);
