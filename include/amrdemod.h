@@ -94,6 +94,8 @@ typedef struct amr_result {
      */
     int32_t r900_preamble;            /* preamble id the digits belong to, -1 = not enabled */
     const uint8_t *r900_digits;       /* [(off[r900_preamble+1]-off[r900_preamble]) * 42] */
+    /* hits the search found; n_hits is smaller only when amr_set_validation dropped some on the device */
+    uint64_t n_hits_searched;
 } amr_result;
 
 /* Timing of the last batch, measured with HIP events on the handle's stream. */
@@ -131,6 +133,32 @@ amr_status amr_get_mag_lut(const amr_handle *h, float *out256);
  * (amr_result.r900_digits).  Call after amr_create, before the first batch.
  */
 amr_status amr_r900_enable(amr_handle *h, int32_t proto_index);
+
+/*
+ * Per-hit validation on the GPU (optional): what every rtlamr parser does first with a packet, done before the
+ * hits leave the device, so that the read-back (and the multi-GPU hit gather) carries only hits a parser can
+ * turn into a message.  A hit of preamble_id is dropped when one of the CRC checks fails, or when its first
+ * dedupe_bytes packet bytes equal those of the hit right before it in the same block (Parse's `seen` map drops
+ * those too).  The parsers run unchanged on what is left and emit the same messages.
+ *   check = crc.Checksum (crc/crc.go:49-55) over one or two byte spans of the packet, compared with residue:
+ *     SCM     scm/scm.go:77           {0x0000, 0x6F63, 0x0000, spans {2,10}}
+ *     SCM+    scmplus/scmplus.go:77   {0xFFFF, 0x1021, 0x1D0F, spans {2,14}}
+ *     IDM, NetIDM  idm/idm.go:77-87, netidm/netidm.go:88-98
+ *                                     {0xFFFF, 0x1021, 0x1D0F, spans {4,88}} and {.., spans {9,4},{88,2}}
+ * v == NULL switches the preamble's validation off.  Not allowed on the r900 preamble (its hits carry digits).
+ * Call with no batch in flight.
+ */
+typedef struct amr_crc_check {
+    uint16_t init, poly, residue;
+    uint16_t n_spans;                 /* 1 or 2 */
+    uint16_t span_off[2], span_len[2];
+} amr_crc_check;
+typedef struct amr_validator {
+    int32_t n_checks;                 /* 0..2, all must pass */
+    int32_t dedupe_bytes;             /* 0 = keep repeats; else the parser's own packet length in bytes */
+    amr_crc_check checks[2];
+} amr_validator;
+amr_status amr_set_validation(amr_handle *h, int32_t preamble_id, const amr_validator *v);
 
 /* Run on a caller-owned HIP stream (hipStream_t passed as void*); NULL = the handle's own stream. */
 amr_status amr_set_stream(amr_handle *h, void *hip_stream);
@@ -175,7 +203,8 @@ amr_status amr_host_free(void *ptr);
 
 /*
  * Device-side view of the result amr_collect / amr_decode_* returned last: the packed buffer
- * [hit_block u64 x n | hit_idx u32 x n | pkt x n] in device memory, for consumers that stay on the GPU
+ * [hit_block u64 x n | hit_idx u32 x n | pkt x n] in device memory (the validated list when
+ * amr_set_validation is active), for consumers that stay on the GPU
  * (the multi-GPU hit gather sends the first 12*n bytes over RCCL without a host round trip).
  * Valid until the second amr_submit_device after that collect.
  */

@@ -14,7 +14,7 @@ AMR_OK, AMR_EINVAL, AMR_ENOMEM, AMR_EHIP, AMR_ENODEV, AMR_EOVERFLOW = 0, -1, -2,
 
 # every symbol include/amrdemod.h declares (checked by tests/test_abi.py)
 SYMBOLS = [
-    "amr_create", "amr_destroy", "amr_reset", "amr_get_geometry", "amr_preamble_id", "amr_get_mag_lut", "amr_r900_enable",
+    "amr_create", "amr_destroy", "amr_reset", "amr_get_geometry", "amr_preamble_id", "amr_get_mag_lut", "amr_r900_enable", "amr_set_validation",
     "amr_set_stream", "amr_set_block_base", "amr_decode_batch", "amr_decode_batch_device", "amr_submit_device", "amr_collect", "amr_submit_host", "amr_host_alloc", "amr_host_free", "amr_result_device", "amr_prime",
     "amr_halo_bytes", "amr_prime_blocks", "amr_copy_quantized", "amr_set_timing", "amr_get_timing", "amr_strerror",
     "amr_last_error", "amr_describe", "amr_dev_alloc", "amr_dev_free", "amr_dev_upload", "amr_dev_download",
@@ -44,7 +44,17 @@ class AmrResult(C.Structure):
     _fields_ = [("n_preambles", C.c_uint32), ("pkt_bytes", C.c_uint32), ("n_hits", C.c_uint64),
                 ("preamble_offset", C.POINTER(C.c_uint64)), ("hit_block", C.POINTER(C.c_uint64)),
                 ("hit_idx", C.POINTER(C.c_uint32)), ("pkt", C.POINTER(C.c_uint8)),
-                ("r900_preamble", C.c_int32), ("r900_digits", C.POINTER(C.c_uint8))]
+                ("r900_preamble", C.c_int32), ("r900_digits", C.POINTER(C.c_uint8)),
+                ("n_hits_searched", C.c_uint64)]
+
+
+class AmrCrcCheck(C.Structure):
+    _fields_ = [("init", C.c_uint16), ("poly", C.c_uint16), ("residue", C.c_uint16), ("n_spans", C.c_uint16),
+                ("span_off", C.c_uint16 * 2), ("span_len", C.c_uint16 * 2)]
+
+
+class AmrValidator(C.Structure):
+    _fields_ = [("n_checks", C.c_int32), ("dedupe_bytes", C.c_int32), ("checks", AmrCrcCheck * 2)]
 
 
 class AmrTiming(C.Structure):
@@ -53,7 +63,7 @@ class AmrTiming(C.Structure):
 
 def build(force: bool = False) -> str:
     """Compile libamrdemod.so in-tree with hipcc for gfx950 (cross-compiles without a GPU)."""
-    srcs = [os.path.join(CSRC, f) for f in ("amrdemod.hip", "k1_demod.h", "k2_search.h", "k4_r900.h", "synth.h")]
+    srcs = [os.path.join(CSRC, f) for f in ("amrdemod.hip", "k1_demod.h", "k2_search.h", "k4_r900.h", "k5_validate.h", "synth.h")]
     srcs.append(os.path.join(_HERE, "..", "include", "amrdemod.h"))
     stale = (not os.path.exists(SO_PATH)) or any(os.path.getmtime(s) > os.path.getmtime(SO_PATH) for s in srcs)
     if force or stale:
@@ -96,6 +106,7 @@ def lib() -> C.CDLL:
     L.amr_prime_blocks.restype = C.c_size_t
     L.amr_copy_quantized.argtypes = [vp, vp, C.c_size_t]
     L.amr_r900_enable.argtypes = [vp, C.c_int32]
+    L.amr_set_validation.argtypes = [vp, C.c_int32, C.POINTER(AmrValidator)]
     L.amr_submit_host.argtypes = [vp, C.c_void_p, C.c_size_t, C.c_size_t]
     L.amr_host_alloc.argtypes = [C.c_size_t, C.POINTER(C.c_void_p)]
     L.amr_host_free.argtypes = [C.c_void_p]

@@ -21,6 +21,7 @@
 #include "k1_demod.h"
 #include "k2_search.h"
 #include "k4_r900.h"
+#include "k5_validate.h"
 #include "synth.h"
 
 namespace {
@@ -86,6 +87,9 @@ struct Slot {
     uint32_t *h_ovf = nullptr;
     uint8_t *h_out = nullptr; uint64_t host_cap = 0;
     uint8_t *d_r900 = nullptr; uint8_t *h_r900 = nullptr; uint64_t r900_host_cap = 0;   // [out_cap][42] digits (r900 enabled)
+    // validation (amr_set_validation): the surviving hits, packed like d_out, and the scratch of the compaction
+    uint8_t *d_val = nullptr; uint8_t *d_keep = nullptr; uint32_t *d_chunk = nullptr;
+    uint64_t *d_offs_val = nullptr; uint64_t *h_offv = nullptr;   // [AMR_MAX_PREAMBLES+1] each
     uint8_t *d_iq_stage = nullptr; size_t iq_stage_cap = 0;   // device copy of a host-resident batch (amr_submit_host)
     hipEvent_t ev_h2d = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr, ev_s = nullptr, ev2 = nullptr;   // K1 start/stop, K2 start, K3 stop (timing levels 1/2)
@@ -122,6 +126,7 @@ struct amr_handle {
     uint8_t *d_carry = nullptr;
     bool zero_halo = true;
     bool dense_search = false;   // test hook (AMR_DENSE_SEARCH): always use the fallback search kernel
+    uint64_t init_hit_cap = 1 << 16;   // hits the result buffers hold at first (test hook AMR_HIT_CAP: exercise the growth)
     int dense_streak = 0;        // consecutive batches whose sparse lists overflowed; >= 4: stay dense for a while
     int dense_hold = 0;          // batches left in which the dense kernel is used straight away
     uint8_t *d_iq = nullptr;      size_t iq_cap = 0;       // staging for host input
@@ -137,6 +142,10 @@ struct amr_handle {
     uint64_t last_total = 0;
     // r900 second stage: the preamble id, and the PL samples of IQ that precede the next batch (two buffers, alternating)
     int r900_pid = -1;
+    // per-hit validation on the device
+    bool validate = false;
+    amr::ValRule rules[AMR_MAX_PREAMBLES] = {};
+    uint64_t last_searched = 0;   // hits the search of the last collected batch found (before validation)
     uint8_t *d_iqhist[3] = {nullptr, nullptr, nullptr};   // three, rotating: a batch in flight keeps its own for a re-run
     int iqhist_cur = 0;
     uint32_t iqhist_valid = 0;
@@ -207,6 +216,19 @@ amr_status ensure_qt(amr_handle *h, size_t tiles)
     return AMR_OK;
 }
 
+// (Re)allocate everything sized by the hit capacity of a slot.
+amr_status alloc_hit_buffers(amr_handle *h, Slot &s)
+{
+    AMR_TRY(dev_realloc(s.d_out, s.out_cap * (12 + h->sg.pkt_bytes)));
+    if (h->r900_pid >= 0) AMR_TRY(dev_realloc(s.d_r900, s.out_cap * amr::kR900Digits));
+    if (h->validate) {
+        AMR_TRY(dev_realloc(s.d_val, s.out_cap * (12 + h->sg.pkt_bytes)));
+        AMR_TRY(dev_realloc(s.d_keep, s.out_cap));
+        AMR_TRY(dev_realloc(s.d_chunk, s.out_cap / amr::kValChunk + 2));
+    }
+    return AMR_OK;
+}
+
 amr_status ensure_capacity(amr_handle *h, Slot &s, size_t n_blocks)
 {
     const size_t bt = (n_blocks + 63) / 64;   // batch tiles
@@ -221,11 +243,8 @@ amr_status ensure_capacity(amr_handle *h, Slot &s, size_t n_blocks)
         AMR_TRY(dev_realloc(s.d_staging, st * h->sg.n_pre * s.stage_cap));
         s.staging_tiles = st;
     }
-    if (s.out_cap == 0) {
-        s.out_cap = 1 << 16;
-        AMR_TRY(dev_realloc(s.d_out, s.out_cap * (12 + h->sg.pkt_bytes)));
-        if (h->r900_pid >= 0) AMR_TRY(dev_realloc(s.d_r900, s.out_cap * amr::kR900Digits));
-    }
+    if (s.out_cap == 0) s.out_cap = h->init_hit_cap;
+    if (!s.d_out || (h->validate && !s.d_val)) AMR_TRY(alloc_hit_buffers(h, s));
     return AMR_OK;
 }
 
@@ -295,6 +314,19 @@ amr_status enqueue_search(amr_handle *h, Slot &s, bool rerun = false, bool dense
         hipLaunchKernelGGL(amr::k4_r900_digits, dim3((unsigned)((s.out_cap + 63) / 64)), dim3(64), 0, st, k4);
         HIP_TRY(hipGetLastError());
         AMR_DBG(st, "k4_r900_digits");
+    }
+    if (h->validate) {   // checksum test + repeated-packet removal, ordered compaction into d_val
+        amr::K5Args k5{};
+        k5.in = s.d_out; k5.out = s.d_val; k5.offs_pre = s.d_offs_pre; k5.offs_val = s.d_offs_val; k5.h_offs_val = s.h_offv;
+        k5.chunk = s.d_chunk; k5.keep = s.d_keep; k5.overflow = s.d_overflow; k5.cap = s.out_cap;
+        k5.n_pre = n_pre; k5.pkt_bytes = h->sg.pkt_bytes;
+        for (uint32_t q = 0; q < n_pre; ++q) k5.rule[q] = h->rules[q];
+        const unsigned nb = (unsigned)((s.out_cap + amr::kValChunk - 1) / amr::kValChunk);   // surplus groups exit at once
+        hipLaunchKernelGGL(amr::k5_flag, dim3(nb), dim3(amr::kValChunk), 0, st, k5);
+        hipLaunchKernelGGL(amr::k5_scan, dim3(1), dim3(1024), 0, st, k5);
+        hipLaunchKernelGGL(amr::k5_compact, dim3(nb), dim3(amr::kValChunk), 0, st, k5);
+        HIP_TRY(hipGetLastError());
+        AMR_DBG(st, "k5_validate");
     }
     return AMR_OK;
 }
@@ -392,7 +424,7 @@ amr_status collect(amr_handle *h, amr_result *res)
     Slot &s = h->slot[si];
     const uint32_t n_pre = h->sg.n_pre;
     AMR_TRY(wait_done(h, s));
-    uint64_t total = 0;
+    uint64_t total = 0, searched = 0;
     bool use_dense = s.dense;
     if (s.search) {
         for (int attempt = 0;; ++attempt) {
@@ -416,8 +448,7 @@ amr_status collect(amr_handle *h, amr_result *res)
                 while (nc < total) nc *= 2;
                 s.out_cap = nc;
                 HIP_TRY(hipStreamSynchronize(h->stream));
-                AMR_TRY(dev_realloc(s.d_out, s.out_cap * (12 + h->sg.pkt_bytes)));
-                if (h->r900_pid >= 0) AMR_TRY(dev_realloc(s.d_r900, s.out_cap * amr::kR900Digits));
+                AMR_TRY(alloc_hit_buffers(h, s));
                 rerun = true;
             }
             if (!rerun) break;
@@ -430,6 +461,8 @@ amr_status collect(amr_handle *h, amr_result *res)
         } else if (!use_dense) {
             h->dense_streak = 0;
         }
+        searched = total;
+        if (h->validate) total = s.h_offv[n_pre];   // what is read back is the validated list
         if (total > s.host_cap) {
             uint64_t nc = s.host_cap ? s.host_cap : (1 << 16);
             while (nc < total) nc *= 2;
@@ -437,7 +470,8 @@ amr_status collect(amr_handle *h, amr_result *res)
             s.host_cap = nc;
         }
         if (total) {   // on the copy stream: overlaps the next batch's kernels
-            HIP_TRY(hipMemcpyAsync(s.h_out, s.d_out, total * (12 + h->sg.pkt_bytes), hipMemcpyDeviceToHost, h->copy_stream));
+            HIP_TRY(hipMemcpyAsync(s.h_out, h->validate ? s.d_val : s.d_out, total * (12 + h->sg.pkt_bytes),
+                                   hipMemcpyDeviceToHost, h->copy_stream));
             if (h->r900_pid >= 0) {
                 const uint64_t nr = s.h_off[h->r900_pid + 1] - s.h_off[h->r900_pid];
                 if (nr > s.r900_host_cap) {
@@ -466,8 +500,10 @@ amr_status collect(amr_handle *h, amr_result *res)
     if (s.search) {
         h->last_slot = si;
         h->last_n_blocks = s.n_blocks;
-        h->r_off.assign(s.h_off, s.h_off + n_pre + 1);
+        const uint64_t *offs = h->validate ? s.h_offv : s.h_off;
+        h->r_off.assign(offs, offs + n_pre + 1);
         h->last_total = total;
+        h->last_searched = searched;
         if (res) {
             res->n_preambles = n_pre;
             res->pkt_bytes = h->sg.pkt_bytes;
@@ -478,6 +514,7 @@ amr_status collect(amr_handle *h, amr_result *res)
             res->pkt = s.h_out + total * 12;
             res->r900_preamble = h->r900_pid;
             res->r900_digits = h->r900_pid >= 0 ? s.h_r900 : nullptr;
+            res->n_hits_searched = searched;
         }
     }
     return AMR_OK;
@@ -521,6 +558,7 @@ amr_status amr_create(const amr_protocol *protos, int32_t n_protos, int32_t devi
     if (!h) return fail(AMR_ENOMEM, "new amr_handle");
     h->device = device_id;
     h->dense_search = getenv("AMR_DENSE_SEARCH") != nullptr;   // test hook: force the fallback search kernel
+    if (const char *hc = getenv("AMR_HIT_CAP")) h->init_hit_cap = std::max<uint64_t>(256, strtoull(hc, nullptr, 10));
 
     // RegisterProtocol, decode.go:100-128: field-wise max, preambles grouped by value
     amr_geometry &g = h->geom;
@@ -609,6 +647,8 @@ amr_status amr_create(const amr_protocol *protos, int32_t n_protos, int32_t devi
         if (e == hipSuccess) *sl.h_done = 0;
         if (e == hipSuccess) e = hipMalloc((void **)&sl.d_offs_pre, (AMR_MAX_PREAMBLES + 1) * 8);
         if (e == hipSuccess) e = hipMalloc((void **)&sl.d_overflow, 4);
+        if (e == hipSuccess) e = hipMalloc((void **)&sl.d_offs_val, (AMR_MAX_PREAMBLES + 1) * 8);
+        if (e == hipSuccess) e = hipHostMalloc((void **)&sl.h_offv, (AMR_MAX_PREAMBLES + 1) * 8, hipHostMallocDefault);
         if (e == hipSuccess) e = hipMemset(sl.d_overflow, 0, 4);
         if (e == hipSuccess) e = hipHostMalloc((void **)&sl.h_off, (AMR_MAX_PREAMBLES + 1) * 8, hipHostMallocDefault);
         if (e == hipSuccess) e = hipHostMalloc((void **)&sl.h_ovf, 4, hipHostMallocDefault);
@@ -631,11 +671,12 @@ amr_status amr_destroy(amr_handle *h)
     void *ptrs[] = {h->d_lut, h->d_carry, h->d_iq, h->d_untile, h->d_iqhist[0], h->d_iqhist[1], h->d_iqhist[2]};
     for (void *p : ptrs) if (p) (void)hipFree(p);
     for (Slot &sl : h->slot) {
-        void *dp[] = {sl.d_qt, sl.d_counts, sl.d_offsets, sl.d_offs_pre, sl.d_overflow, sl.d_staging, sl.d_out, sl.d_iq_stage, sl.d_r900};
+        void *dp[] = {sl.d_qt, sl.d_counts, sl.d_offsets, sl.d_offs_pre, sl.d_overflow, sl.d_staging, sl.d_out, sl.d_iq_stage, sl.d_r900,
+                      sl.d_val, sl.d_keep, sl.d_chunk, sl.d_offs_val};
         if (sl.h_r900) (void)hipHostFree(sl.h_r900);
         if (sl.ev_h2d) (void)hipEventDestroy(sl.ev_h2d);
         for (void *p : dp) if (p) (void)hipFree(p);
-        void *hp[] = {sl.h_off, sl.h_ovf, sl.h_out};
+        void *hp[] = {sl.h_off, sl.h_ovf, sl.h_out, sl.h_offv};
         for (void *p : hp) if (p) (void)hipHostFree(p);
         hipEvent_t evs[] = {sl.ev0, sl.ev1, sl.ev_s, sl.ev2};
         if (sl.h_done) (void)hipHostFree(sl.h_done);
@@ -689,6 +730,7 @@ amr_status amr_r900_enable(amr_handle *h, int32_t proto_index)
     if (h->calls_done != 0 || h->n_pending != 0) return fail(AMR_EINVAL, "amr_r900_enable: call before the first batch");
     HIP_TRY(hipSetDevice(h->device));
     h->r900_pid = h->proto_pid[(size_t)proto_index];
+    h->rules[h->r900_pid] = amr::ValRule{};   // its hits carry digits by position: never filtered
     const size_t bytes = 2 * (size_t)h->geom.packet_length;
     for (uint8_t *&p : h->d_iqhist) {
         if (!p) AMR_TRY(dev_realloc(p, bytes));
@@ -697,6 +739,37 @@ amr_status amr_r900_enable(amr_handle *h, int32_t proto_index)
     for (Slot &sl : h->slot)
         if (sl.out_cap && !sl.d_r900) AMR_TRY(dev_realloc(sl.d_r900, sl.out_cap * amr::kR900Digits));
     h->iqhist_valid = 0;
+    return AMR_OK;
+}
+
+amr_status amr_set_validation(amr_handle *h, int32_t preamble_id, const amr_validator *v)
+{
+    if (!h || preamble_id < 0 || (uint32_t)preamble_id >= h->sg.n_pre) return fail(AMR_EINVAL, "bad preamble id");
+    if (h->n_pending != 0) return fail(AMR_EINVAL, "amr_set_validation: batches in flight");
+    amr::ValRule r{};
+    if (v) {
+        if (preamble_id == h->r900_pid)
+            return fail(AMR_EINVAL, "amr_set_validation: the r900 preamble's hits carry digits and are always kept");
+        if (v->n_checks < 0 || v->n_checks > 2 || v->dedupe_bytes < 0 || (uint32_t)v->dedupe_bytes > h->sg.pkt_bytes)
+            return fail(AMR_EINVAL, "amr_set_validation: n_checks must be 0..2, dedupe_bytes 0..pkt_bytes");
+        r.n_checks = v->n_checks;
+        r.dedupe_bytes = v->dedupe_bytes;
+        for (int c = 0; c < v->n_checks; ++c) {
+            const amr_crc_check &k = v->checks[c];
+            if (k.n_spans < 1 || k.n_spans > 2) return fail(AMR_EINVAL, "amr_set_validation: 1 or 2 spans per check");
+            r.chk[c].init = k.init; r.chk[c].poly = k.poly; r.chk[c].residue = k.residue; r.chk[c].n_spans = k.n_spans;
+            for (int sp = 0; sp < k.n_spans; ++sp) {
+                if ((uint32_t)k.span_off[sp] + k.span_len[sp] > h->sg.pkt_bytes)
+                    return fail(AMR_EINVAL, "amr_set_validation: span outside the packet");
+                r.chk[c].off[sp] = k.span_off[sp];
+                r.chk[c].len[sp] = k.span_len[sp];
+            }
+        }
+    }
+    h->rules[preamble_id] = r;
+    bool any = false;
+    for (uint32_t q = 0; q < h->sg.n_pre; ++q) any = any || h->rules[q].n_checks > 0 || h->rules[q].dedupe_bytes > 0;
+    h->validate = any;
     return AMR_OK;
 }
 
@@ -783,7 +856,7 @@ amr_status amr_result_device(const amr_handle *h, const void **d_packed, uint64_
 {
     if (!h || !d_packed || !n_hits) return fail(AMR_EINVAL, "null argument");
     if (h->last_slot < 0) return fail(AMR_EINVAL, "no batch collected yet");
-    *d_packed = h->slot[h->last_slot].d_out;
+    *d_packed = h->validate ? h->slot[h->last_slot].d_val : h->slot[h->last_slot].d_out;
     *n_hits = h->last_total;
     return AMR_OK;
 }

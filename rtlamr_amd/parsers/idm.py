@@ -51,6 +51,9 @@ class IDM(Message):
 class IdmParser(Parser):
     """idm.Parser (idm/idm.go:34-98): packet CRC over bytes 4..91 and serial-number CRC."""
     NAME, MSG = "idm", "IDM"
+    # what Parse tests before anything else, for Decoder.EnableValidation (idm.go:68-87; netidm.go:79-98 is the same)
+    VALIDATOR = {"dedupe_bytes": 92, "checks": [(0xFFFF, 0x1021, 0x1D0F, [(4, 88)]),
+                                                (0xFFFF, 0x1021, 0x1D0F, [(9, 4), (88, 2)])]}
 
     def __init__(self, chip_length: int):
         self.crc = CRC("CCITT", 0xFFFF, 0x1021, 0x1D0F)
@@ -77,9 +80,45 @@ class IdmParser(Parser):
         return out
 
 
+@dataclass
+class NetIDM(Message):
+    """netidm.NetIDM (netidm/netidm.go:114-131), fields of NewNetIDM (netidm/netidm.go:133-161)."""
+    Preamble: int = 0
+    ProtocolID: int = 0
+    PacketLength: int = 0
+    HammingCode: int = 0
+    ApplicationVersion: int = 0
+    ERTType: int = 0
+    ERTSerialNumber: int = 0
+    ConsumptionIntervalCount: int = 0
+    ProgrammingState: int = 0
+    LastGeneration: int = 0
+    LastConsumption: int = 0
+    LastConsumptionNet: int = 0
+    DifferentialConsumptionIntervals: List[int] = field(default_factory=list)
+    TransmitTimeOffset: int = 0
+    SerialNumberCRC: int = 0
+    PacketCRC: int = 0
+
+    @staticmethod
+    def from_data(d: Data) -> "NetIDM":
+        B, bits = d.Bytes, d.Bits
+        be = lambda b: int.from_bytes(b, "big")
+        iv = [int(bits[304 + 14 * i: 318 + 14 * i], 2) for i in range(27)]     # netidm.go:149-155
+        return NetIDM(be(B[0:4]), B[4], B[5], B[6], B[7], B[8] & 0x0F, be(B[9:13]), B[13], B[14],
+                      be(B[28:31]), be(B[25:28]), be(B[34:38]), iv, be(B[86:88]), be(B[88:90]), be(B[90:92]))
+
+    def MsgType(self): return "NetIDM"
+    def MeterID(self): return self.ERTSerialNumber
+    def MeterType(self): return self.ERTType
+    def Checksum(self): return self.PacketCRC.to_bytes(2, "big")
+    def Record(self): return [hex(self.Preamble), str(self.ERTType), str(self.ERTSerialNumber),
+                              str(self.LastConsumptionNet), hex(self.PacketCRC)]
+
+
 class NetIdmParser(IdmParser):
-    """netidm.Parser (netidm/netidm.go:57-111): same preamble/length/CRC as IDM (one shared Search);
-    only the packet CRC is checked there (netidm.go:88)."""
+    """netidm.Parser (netidm/netidm.go:57-111): same preamble, length and both CRC checks as IDM (one shared
+    Search, decode.go:124); only the message layout differs."""
     NAME, MSG = "netidm", "NetIDM"
 
     def Parse(self, pkts: List[Data]) -> List[Message]:
@@ -89,9 +128,11 @@ class NetIdmParser(IdmParser):
             if data.Bytes in seen:
                 continue
             seen.add(data.Bytes)
-            if self.crc.Checksum(data.Bytes[4:92]) != self.crc.Residue:
+            if self.crc.Checksum(data.Bytes[4:92]) != self.crc.Residue:      # netidm.go:88
                 continue
-            m = IDM.from_data(data)
+            if self.crc.Checksum(data.Bytes[9:13] + data.Bytes[88:90]) != self.crc.Residue:   # netidm.go:93-98
+                continue
+            m = NetIDM.from_data(data)
             if m.ERTSerialNumber == 0:
                 continue
             out.append(m)
@@ -119,6 +160,7 @@ class SCMPlus(Message):
 
 class ScmPlusParser(Parser):
     """scmplus.Parser (scmplus/scmplus.go:40-92): CCITT over bytes 2..15."""
+    VALIDATOR = {"dedupe_bytes": 16, "checks": [(0xFFFF, 0x1021, 0x1D0F, [(2, 14)])]}   # scmplus.go:68-79
 
     def __init__(self, chip_length: int):
         self.crc = CRC("CCITT", 0xFFFF, 0x1021, 0x1D0F)
@@ -138,7 +180,7 @@ class ScmPlusParser(Parser):
                 continue
             be = lambda b: int.from_bytes(b, "big")
             m = SCMPlus(be(B[0:2]), B[2], B[3], be(B[4:8]), be(B[8:12]), be(B[12:14]), be(B[14:16]))
-            if m.EndpointID == 0:
+            if m.EndpointID == 0 or m.ProtocolID != 0x1E:   # scmplus.go:84
                 continue
             out.append(m)
         return out

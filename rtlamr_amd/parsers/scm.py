@@ -41,6 +41,7 @@ class SCM(Message):
 
 class ScmParser(Parser):
     """scm.Parser (scm/scm.go:33-91)."""
+    VALIDATOR = {"dedupe_bytes": 12, "checks": [(0x0000, 0x6F63, 0x0000, [(2, 10)])]}   # scm.go:68-79
 
     def __init__(self, chip_length: int):
         self.crc = CRC("BCH", 0, 0x6F63, 0)

@@ -124,6 +124,7 @@ class BatchResult:
     pkt: np.ndarray              # uint8 [n, pkt_bytes]
     r900_preamble: int = -1      # preamble id whose hits carry digits, -1 = none
     r900_digits: Optional[np.ndarray] = None   # uint8 [hits of that preamble, 42]
+    n_hits_searched: int = 0     # hits the search found (more than len(hit_idx) only with EnableValidation)
 
     def for_preamble(self, pid: int):
         lo, hi = int(self.preamble_offset[pid]), int(self.preamble_offset[pid + 1])
@@ -194,6 +195,28 @@ class Decoder:
             if getattr(p, "NEEDS_R900_DIGITS", False):   # r900-type parser: its second matched filter runs on the GPU
                 _lib.check(L.amr_r900_enable(h, i), "amr_r900_enable")
 
+    def EnableValidation(self) -> List[str]:
+        """Binding-level option (no Go counterpart): run the checksum test and the repeated-packet
+        removal every Parse starts with (scm/scm.go:68-79, idm/idm.go:68-87, ...) on the GPU, so that only hits a
+        parser can turn into a message are read back.  A preamble is validated when all its parsers declare the same
+        VALIDATOR; the parsers still run unchanged and emit the same messages.  Returns the validated preambles."""
+        h, L = self._require(), _lib.lib()
+        done = []
+        for pre, parsers in self._preambles.items():
+            rules = [getattr(p, "VALIDATOR", None) for p in parsers]
+            if rules[0] is None or any(r != rules[0] for r in rules):
+                continue
+            v = _lib.AmrValidator()
+            v.n_checks = len(rules[0]["checks"])
+            v.dedupe_bytes = rules[0]["dedupe_bytes"]
+            for c, (init, poly, residue, spans) in enumerate(rules[0]["checks"]):
+                v.checks[c].init, v.checks[c].poly, v.checks[c].residue, v.checks[c].n_spans = init, poly, residue, len(spans)
+                for k, (off, ln) in enumerate(spans):
+                    v.checks[c].span_off[k], v.checks[c].span_len[k] = off, ln
+            _lib.check(L.amr_set_validation(h, self._pid_of_preamble[pre], C.byref(v)), "amr_set_validation")
+            done.append(pre)
+        return done
+
     def close(self) -> None:
         if self._handle is not None:
             _lib.lib().amr_destroy(self._handle)
@@ -249,7 +272,7 @@ class Decoder:
             dg = np.ctypeslib.as_array(res.r900_digits, shape=(nr, 42)) if nr else np.zeros((0, 42), np.uint8)
             if copy and nr:
                 dg = dg.copy()
-        return BatchResult(n_blocks, first_block, off, blk, idx, pkt, rp, dg)
+        return BatchResult(n_blocks, first_block, off, blk, idx, pkt, rp, dg, int(res.n_hits_searched))
 
     def decode_batch(self, iq) -> BatchResult:
         """n = len(iq)//BlockSize2 consecutive Decode calls (decode.go:163-172 + Search/Slice), no parsers."""

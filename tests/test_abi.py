@@ -25,11 +25,26 @@ def test_header_symbols_all_exported(amr_lib):
     assert sorted(_lib.SYMBOLS) == declared, "rtlamr_amd/_lib.py SYMBOLS out of sync with the header"
 
 
-def test_struct_layouts_match_header():
-    assert C.sizeof(_lib.AmrGeometry) == 13 * 4
-    assert C.sizeof(_lib.AmrProtocol) == 8 + 4 * 4
-    assert C.sizeof(_lib.AmrTiming) == 12
-    assert C.sizeof(_lib.AmrResult) == 4 + 4 + 8 + 4 * 8 + 8 + 8   # + r900_preamble (padded) + r900_digits
+def test_struct_layouts_match_header(tmp_path):
+    """sizeof / offsetof as a C compiler sees include/amrdemod.h == the ctypes mirrors in rtlamr_amd/_lib.py."""
+    import subprocess
+    structs = {"amr_geometry": _lib.AmrGeometry, "amr_protocol": _lib.AmrProtocol, "amr_timing": _lib.AmrTiming,
+               "amr_result": _lib.AmrResult, "amr_crc_check": _lib.AmrCrcCheck, "amr_validator": _lib.AmrValidator}
+    lines = ['#include <stdio.h>', '#include <stddef.h>', '#include "amrdemod.h"', 'int main(void){']
+    for cname, ct in structs.items():
+        lines.append(f'printf("{cname} %zu\\n", sizeof({cname}));')
+        for fname, _ in ct._fields_:
+            lines.append(f'printf("{cname}.{fname} %zu\\n", offsetof({cname}, {fname}));')
+    lines.append('return 0;}')
+    src = tmp_path / "layout.c"
+    src.write_text("\n".join(lines))
+    exe = tmp_path / "layout"
+    subprocess.check_call(["gcc", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)])
+    seen = dict(l.split() for l in subprocess.check_output([str(exe)], text=True).splitlines())
+    for cname, ct in structs.items():
+        assert int(seen[cname]) == C.sizeof(ct), cname
+        for fname, _ in ct._fields_:
+            assert int(seen[f"{cname}.{fname}"]) == getattr(ct, fname).offset, f"{cname}.{fname}"
 
 
 def test_strerror_and_argument_checks(amr_lib):
