@@ -87,6 +87,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--blocks", type=int, default=GIB_BLOCKS, help="blocks per GPU per step (default 1 GiB)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--validate", action="store_true",
+                    help="also run the parsers' checksum tests + repeat removal on the GPU (K5); only surviving hits are read back")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -110,6 +112,8 @@ def main():
     for p in PROTOS:
         dec.RegisterProtocol(ra.new_parser(p, CHIP))
     dec.Allocate()
+    if args.validate:
+        dec.EnableValidation()
     bs, bs2 = dec.Cfg.BlockSize, dec.Cfg.BlockSize2
     n_blocks = args.blocks
     n_samples = n_blocks * bs
@@ -183,6 +187,7 @@ def main():
     demod_ms = [t["demod_ms"] for _, t in res]
     search_ms = [t["search_ms"] for _, t in warm] or [float("nan")]
     n_hits = len(res[-1][0].hit_idx)
+    n_searched = res[-1][0].n_hits_searched
     if distributed:
         tt = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -209,7 +214,8 @@ def main():
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"scm_chip72_{n_blocks}_blocks_per_gpu", "protocols": PROTOS, "chip_length": CHIP,
                        "block_size": bs, "bytes_per_gpu_per_step": nbytes, "planted_packets_per_gpu": N_PACKETS,
-                       "hits_per_step_rank0": n_hits, "parallelism": f"block-range shards x{world}",
+                       "hits_per_step_rank0": n_hits, "hits_searched_per_step_rank0": n_searched,
+                       "gpu_validation": bool(args.validate), "parallelism": f"block-range shards x{world}",
                        "hit_gather": ("RCCL gather of (block, idx) records to rank 0, one async collective per step"
                                       if distributed else "none (single GPU)"),
                        "hit_gather_truncated": state["gather_truncated"]},

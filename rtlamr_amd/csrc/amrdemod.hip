@@ -323,7 +323,6 @@ amr_status enqueue_search(amr_handle *h, Slot &s, bool rerun = false, bool dense
         for (uint32_t q = 0; q < n_pre; ++q) k5.rule[q] = h->rules[q];
         const unsigned nb = (unsigned)((s.out_cap + amr::kValChunk - 1) / amr::kValChunk);   // surplus groups exit at once
         hipLaunchKernelGGL(amr::k5_flag, dim3(nb), dim3(amr::kValChunk), 0, st, k5);
-        hipLaunchKernelGGL(amr::k5_scan, dim3(1), dim3(1024), 0, st, k5);
         hipLaunchKernelGGL(amr::k5_compact, dim3(nb), dim3(amr::kValChunk), 0, st, k5);
         HIP_TRY(hipGetLastError());
         AMR_DBG(st, "k5_validate");

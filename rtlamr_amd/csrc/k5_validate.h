@@ -12,8 +12,8 @@
 // right before it in the same (preamble, block) list -- a subset of what `seen` drops, so the parser's own `seen`
 // finishes the job and the message stream is unchanged.  The order of the surviving hits is kept.
 //
-// Three small kernels (the hit count is known on the device only): flag + per-chunk counts, scan of the chunk
-// counts, ordered compaction into a second packed buffer of the same layout as K3's.
+// Two small kernels (the hit count is known on the device only): flag + per-chunk counts, then an ordered
+// compaction into a second packed buffer of the same layout as K3's.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -40,7 +40,7 @@ struct K5Args {
     const uint64_t *offs_pre;   // [n_pre+1] from k2s_scan
     uint64_t *offs_val;         // [n_pre+1] offsets into the validated list (device)
     uint64_t *h_offs_val;       // the same in pinned host memory
-    uint32_t *chunk;            // [cap/kValChunk + 2]: survivors per chunk, then their exclusive scan
+    uint32_t *chunk;            // [cap/kValChunk + 2]: survivors per chunk
     uint8_t *keep;              // [cap]
     const uint32_t *overflow;   // K2's overflow word: the host searches again, nothing here is used
     uint64_t cap;               // hits the buffers hold
@@ -112,63 +112,51 @@ __global__ __launch_bounds__(kValChunk) void k5_flag(const K5Args a)
     }
 }
 
-// exclusive scan of the chunk counts (one workgroup), the total behind the last chunk
-__global__ __launch_bounds__(1024) void k5_scan(const K5Args a)
-{
-    __shared__ uint32_t part[1024];
-    const uint32_t tid = threadIdx.x;
-    uint64_t total;
-    if (!k5_usable(a, total)) {
-        if (tid <= a.n_pre) { a.offs_val[tid] = 0; a.h_offs_val[tid] = 0; }
-        return;
-    }
-    const uint32_t n = (uint32_t)((total + kValChunk - 1) / kValChunk);
-    const uint32_t per = (n + 1023) / 1024;
-    const uint32_t lo = tid * per < n ? tid * per : n, hi = lo + per < n ? lo + per : n;
-    uint32_t s = 0;
-    for (uint32_t i = lo; i < hi; ++i) s += a.chunk[i];
-    part[tid] = s;
-    __syncthreads();
-    for (uint32_t d = 1; d < 1024; d <<= 1) {
-        const uint32_t t = tid >= d ? part[tid - d] : 0;
-        __syncthreads();
-        part[tid] += t;
-        __syncthreads();
-    }
-    uint32_t run = tid ? part[tid - 1] : 0;
-    for (uint32_t i = lo; i < hi; ++i) {
-        const uint32_t c = a.chunk[i];
-        a.chunk[i] = run;
-        run += c;
-    }
-    const uint32_t kept = part[1023];
-    if (tid == 0) a.chunk[n] = kept;
-    // preambles whose first hit does not exist (empty tail ranges) start at the end of the validated list;
-    // the others get their offset from the lane of k5_compact that holds their first hit
-    if (tid <= a.n_pre && a.offs_pre[tid] >= total) { a.offs_val[tid] = kept; a.h_offs_val[tid] = kept; }
-}
-
+// Ordered compaction.  Every workgroup adds up the chunk counts itself (those before it = its base, all of them =
+// the size of the validated list, which fixes the packed layout): a few loads per lane, cheaper than a scan kernel
+// of its own between the two passes (each dispatch costs ~4.5 us on the stream).
 __global__ __launch_bounds__(kValChunk) void k5_compact(const K5Args a)
 {
-    __shared__ uint32_t wbase[kValChunk / 64];
+    __shared__ uint32_t wcnt[kValChunk / 64], wred[2][kValChunk / 64];
     uint64_t total;
-    if (!k5_usable(a, total)) return;
+    const bool usable = k5_usable(a, total);
+    if (!usable || total == 0) {
+        if (blockIdx.x == 0 && threadIdx.x <= a.n_pre) { a.offs_val[threadIdx.x] = 0; a.h_offs_val[threadIdx.x] = 0; }
+        return;
+    }
     const uint64_t g0 = (uint64_t)blockIdx.x * kValChunk;
     if (g0 >= total) return;
     const uint32_t n = (uint32_t)((total + kValChunk - 1) / kValChunk);
-    const uint64_t kept = a.chunk[n];
+    const uint32_t lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    uint32_t before = 0, all = 0;
+    for (uint32_t i = threadIdx.x; i < n; i += kValChunk) {
+        const uint32_t c = a.chunk[i];
+        all += c;
+        before += i < blockIdx.x ? c : 0u;
+    }
+    for (int d = 32; d; d >>= 1) { before += __shfl_down(before, d); all += __shfl_down(all, d); }
     const uint64_t g = g0 + threadIdx.x;
     const bool keep = g < total && a.keep[g] != 0;
     const uint64_t m = __ballot(keep);
-    const uint32_t lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    if (lane == 0) wbase[w] = (uint32_t)__popcll(m);
+    if (lane == 0) { wred[0][w] = before; wred[1][w] = all; wcnt[w] = (uint32_t)__popcll(m); }
     __syncthreads();
-    uint32_t before = 0;
-    for (uint32_t i = 0; i < w; ++i) before += wbase[i];
-    const uint64_t rank = (uint64_t)a.chunk[blockIdx.x] + before + (uint32_t)__popcll(m & ((1ull << lane) - 1));
+    uint64_t base = 0, kept = 0;
+    uint32_t inblock = 0;
+    for (uint32_t i = 0; i < kValChunk / 64; ++i) {
+        base += wred[0][i];
+        kept += wred[1][i];
+        inblock += i < w ? wcnt[i] : 0u;
+    }
+    const uint64_t rank = base + inblock + (uint32_t)__popcll(m & ((1ull << lane) - 1));
+    // new preamble offsets: the lane that holds a preamble's first hit knows how many hits survive before it;
+    // preambles whose range starts at the end of the list (empty tail ranges, and the end marker) get the total
     if (g < total)
         for (uint32_t q = 0; q < a.n_pre; ++q)
             if (a.offs_pre[q] == g) { a.offs_val[q] = rank; a.h_offs_val[q] = rank; }
+    if (blockIdx.x == 0 && threadIdx.x <= a.n_pre && a.offs_pre[threadIdx.x] >= total) {
+        a.offs_val[threadIdx.x] = kept;
+        a.h_offs_val[threadIdx.x] = kept;
+    }
     if (!keep) return;
     const uint64_t *ib = reinterpret_cast<const uint64_t *>(a.in);
     const uint32_t *ii = reinterpret_cast<const uint32_t *>(a.in + total * 8);

@@ -86,12 +86,16 @@ def main(argv=None) -> int:
     ap.add_argument("--batch-blocks", type=int, default=16384)
     ap.add_argument("--device", type=int, default=0)
     ap.add_argument("--no-unique", action="store_true")
+    ap.add_argument("--no-validate", action="store_true",
+                    help="read every preamble hit back instead of only those that pass the parsers' checksum tests on the GPU")
     a = ap.parse_args(argv)
     names = ["scm", "scm+", "idm", "r900"] if a.msgtype == "all" else a.msgtype.split(",")   # main.go:67-73
     dec = ra.new_decoder(a.device)
     for n in names:
         dec.RegisterProtocol(ra.new_parser(n, a.symbollength))
     dec.Allocate()
+    if not a.no_validate:
+        dec.EnableValidation()
     dec.Log(out=lambda s: print(s, file=sys.stderr))
     f = sys.stdin.buffer if a.file == "-" else open(a.file, "rb")
     t0, n = time.perf_counter(), 0
