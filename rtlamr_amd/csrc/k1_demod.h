@@ -47,6 +47,12 @@
 #define AMR_K1_DIAG 0
 #endif
 // 1: LUT gathers one group ahead of their use (32 more VGPRs), 0: gathers, row read and one wait per group
+// LDS waits of a group: 0 = hipcc's own (one s_waitcnt per LUT pair as the values are used), 1 = one wait for all 16
+// gathers before the arithmetic, 2 = two waits (first half, second half).  Measured on MI355X (chip 72, 1 GiB):
+// 0.2226 / 0.2244 / 0.2223 ms -- seven fewer s_waitcnt per group buy nothing, a satisfied s_waitcnt is almost free.
+#ifndef AMR_K1_WAIT
+#define AMR_K1_WAIT 0
+#endif
 #ifndef AMR_K1_PIPE
 #define AMR_K1_PIPE 0   // measured on MI355X (SCM chip 72, 1 GiB): 0.231 ms without, 0.239 ms with (and 40 fewer free VGPRs)
 #endif
@@ -301,9 +307,19 @@ __device__ __forceinline__ void k1_body(K1Lane<CL> &L, K1Uni &U, const K1Args &a
         }
         const uint4 row2 = k1_fetch_next<CL, TAIL>(U, a, tiles_lds, tiles, wg, lane, rdv, voff_e, voff_o, rows_valid);
         __builtin_amdgcn_sched_barrier(0);
+#if AMR_K1_WAIT == 1
+        __builtin_amdgcn_s_waitcnt(0xC17F);   // lgkmcnt(1): LDS returns in order, only the row read may be outstanding
+        __builtin_amdgcn_sched_barrier(0);
+#elif AMR_K1_WAIT == 2
+        __builtin_amdgcn_s_waitcnt(0xC97F);   // lgkmcnt(9): the first 8 gathers are back
+        __builtin_amdgcn_sched_barrier(0);
+#endif
 #endif
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
+#if AMR_K1_WAIT == 2
+            if (k == 4) { __builtin_amdgcn_s_waitcnt(0xC17F); __builtin_amdgcn_sched_barrier(0); }
+#endif
             constexpr int R = G::RING;
             const int r = g * 8 + k, rp = (r + R - 1) % R, ro = (r + 8) % R;
             float m = L.li[k] + L.lq[k];                       // decode.go:222
