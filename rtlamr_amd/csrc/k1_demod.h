@@ -53,6 +53,13 @@
 #ifndef AMR_K1_WAIT
 #define AMR_K1_WAIT 0
 #endif
+// 1: magnitude add and the two differences as v_pk_add_f32 (12 packed + 8 plain adds per group instead of 32 plain:
+// 11 fewer instructions of 90).  Measured on MI355X, A/B on one box: 0.2296 / 0.2174 ms against 0.2276 / 0.2144 ms for
+// the plain build -- no gain: a packed op takes two passes through the FP32 lanes, and those, not the issue slots, are
+// what the arithmetic costs.  Bit-exact either way (tests/test_gpu_parity.py, test_gpu_fullsize.py pass with it).
+#ifndef AMR_K1_PK
+#define AMR_K1_PK 0
+#endif
 #ifndef AMR_K1_PIPE
 #define AMR_K1_PIPE 0   // measured on MI355X (SCM chip 72, 1 GiB): 0.231 ms without, 0.239 ms with (and 40 fewer free VGPRs)
 #endif
@@ -315,6 +322,73 @@ __device__ __forceinline__ void k1_body(K1Lane<CL> &L, K1Uni &U, const K1Args &a
         __builtin_amdgcn_sched_barrier(0);
 #endif
 #endif
+#if AMR_K1_PK
+        // Packed form: a wave is limited by its own issue rate (one instruction per ~5 cycles whatever it is), and
+        // v_pk_add_f32 does two independent IEEE binary32 adds in one issue slot: the magnitude add and the two
+        // differences of samples (2j, 2j+1) pair up (ring slots r, r+1 and ro, ro+1 are adjacent registers, RING
+        // is even); the running sum itself stays a serial chain of plain v_add_f32 (in asm: left to itself hipcc
+        // packs those too, with a wasted half and two v_mov per pair).  Same operations, same roundings.
+        // gfx950 needs a wait state between a packed op and a dependent instruction right behind it, so the 28
+        // instructions are laid out by hand with independent work in between, and pinned with sched_barrier.
+        {
+            typedef float v2f __attribute__((ext_vector_type(2)));
+            constexpr int R = G::RING;
+#define AMR_SB __builtin_amdgcn_sched_barrier(0)
+#define AMR_ADD(dst, x, y) asm("v_add_f32 %0, %1, %2" : "=v"(dst) : "v"(x), "v"(y))
+#define AMR_RO(j) ((g * 8 + 2 * (j) + 8) % R)
+#define AMR_HC(j) v2f{L.hc[AMR_RO(j)], L.hc[AMR_RO(j) + 1]}
+#define AMR_HD(j) v2f{L.hd[AMR_RO(j)], L.hd[AMR_RO(j) + 1]}
+#define AMR_BIT(x) L.acc = __builtin_amdgcn_alignbit(L.acc, __float_as_uint(x), 31)   /* decode.go:243, inverted */
+            // issue order: m0 m1 c0x m2 c0y m3 c1x d0 c1y f0 c2x d1 c2y b c3x f1 c3y b d2 b d3 f2 b f3 b b b b
+#define AMR_MAG(j) v2f m##j = v2f{L.li[2 * j], L.li[2 * j + 1]} + v2f{L.lq[2 * j], L.lq[2 * j + 1]};   /* decode.go:222 */ \
+            if (PRO) {                                                                    /* zero history, decode.go:144 */ \
+                m##j.x = U.G * 8 + 2 * j < zlim ? 0.0f : m##j.x;                                                          \
+                m##j.y = U.G * 8 + 2 * j + 1 < zlim ? 0.0f : m##j.y;                                                      \
+            }                                                                                                            \
+            AMR_SB
+            float c0x, c0y, c1x, c1y, c2x, c2y, c3x, c3y;
+            AMR_MAG(0);
+            AMR_MAG(1);
+            AMR_ADD(c0x, L.hc[(g * 8 + R - 1) % R], m0.x); AMR_SB;                        // decode.go:234
+            AMR_MAG(2);
+            AMR_ADD(c0y, c0x, m0.y); AMR_SB;
+            AMR_MAG(3);
+            AMR_ADD(c1x, c0y, m1.x); AMR_SB;
+            const v2f d0 = v2f{c0x, c0y} - AMR_HC(0); AMR_SB;                             // decode.go:242
+            AMR_ADD(c1y, c1x, m1.y); AMR_SB;
+            const v2f f0 = AMR_HD(0) - d0; AMR_SB;
+            AMR_ADD(c2x, c1y, m2.x); AMR_SB;
+            const v2f d1 = v2f{c1x, c1y} - AMR_HC(1); AMR_SB;
+            AMR_ADD(c2y, c2x, m2.y); AMR_SB;
+            AMR_BIT(f0.x); AMR_SB;
+            AMR_ADD(c3x, c2y, m3.x); AMR_SB;
+            const v2f f1 = AMR_HD(1) - d1; AMR_SB;
+            AMR_ADD(c3y, c3x, m3.y); AMR_SB;
+            AMR_BIT(f0.y); AMR_SB;
+            const v2f d2 = v2f{c2x, c2y} - AMR_HC(2); AMR_SB;
+            AMR_BIT(f1.x); AMR_SB;
+            const v2f d3 = v2f{c3x, c3y} - AMR_HC(3); AMR_SB;
+            const v2f f2 = AMR_HD(2) - d2; AMR_SB;
+            AMR_BIT(f1.y); AMR_SB;
+            const v2f f3 = AMR_HD(3) - d3; AMR_SB;
+            AMR_BIT(f2.x); AMR_SB;
+            AMR_BIT(f2.y); AMR_SB;
+            AMR_BIT(f3.x); AMR_SB;
+            AMR_BIT(f3.y); AMR_SB;
+            const int r0 = g * 8;
+            L.hc[r0 + 0] = c0x; L.hc[r0 + 1] = c0y; L.hc[r0 + 2] = c1x; L.hc[r0 + 3] = c1y;
+            L.hc[r0 + 4] = c2x; L.hc[r0 + 5] = c2y; L.hc[r0 + 6] = c3x; L.hc[r0 + 7] = c3y;
+            L.hd[r0 + 0] = d0.x; L.hd[r0 + 1] = d0.y; L.hd[r0 + 2] = d1.x; L.hd[r0 + 3] = d1.y;
+            L.hd[r0 + 4] = d2.x; L.hd[r0 + 5] = d2.y; L.hd[r0 + 6] = d3.x; L.hd[r0 + 7] = d3.y;
+#undef AMR_MAG
+#undef AMR_SB
+#undef AMR_ADD
+#undef AMR_RO
+#undef AMR_HC
+#undef AMR_HD
+#undef AMR_BIT
+        }
+#else
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
 #if AMR_K1_WAIT == 2
@@ -331,6 +405,7 @@ __device__ __forceinline__ void k1_body(K1Lane<CL> &L, K1Uni &U, const K1Args &a
             L.hc[r] = c;
             L.hd[r] = d;
         }
+#endif
         __builtin_amdgcn_sched_barrier(0);
 #if AMR_K1_PIPE
 #pragma unroll
