@@ -238,10 +238,19 @@ def main():
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(dec, d_iq.value, bs2)
-        print(json.dumps(out), flush=True)
+    else:
+        out = None
     if distributed:
         dist.barrier()
         dist.destroy_process_group()
+    if out is not None:
+        # RCCL writes its version banner to the C stdout buffer; push that out first so that the JSON line is the
+        # last line this job prints
+        try:
+            C.CDLL(None).fflush(None)
+        except Exception:
+            pass
+        print(json.dumps(out), flush=True)
 
 
 if __name__ == "__main__":
