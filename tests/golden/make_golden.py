@@ -1,6 +1,6 @@
 #!/usr/bin/env python
-"""Regenerates tests/golden/*.json.  Run in the BUILD container (needs /root/reference for the
-sample.bin vectors; the synthetic vectors need nothing).  The JSON files are committed; tests on the
+"""Regenerates tests/golden/*.json and capture_iq.xz.  Run in the BUILD container (needs /root/reference for the
+sample.bin vectors and the capture fixture; the synthetic vectors need nothing).  The JSON files are committed; tests on the
 GPU box compare the HIP path against them without touching /root/reference.
 
     python tests/golden/make_golden.py
@@ -67,8 +67,18 @@ def synth_vectors():
     return {"cases": cases}
 
 
+def capture_fixture():
+    """The reference's only real-signal input, assets/sample.bin (raw uint8 IQ -- data, not code), xz-compressed, so
+    that the -m gpu tests can run BASELINE config 1 on the GPU box, where /root/reference does not exist."""
+    import lzma
+    raw = open(SAMPLE, "rb").read()
+    with open(os.path.join(HERE, "capture_iq.xz"), "wb") as f:
+        f.write(lzma.compress(raw, preset=9 | lzma.PRESET_EXTREME))
+
+
 if __name__ == "__main__":
     if os.path.exists(SAMPLE):
         json.dump(sample_bin_vectors(), open(os.path.join(HERE, "sample_bin.json"), "w"), indent=1)
+        capture_fixture()
     json.dump(synth_vectors(), open(os.path.join(HERE, "synth.json"), "w"), indent=1)
     print("golden vectors written")

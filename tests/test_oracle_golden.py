@@ -15,7 +15,7 @@ from tests import util
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 SAMPLE = "/root/reference/assets/sample.bin"
-need_sample = pytest.mark.skipif(not os.path.exists(SAMPLE), reason="reference capture only exists in the build container")
+need_reference = pytest.mark.skipif(not os.path.exists(SAMPLE), reason="the reference tree only exists in the build container")
 
 
 def sha(a):
@@ -59,10 +59,15 @@ def test_geometry_table(chip, protos, exp):
     assert next_power_of_2(exp["PreL"]) == exp["BS"]
 
 
-@need_sample
+@need_reference
+def test_capture_fixture_is_the_reference_capture():
+    """tests/golden/capture_iq.xz (made by make_golden.py) decompresses to assets/sample.bin byte for byte."""
+    assert np.array_equal(util.load_capture(), np.fromfile(SAMPLE, dtype=np.uint8))
+
+
 @pytest.mark.parametrize("protos,chip,nbytes,calls,ones,qsha,nhits", SURVEY_CASES)
 def test_sample_bin_survey_vectors(protos, chip, nbytes, calls, ones, qsha, nhits):
-    raw = np.fromfile(SAMPLE, dtype=np.uint8)
+    raw = util.load_capture()
     assert sha(raw) == SURVEY_SAMPLE_SHA
     d = OracleDecoder(protos, chip)
     nb = (nbytes or raw.size) // d.geom.block_size2
@@ -77,10 +82,9 @@ def test_sample_bin_survey_vectors(protos, chip, nbytes, calls, ones, qsha, nhit
     assert np.array_equal(np.packbits(npo.quantize_stream(raw[: nb * d.geom.block_size2], chip, d.geom.block_size)), q)
 
 
-@need_sample
 def test_sample_bin_true_chip_length_decodes_crc_valid_packets():
     """SURVEY 8c self-check: chip 78 semantic search -> 853 hits, 14 distinct CRC-valid SCM packets."""
-    raw = np.fromfile(SAMPLE, dtype=np.uint8)
+    raw = util.load_capture()
     d = OracleDecoder(["scm"], 78)
     nb = raw.size // d.geom.block_size2
     q, hits, hb = d.decode_stream(raw[: nb * d.geom.block_size2], mode=1)
@@ -97,7 +101,6 @@ def test_sample_bin_true_chip_length_decodes_crc_valid_packets():
     assert [tuple(x) for x in hits_lit[:, [0, 2]].tolist()] == [(13, 376), (23, 304), (23, 305), (23, 306), (46, 1592), (51, 88)]
 
 
-@need_sample
 def test_committed_sample_fixture_is_current():
     fx = json.load(open(os.path.join(HERE, "golden", "sample_bin.json")))
     assert fx["file_sha256"] == SURVEY_SAMPLE_SHA and fx["lut_sha256"] == SURVEY_LUT_SHA

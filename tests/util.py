@@ -10,6 +10,15 @@ from rtlamr_amd.parsers.idm import build_idm_packet, build_scmplus_packet
 from rtlamr_amd.parsers.scm import build_packet
 
 
+def load_capture() -> np.ndarray:
+    """The reference's capture assets/sample.bin (raw uint8 IQ, 572 160 bytes) from the committed fixture
+    tests/golden/capture_iq.xz; its sha256 is pinned in tests/golden/sample_bin.json and SURVEY.md 8c."""
+    import lzma
+    import os
+    with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "capture_iq.xz"), "rb") as f:
+        return np.frombuffer(lzma.decompress(f.read()), dtype=np.uint8).copy()
+
+
 def make_decoder(protos, chip) -> ra.Decoder:
     d = ra.new_decoder()
     for name in protos:
