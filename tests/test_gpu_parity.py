@@ -280,3 +280,34 @@ def test_error_paths_return_status_not_crash():
         dec.close()
     with pytest.raises(Exception):
         util.make_decoder(["scm"], 78)
+
+
+def test_ragged_and_empty_inputs():
+    """Extra input beyond whole blocks is ignored (as in Go: Decode reads exactly BlockSize2 bytes, decode.go:169);
+    zero blocks, a collect without a submit and a timing query without timing are AMR_EINVAL, not crashes."""
+    import ctypes as C
+    from rtlamr_amd import _lib
+    L = _lib.lib()
+    dec = util.make_decoder(["scm"], 72)
+    try:
+        bs2 = dec.Cfg.BlockSize2
+        iq, _ = util.synth_stream(["scm"], 72, 40, dec.Cfg.BlockSize, seed=12, n_packets=3)
+        want = util.gpu_run(dec, iq)
+        dec.reset()
+        ragged = np.concatenate([iq, np.full(bs2 - 1, 200, np.uint8)])       # 40 blocks + almost one more
+        got = util.gpu_run(dec, ragged[: 40 * bs2])                              # the mirror passes whole blocks ...
+        assert all(np.array_equal(a, b) for a, b in zip(want, got))
+        dec.reset()
+        res = _lib.AmrResult()                                                   # ... the ABI itself ignores the surplus
+        _lib.check(L.amr_decode_batch(dec._require(), ragged.ctypes.data, ragged.size, 40, C.byref(res)), "ragged")
+        assert int(res.n_hits) == len(want[1]) > 0
+        assert L.amr_decode_batch(dec._require(), ragged.ctypes.data, ragged.size, 0, C.byref(res)) == _lib.AMR_EINVAL
+        assert L.amr_collect(dec._require(), C.byref(res)) == _lib.AMR_EINVAL
+        t = _lib.AmrTiming()
+        fresh = util.make_decoder(["scm"], 72)
+        try:
+            assert L.amr_get_timing(fresh._require(), C.byref(t)) == _lib.AMR_EINVAL
+        finally:
+            fresh.close()
+    finally:
+        dec.close()
