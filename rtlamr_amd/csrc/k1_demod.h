@@ -57,6 +57,11 @@
 // 11 fewer instructions of 90).  Measured on MI355X, A/B on one box: 0.2296 / 0.2174 ms against 0.2276 / 0.2144 ms for
 // the plain build -- no gain: a packed op takes two passes through the FP32 lanes, and those, not the issue slots, are
 // what the arithmetic costs.  Bit-exact either way (tests/test_gpu_parity.py, test_gpu_fullsize.py pass with it).
+// cache-policy bits of the LDS-DMA loads of the IQ stream.  A/B on one MI355X (K1 ms, 1 GiB): "nt" 0.2255 / 0.2261,
+// "sc1 nt" 0.2261 / 0.2258, "sc0 sc1 nt" 0.2271 / 0.2257, "sc0 nt" 0.2256 / 0.2246, "sc1" (temporal) 0.2430 / 0.2447.
+#ifndef AMR_K1_LDFLAGS
+#define AMR_K1_LDFLAGS "nt"
+#endif
 #ifndef AMR_K1_PK
 #define AMR_K1_PK 0
 #endif
@@ -170,10 +175,10 @@ __device__ __forceinline__ void k1_prefetch(const K1Args &a, uint32_t lds_base, 
         uint32_t m0v = lds_base + buf_off;
 #pragma unroll 1
         for (int q = 0; q < 4; ++q) {                               // a rolled loop: this code sits in every group
-            asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1 nt"
+            asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1 " AMR_K1_LDFLAGS
                          :: "v"(voff_e), "s"(base), "s"(m0v) : "memory");
             base += (size_t)8 * bs2;
-            asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1 nt"
+            asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1 " AMR_K1_LDFLAGS
                          :: "v"(voff_o), "s"(base), "s"(m0v + 1024) : "memory");
             base += (size_t)8 * bs2;
             m0v += 2048;
@@ -197,7 +202,7 @@ __device__ __forceinline__ void k1_prefetch(const K1Args &a, uint32_t lds_base, 
                 g = (rl == 0) ? a.carry + t * kTileBytes + colb : g;
             }
         }
-        asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off nt"
+        asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off " AMR_K1_LDFLAGS
                      :: "v"(g), "s"(lds_base + buf_off + q * 1024) : "memory");
     }
 }

@@ -21,7 +21,7 @@ def _random_split(rng, n):
     return parts
 
 
-@pytest.mark.parametrize("seed", range(16))
+@pytest.mark.parametrize("seed", range(48))
 def test_random_configuration(seed):
     rng = np.random.default_rng(1000 + seed)
     protos = PROTO_SETS[int(rng.integers(len(PROTO_SETS)))]
