@@ -101,7 +101,7 @@ typedef struct amr_result {
 /* Timing of the last batch, measured with HIP events on the handle's stream. */
 typedef struct amr_timing {
     float demod_ms;   /* K1: magnitude + csum matched filter + quantize + pack */
-    float search_ms;  /* K2 + scan + K3: preamble search, compaction, slice */
+    float search_ms;  /* K2 + K3: preamble search, compaction, slice */
     float total_ms;   /* first kernel start to last kernel end (device side) */
 } amr_timing;
 

@@ -75,7 +75,8 @@ bool legal_chip_length(int cl)
 // already runs batch i+1 (compute stream); the quantized history flows slot -> slot.
 struct Slot {
     uint32_t *d_qt = nullptr;     size_t qt_tiles = 0;     // tiled bitstream, tile 0 = history tile
-    uint32_t *d_counts = nullptr; uint64_t *d_offsets = nullptr; size_t cnt_tiles = 0;
+    uint32_t *d_counts = nullptr; size_t cnt_tiles = 0;
+    uint32_t *d_gcnt = nullptr; uint32_t gcnt_words = 0;     // hit counts summed over groups of 64 tiles (K2 -> K3)
     uint64_t *d_offs_pre = nullptr;                        // [n_pre+1] + overflow word behind it
     uint32_t *d_overflow = nullptr;
     uint32_t *d_staging = nullptr; size_t staging_tiles = 0; uint32_t stage_cap = 1024;
@@ -236,8 +237,16 @@ amr_status ensure_capacity(amr_handle *h, Slot &s, size_t n_blocks)
     const size_t st = bt + 1;                 // tiles searched
     if (st > s.cnt_tiles) {
         AMR_TRY(dev_realloc(s.d_counts, st * h->sg.n_pre));
-        AMR_TRY(dev_realloc(s.d_offsets, st * h->sg.n_pre));
         s.cnt_tiles = st;
+    }
+    // group sums: BOTH slots (the hist kernel of the batch in one slot zeroes those of the other), kept zero between uses
+    const uint32_t gw = (uint32_t)(amr::k2_groups((uint32_t)st) * h->sg.n_pre);
+    for (Slot &sl : h->slot) {
+        if (gw <= sl.gcnt_words) continue;
+        HIP_TRY(hipStreamSynchronize(h->stream));
+        AMR_TRY(dev_realloc(sl.d_gcnt, gw));
+        HIP_TRY(hipMemset(sl.d_gcnt, 0, (size_t)gw * 4));
+        sl.gcnt_words = gw;
     }
     if (st > s.staging_tiles) {
         AMR_TRY(dev_realloc(s.d_staging, st * h->sg.n_pre * s.stage_cap));
@@ -248,7 +257,7 @@ amr_status ensure_capacity(amr_handle *h, Slot &s, size_t n_blocks)
     return AMR_OK;
 }
 
-// K2 + K2s + K3 for the batch held by slot s (may be re-run after a capacity overflow).
+// K2 + K3 (+ K4, K5) for the batch held by slot s (may be re-run after a capacity overflow).
 amr_status enqueue_search(amr_handle *h, Slot &s, bool rerun = false, bool dense = false)
 {
     hipStream_t st = h->stream;
@@ -257,6 +266,7 @@ amr_status enqueue_search(amr_handle *h, Slot &s, bool rerun = false, bool dense
     amr::K2Args k2{};
     k2.qt = s.d_qt;
     k2.counts = s.d_counts;
+    k2.gcnt = s.d_gcnt;
     k2.staging = s.d_staging;
     k2.overflow = s.d_overflow;
     k2.n_tiles = s.n_tiles;
@@ -266,8 +276,13 @@ amr_status enqueue_search(amr_handle *h, Slot &s, bool rerun = false, bool dense
     k2.g = h->sg;
     const bool t2 = s.timed >= 2;
     // the overflow word is zeroed by the previous batch's k_hist_update; only a re-run has to do it here
-    if (rerun) HIP_TRY(hipMemsetAsync(s.d_overflow, 0, 4, st));
-    if (!h->dense_search && !dense && n_pre <= 4) {
+    if (rerun) {
+        HIP_TRY(hipMemsetAsync(s.d_overflow, 0, 4, st));
+        HIP_TRY(hipMemsetAsync(s.d_gcnt, 0, (size_t)s.gcnt_words * 4, st));
+    }
+    // the list-based kernel splits a row's words over 4 or 8 waves, 4 or 8 words per step: rows of fewer than 16 words
+    // (BlockSize 256: scm+ alone at chip length 8) go through the dense kernel
+    if (!h->dense_search && !dense && n_pre <= 4 && h->sg.wpb >= 16) {
         const int nwv = h->sg.wpb >= 32 ? 8 : 4;
         const size_t lds2 = amr::k2_fast_lds_bytes(h->sg.wpb, (int)n_pre, nwv);
 #define AMR_K2_LAUNCH(N, W, J)                                                                                        \
@@ -292,12 +307,10 @@ amr_status enqueue_search(amr_handle *h, Slot &s, bool rerun = false, bool dense
         hipExtLaunchKernelGGL(amr::k2_search_dense, dim3(s.n_tiles), dim3(256), lds2, st, t2 ? s.ev_s : nullptr, nullptr, 0, k2);
     }
     AMR_DBG(st, "k2_search");
-    amr::ScanArgs sc{s.d_counts, s.d_offsets, s.d_offs_pre, s.n_tiles, n_pre, s.h_off, s.h_ovf, s.d_overflow};
-    hipLaunchKernelGGL(amr::k2s_scan, dim3(1), dim3(1024), 0, st, sc);
-    AMR_DBG(st, "k2s_scan");
     amr::K3Args k3{};
-    k3.qt = s.d_qt; k3.counts = s.d_counts; k3.offsets = s.d_offsets; k3.staging = s.d_staging;
-    k3.out = s.d_out; k3.offs_pre = s.d_offs_pre; k3.out_cap = s.out_cap; k3.overflow = s.d_overflow;
+    k3.qt = s.d_qt; k3.counts = s.d_counts; k3.gcnt = s.d_gcnt; k3.staging = s.d_staging;
+    k3.out = s.d_out; k3.offs_pre = s.d_offs_pre; k3.h_offs_pre = s.h_off; k3.h_overflow = s.h_ovf;
+    k3.out_cap = s.out_cap; k3.overflow = s.d_overflow;
     k3.block_base = s.calls_base; k3.n_tiles = s.n_tiles; k3.cap = s.stage_cap; k3.g = h->sg;
     hipExtLaunchKernelGGL(amr::k3_slice, dim3(s.n_tiles, n_pre), dim3(256), 0, st, nullptr, t2 ? s.ev2 : nullptr, 0, k3);
     HIP_TRY(hipGetLastError());
@@ -384,7 +397,7 @@ amr_status submit(amr_handle *h, const uint8_t *d_iq, size_t n_blocks, bool sear
     // history tile of the OTHER slot (where the next batch runs); last HBA bytes of IQ become the carry
     amr::HistArgs ha{s.d_qt, other.d_qt, (uint32_t)n_blocks, h->hist_rows, h->sg.wpb, h->sg.lg_wpb,
                      d_iq + n_blocks * (size_t)h->geom.block_size2 - h->halo_bytes, h->d_carry, h->halo_bytes, other.d_overflow,
-                     s.h_done, s.ticket = h->next_ticket++};
+                     other.d_gcnt, other.gcnt_words, s.h_done, s.ticket = h->next_ticket++};
     hipLaunchKernelGGL(amr::k_hist_update, dim3(1), dim3(1024), (size_t)h->hist_rows * h->sg.wpb * 4, st, ha);
     HIP_TRY(hipGetLastError());
     AMR_DBG(st, "k_hist_update");
@@ -450,7 +463,12 @@ amr_status collect(amr_handle *h, amr_result *res)
                 AMR_TRY(alloc_hit_buffers(h, s));
                 rerun = true;
             }
-            if (!rerun) break;
+            if (!rerun) {
+                // the hist kernel of the batch that followed zeroed this slot's group sums before the re-run added
+                // to them again: leave them zero for the slot's next batch
+                if (attempt) HIP_TRY(hipMemsetAsync(s.d_gcnt, 0, (size_t)s.gcnt_words * 4, h->stream));
+                break;
+            }
             // the slot's bitstream is intact until the slot is reused, so the search can simply run again
             AMR_TRY(enqueue_search(h, s, true, use_dense));
             HIP_TRY(hipStreamSynchronize(h->stream));
@@ -619,7 +637,7 @@ amr_status amr_create(const amr_protocol *protos, int32_t n_protos, int32_t devi
     // word-aligned PacketLength
     for (uint32_t q = 0; q < sg.n_pre; ++q)
         if ((int)sg.pre_len[q] > g.preamble_symbols) { delete h; return fail(AMR_EINVAL, "preamble longer than PreambleSymbols"); }
-    if (h->hist_rows > 63 || (g.packet_length & 63) || g.block_size < 512 || g.packet_symbols < g.preamble_symbols) {
+    if (h->hist_rows > 63 || (g.packet_length & 63) || g.block_size < 256 || g.packet_symbols < g.preamble_symbols) {
         delete h;
         return fail(AMR_EINVAL, "geometry outside the supported range");
     }
@@ -670,7 +688,7 @@ amr_status amr_destroy(amr_handle *h)
     void *ptrs[] = {h->d_lut, h->d_carry, h->d_iq, h->d_untile, h->d_iqhist[0], h->d_iqhist[1], h->d_iqhist[2]};
     for (void *p : ptrs) if (p) (void)hipFree(p);
     for (Slot &sl : h->slot) {
-        void *dp[] = {sl.d_qt, sl.d_counts, sl.d_offsets, sl.d_offs_pre, sl.d_overflow, sl.d_staging, sl.d_out, sl.d_iq_stage, sl.d_r900,
+        void *dp[] = {sl.d_qt, sl.d_counts, sl.d_gcnt, sl.d_offs_pre, sl.d_overflow, sl.d_staging, sl.d_out, sl.d_iq_stage, sl.d_r900,
                       sl.d_val, sl.d_keep, sl.d_chunk, sl.d_offs_val};
         if (sl.h_r900) (void)hipHostFree(sl.h_r900);
         if (sl.ev_h2d) (void)hipEventDestroy(sl.ev_h2d);

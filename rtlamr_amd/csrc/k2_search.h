@@ -19,8 +19,8 @@
 // blocks) of the tiled bitstream, staged in LDS together with row 0 of the
 // next tile (a window never reaches further: (L-1)*SL < PreambleLength <=
 // BlockSize).  Threads walk the tile in stream order, so hits leave the tile
-// already sorted; a per-tile count plus an exclusive scan over tiles (K2s)
-// gives every tile its slot in the final per-preamble arrays, which K3 fills
+// already sorted; the per-tile counts (and their sums over groups of 64 tiles)
+// give every tile its slot in the final per-preamble arrays, which K3 fills
 // (hit position + the sliced packet, decode.go:353-375).
 #pragma once
 #include <hip/hip_runtime.h>
@@ -48,6 +48,7 @@ struct SearchGeom {
 struct K2Args {
     const uint32_t *qt;    // tiled bitstream, tile 0 = history tile
     uint32_t *counts;      // [n_pre][n_tiles]
+    uint32_t *gcnt;        // [n_pre][n_groups] sums of counts over groups of 64 tiles (atomicAdd; zero before K2 runs)
     uint32_t *staging;     // [n_tiles][n_pre][cap] tile-local positions (row*BS + bit), ascending
     uint32_t *overflow;    // set to 1 when a tile found more than cap hits for a preamble
     uint32_t n_tiles;      // tiles searched: ceil(n_blocks/64) + 1 (history tile first)
@@ -70,6 +71,10 @@ __device__ __forceinline__ uint32_t k2_word(const uint32_t *lds, uint32_t x, uin
 {
     return lds[(x & wpb_mask) * 65 + l + (x >> lg_wpb)];
 }
+
+// The per-(preamble, tile) hit counts are also summed per group of 64 tiles, so that K3 finds the slot of a list in
+// the packed result from <= n_pre * n_groups + 63 values instead of a scan over all of them.
+__host__ __device__ __forceinline__ uint32_t k2_groups(uint32_t n_tiles) { return (n_tiles + 63) >> 6; }
 
 __global__ __launch_bounds__(256) void k2_search_dense(const K2Args a)
 {
@@ -158,7 +163,9 @@ __global__ __launch_bounds__(256) void k2_search_dense(const K2Args a)
 #pragma unroll
     for (int q = 0; q < kMaxPre; ++q) {
         if (q < (int)g.n_pre && tid == 0) {
-            a.counts[q * a.n_tiles + T] = running[q] < a.cap ? running[q] : a.cap;
+            const uint32_t c = running[q] < a.cap ? running[q] : a.cap;
+            a.counts[q * a.n_tiles + T] = c;
+            if (c) atomicAdd(&a.gcnt[q * k2_groups(a.n_tiles) + (T >> 6)], c);
             if (running[q] > a.cap) atomicOr(a.overflow, 1u);
         }
     }
@@ -408,7 +415,9 @@ __global__ __launch_bounds__(64 * NWV) void k2_search_fast(const K2Args a)
     if (tid == 0) {
 #pragma unroll
         for (int q = 0; q < NPRE; ++q) {
-            a.counts[q * a.n_tiles + T] = total[q] < a.cap ? total[q] : a.cap;
+            const uint32_t c = total[q] < a.cap ? total[q] : a.cap;
+            a.counts[q * a.n_tiles + T] = c;
+            if (c) atomicAdd(&a.gcnt[q * k2_groups(a.n_tiles) + (T >> 6)], c);
             if (total[q] > a.cap) atomicOr(a.overflow, 1u);
         }
     }
@@ -420,57 +429,20 @@ inline size_t k2_fast_lds_bytes(uint32_t wpb, int npre, int nwv)
     return ((size_t)wpb * 65 + 4 * kListCap * 2 + 2 * (size_t)npre * 64 * nwv + 8) * 4;
 }
 
-// K2s: exclusive scan of counts[n_pre*n_tiles] (preamble-major) -> offsets, plus
-// per-preamble bases offs_pre[n_pre+1].  One workgroup; n is a few thousand.
-struct ScanArgs {
-    const uint32_t *counts;
-    uint64_t *offsets;   // [n_pre*n_tiles]
-    uint64_t *offs_pre;  // [n_pre+1]
-    uint32_t n_tiles;
-    uint32_t n_pre;
-    // what the host needs to size / accept the result, written straight into pinned host memory (no D2H copies
-    // on the compute stream): the per-preamble bases and K2's overflow word
-    uint64_t *h_offs_pre;       // [n_pre+1]
-    uint32_t *h_overflow;
-    const uint32_t *overflow;
-};
-
-__global__ __launch_bounds__(1024) void k2s_scan(const ScanArgs a)
-{
-    __shared__ uint64_t part[1024];
-    const uint32_t tid = threadIdx.x;
-    const uint32_t n = a.n_tiles * a.n_pre;
-    const uint32_t per = (n + 1023) / 1024;
-    const uint32_t lo = tid * per, hi = lo + per < n ? lo + per : n;
-    uint64_t s = 0;
-    for (uint32_t i = lo; i < hi; ++i) s += a.counts[i];
-    part[tid] = s;
-    __syncthreads();
-    for (uint32_t d = 1; d < 1024; d <<= 1) {  // Hillis-Steele inclusive scan, integers: exact
-        uint64_t t = tid >= d ? part[tid - d] : 0;
-        __syncthreads();
-        part[tid] += t;
-        __syncthreads();
-    }
-    uint64_t run = tid ? part[tid - 1] : 0;
-    for (uint32_t i = lo; i < hi; ++i) {
-        a.offsets[i] = run;
-        if (i % a.n_tiles == 0) { a.offs_pre[i / a.n_tiles] = run; a.h_offs_pre[i / a.n_tiles] = run; }
-        run += a.counts[i];
-    }
-    if (tid == 1023) { a.offs_pre[a.n_pre] = part[1023]; a.h_offs_pre[a.n_pre] = part[1023]; *a.h_overflow = *a.overflow; }
-}
-
 // K3: move each tile's hits to their final slot and slice the packets.
 struct K3Args {
     const uint32_t *qt;
-    const uint32_t *counts;
-    const uint64_t *offsets;
+    const uint32_t *counts;     // [n_pre][n_tiles] from K2
+    const uint32_t *gcnt;       // [n_pre][n_groups] from K2
     const uint32_t *staging;
-    // packed result [hit_block u64 x n | hit_idx u32 x n | pkt x n], n = offs_pre[n_pre] (total hits):
+    // packed result [hit_block u64 x n | hit_idx u32 x n | pkt x n], n = total hits:
     //   hit_block = block_base + (pos >> lg BS), pos = n + PacketLength;  hit_idx = pos & (BS-1)  (Data.Idx, decode.go:371)
     uint8_t *out;
-    const uint64_t *offs_pre;   // [n_pre+1] from k2s_scan
+    uint64_t *offs_pre;         // [n_pre+1] per-preamble bases, written here (K4/K5 and device-side consumers read them)
+    // what the host needs to size / accept the result, written straight into pinned host memory (no D2H copy on
+    // the compute stream): the per-preamble bases and K2's overflow word
+    uint64_t *h_offs_pre;       // [n_pre+1]
+    uint32_t *h_overflow;
     uint64_t block_base;        // call index of the first block of the batch
     uint64_t out_cap;           // hits the buffer holds
     const uint32_t *overflow;   // K2's overflow word: non-zero = the host will grow a capacity and search again
@@ -493,17 +465,42 @@ __global__ __launch_bounds__(256) void k3_slice(const K3Args a)
 {
     const SearchGeom &g = a.g;
     const uint32_t T = blockIdx.x, q = blockIdx.y;
+    // Slot of this (tile, preamble) list in the packed result = the hits of all lists before it (preamble-major), and
+    // the layout needs the grand total.  No scan kernel between K2 and K3 (a dispatch costs the stream ~5 us): K2 left
+    // sums over groups of 64 tiles, so a workgroup adds up the group sums before its group, the <= 63 counts before
+    // it inside the group, and all group sums for the total -- one load per lane.  The workgroups of tile 0 publish
+    // the per-preamble bases, (0,0) also the total and K2's overflow word, for the later kernels and for the host.
+    __shared__ uint64_t red[2][4];
+    const uint32_t cnt = a.counts[q * a.n_tiles + T];
+    if (cnt == 0 && T != 0) return;
+    const uint32_t n_groups = k2_groups(a.n_tiles), my_g = q * n_groups + (T >> 6);
+    uint64_t before = 0, all = 0;
+    for (uint32_t i = threadIdx.x; i < g.n_pre * n_groups; i += 256) {
+        const uint32_t c = a.gcnt[i];
+        all += c;
+        before += i < my_g ? c : 0u;
+    }
+    if (threadIdx.x < (T & 63)) before += a.counts[q * a.n_tiles + (T & ~63u) + threadIdx.x];
+    for (int d = 32; d; d >>= 1) {
+        before += __shfl_down((unsigned long long)before, d);
+        all += __shfl_down((unsigned long long)all, d);
+    }
+    if ((threadIdx.x & 63) == 0) { red[0][threadIdx.x >> 6] = before; red[1][threadIdx.x >> 6] = all; }
+    __syncthreads();
+    const uint64_t off = red[0][0] + red[0][1] + red[0][2] + red[0][3];
+    const uint64_t total = red[1][0] + red[1][1] + red[1][2] + red[1][3];
+    if (T == 0 && threadIdx.x == 0) {
+        a.offs_pre[q] = off;
+        a.h_offs_pre[q] = off;
+        if (q == 0) { a.offs_pre[g.n_pre] = total; a.h_offs_pre[g.n_pre] = total; *a.h_overflow = *a.overflow; }
+    }
     // After an overflow the staging slots are incomplete (a wave whose sparse list overflowed counted hits it
     // never emitted), so their contents must not be used as positions; the host re-runs the search anyway.
-    if (*a.overflow) return;
-    const uint32_t cnt = a.counts[q * a.n_tiles + T];
-    if (cnt == 0) return;
-    const uint64_t total = a.offs_pre[g.n_pre];
+    if (*a.overflow || cnt == 0) return;
     if (total > a.out_cap) return;   // the host grows the buffer and searches again
     uint64_t *hit_block = reinterpret_cast<uint64_t *>(a.out);
     uint32_t *hit_idx = reinterpret_cast<uint32_t *>(a.out + total * 8);
     uint8_t *pkt = a.out + total * 12;
-    const uint64_t off = a.offsets[q * a.n_tiles + T];
     const uint32_t *src = a.staging + ((size_t)T * g.n_pre + q) * a.cap;
     // One lane = 32 symbols of one hit (rounds = ceil(PacketSymbols/32) lanes per hit; rounds-major so that the lanes
     // of a wave hold neighbouring hits).  A real packet yields a run of adjacent hit positions: for every symbol
@@ -569,6 +566,8 @@ struct HistArgs {
     uint8_t *carry_dst;
     uint32_t carry_bytes;   // multiple of 16
     uint32_t *ovf_next;
+    uint32_t *gcnt_next;    // the group sums the next batch's K2 adds into
+    uint32_t gcnt_words;
     // completion ticket of the batch, stored to pinned host memory by the last thread of this last kernel
     uint64_t *done_flag;
     uint64_t done_value;
@@ -580,6 +579,7 @@ __global__ __launch_bounds__(1024) void k_hist_update(const HistArgs a)
     if (threadIdx.x < a.carry_bytes / 16)
         reinterpret_cast<uint4 *>(a.carry_dst)[threadIdx.x] = reinterpret_cast<const uint4 *>(a.carry_src)[threadIdx.x];
     if (threadIdx.x == 1023) *a.ovf_next = 0;
+    for (uint32_t i = threadIdx.x; i < a.gcnt_words; i += 1024) a.gcnt_next[i] = 0;
     const uint32_t n = a.hr << a.lg_wpb;
     for (uint32_t i = threadIdx.x; i < n; i += 1024) {
         const uint32_t j = i >> a.lg_wpb, w = i & (a.wpb - 1);

@@ -37,7 +37,7 @@ struct ValRule {
 struct K5Args {
     const uint8_t *in;          // K3's packed result [hit_block u64 x n | hit_idx u32 x n | pkt x n]
     uint8_t *out;               // same layout, n' = surviving hits
-    const uint64_t *offs_pre;   // [n_pre+1] from k2s_scan
+    const uint64_t *offs_pre;   // [n_pre+1] from k3_slice
     uint64_t *offs_val;         // [n_pre+1] offsets into the validated list (device)
     uint64_t *h_offs_val;       // the same in pinned host memory
     uint32_t *chunk;            // [cap/kValChunk + 2]: survivors per chunk

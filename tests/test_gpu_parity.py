@@ -44,6 +44,20 @@ def test_scm_all_legal_chip_lengths(chip):
     _check(["scm"], chip, 150, seed=10 + chip, n_packets=10, batches=[70, 80])
 
 
+def test_scmplus_alone_at_chip_8_has_256_sample_blocks():
+    """The smallest geometry a legal command line produces (-msgtype=scm+ -symbollength=8): PreambleLength 256 =
+    BlockSize, 8 words per row."""
+    dec = util.make_decoder(["scm+"], 8)
+    try:
+        assert dec.Cfg.BlockSize == 256
+        iq, _ = util.synth_stream(["scm+"], 8, 333, 256, seed=21, n_packets=10)
+        for split in ([333], [1, 2, 3, 64, 65, 198]):
+            dec.reset()
+            util.assert_same(util.oracle_run(["scm+"], 8, iq), util.gpu_run(dec, iq, split), dec.Cfg.PacketSymbols)
+    finally:
+        dec.close()
+
+
 def test_idm72():
     o, g, _ = _check(["idm"], 72, 140, seed=4, n_packets=6, batches=[5, 135])
     assert len(g[1]) > 50
