@@ -83,8 +83,8 @@ def cpu_baseline(dec, d_iq, bs2, seconds=12.0):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=50)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--blocks", type=int, default=GIB_BLOCKS, help="blocks per GPU per step (default 1 GiB)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--k1-events", type=int, default=4,
