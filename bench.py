@@ -87,6 +87,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--blocks", type=int, default=GIB_BLOCKS, help="blocks per GPU per step (default 1 GiB)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--iq-candidates", type=int, default=1,
+                    help="allocate this many candidate IQ buffers, keep the one K1 runs fastest on (1 = take the first)")
     ap.add_argument("--k1-events", type=int, default=4,
                     help="HIP events around the K1 dispatch of every N-th timed step (0 = none: roofline fields are NaN)")
     ap.add_argument("--validate", action="store_true",
@@ -121,9 +123,35 @@ def main():
     n_samples = n_blocks * bs
     nbytes = n_blocks * bs2
 
+    # ---- where the IQ batch lives ----
+    # K1's duration depends on where the driver places the 1 GiB buffer physically (0.20 ms or
+    # 0.22 ms, stable per allocation, both modes inside one process).  A caller that keeps its IQ buffers for the
+    # life of the process can choose: allocate a few candidates, time K1 on each, keep the fastest (--iq-candidates N;
+    # off by default: the bench takes the first allocation, whatever mode it lands in).
+    probe_ms = []
+    cands = []
+    for _ in range(max(1, args.iq_candidates)):
+        d = C.c_void_p()
+        _lib.check(L.amr_dev_alloc(local_rank, nbytes, C.byref(d)), "amr_dev_alloc")
+        if args.iq_candidates > 1:
+            synth.device_fill(local_rank, d.value, n_samples, seed=3, first_sample=0, packets=[], chip_length=CHIP)
+            dec.set_timing(1)
+            ts = []
+            for _ in range(6):
+                dec.submit_device(d.value, n_blocks)
+                dec.collect(copy=False)
+                ts.append(dec.timing()["demod_ms"])
+            probe_ms.append(round(float(np.mean(ts[2:])), 4))
+        cands.append(d)
+    best = int(np.argmin(probe_ms)) if probe_ms else 0
+    d_iq = cands[best]
+    for k, d in enumerate(cands):
+        if k != best:
+            _lib.check(L.amr_dev_free(local_rank, d), "amr_dev_free")
+    dec.set_timing(0)
+    dec.reset()          # the probe ran batches through the decoder: back to a fresh Decoder
+
     # ---- synthetic workload, generated in HBM (K0) ----
-    d_iq = C.c_void_p()
-    _lib.check(L.amr_dev_alloc(local_rank, nbytes, C.byref(d_iq)), "amr_dev_alloc")
     pk = build_packets(rank, bs, n_samples)
     synth.device_fill(local_rank, d_iq.value, n_samples, seed=1, first_sample=rank * n_samples, packets=pk,
                       chip_length=CHIP)
@@ -225,7 +253,9 @@ def main():
             "config": {"workload": f"scm_chip72_{n_blocks}_blocks_per_gpu", "protocols": PROTOS, "chip_length": CHIP,
                        "block_size": bs, "bytes_per_gpu_per_step": nbytes, "planted_packets_per_gpu": N_PACKETS,
                        "hits_per_step_rank0": n_hits, "hits_searched_per_step_rank0": n_searched,
-                       "gpu_validation": bool(args.validate), "parallelism": f"block-range shards x{world}",
+                       "gpu_validation": bool(args.validate),
+                       "iq_buffer": (f"fastest of {len(probe_ms)} device allocations by a 6-step K1 probe, ms: {probe_ms}"
+                                     if probe_ms else "first device allocation"), "parallelism": f"block-range shards x{world}",
                        "hit_gather": ("RCCL gather of (block, idx) records to rank 0, one async collective per step"
                                       if distributed else "none (single GPU)"),
                        "hit_gather_truncated": state["gather_truncated"]},
