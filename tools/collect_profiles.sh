@@ -4,7 +4,7 @@
 TAG=${1:-r01}
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/prof_$TAG; rm -rf $O; mkdir -p $O
-B="python $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline"
+B="python $R/bench.py --steps 5 --warmup 2 --k1-events 1 --no-cpu-baseline"
 timeout 200 rocprofv3 --kernel-trace --stats -d $O/stats -o prof --output-format csv -- $B > $O/stats.log 2>&1
 # counters in their own runs (kernel-trace only), FETCH_SIZE and WRITE_SIZE cannot share a pass (TCC slots)
 timeout 200 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $O/pmc_fetch -o pmc --output-format csv -- $B > $O/pmc_fetch.log 2>&1
