@@ -152,19 +152,22 @@ def main():
     dec.reset()          # the probe ran batches through the decoder: back to a fresh Decoder
 
     # ---- synthetic workload, generated in HBM (K0) ----
-    pk = build_packets(rank, bs, n_samples)
-    synth.device_fill(local_rank, d_iq.value, n_samples, seed=1, first_sample=rank * n_samples, packets=pk,
+    # developer hook: build the workload of shard AMR_BENCH_SHARD on a single GPU (exercises the priming path of
+    # ranks > 0 without a second GPU); the process stays rank 0 of a world of 1
+    shard_idx = int(os.environ.get("AMR_BENCH_SHARD", rank))
+    pk = build_packets(shard_idx, bs, n_samples)
+    synth.device_fill(local_rank, d_iq.value, n_samples, seed=1, first_sample=shard_idx * n_samples, packets=pk,
                       chip_length=CHIP)
-    if rank > 0:   # rebuild the history a single decoder would carry into this shard
+    if shard_idx > 0:   # rebuild the history a single decoder would carry into this shard
         pb = dec.prime_blocks()
         hb = pb + 1
         d_h = C.c_void_p()
         _lib.check(L.amr_dev_alloc(local_rank, hb * bs2, C.byref(d_h)), "amr_dev_alloc")
-        prev = build_packets(rank - 1, bs, n_samples)
-        synth.device_fill(local_rank, d_h.value, hb * bs, seed=1, first_sample=rank * n_samples - hb * bs,
+        prev = build_packets(shard_idx - 1, bs, n_samples)
+        synth.device_fill(local_rank, d_h.value, hb * bs, seed=1, first_sample=shard_idx * n_samples - hb * bs,
                           packets=prev[-8:] + pk[:1], chip_length=CHIP)
         dec.prime_device(d_h.value + bs2, pb, d_lead=d_h.value + bs2 - dec.halo_bytes())
-        dec.set_block_base(rank * n_blocks)
+        dec.set_block_base(shard_idx * n_blocks)
         _lib.check(L.amr_dev_free(local_rank, d_h), "amr_dev_free")
 
     dev = torch.device("cuda", local_rank) if distributed else None
