@@ -283,7 +283,7 @@ amr_status enqueue_search(amr_handle *h, Slot &s, bool rerun = false, bool dense
     // the list-based kernel splits a row's words over 4 or 8 waves, 4 or 8 words per step: rows of fewer than 16 words
     // (BlockSize 256: scm+ alone at chip length 8) go through the dense kernel
     if (!h->dense_search && !dense && n_pre <= 4 && h->sg.wpb >= 16) {
-        const int nwv = h->sg.wpb >= 32 ? 8 : 4;
+        const int nwv = h->sg.wpb >= 64 ? 8 : 4;   // a wave needs at least JW words of a row: 8 x 8 or 4 x 4
         const size_t lds2 = amr::k2_fast_lds_bytes(h->sg.wpb, (int)n_pre, nwv);
 #define AMR_K2_LAUNCH(N, W, J)                                                                                        \
     do {                                                                                                             \

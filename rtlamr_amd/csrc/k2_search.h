@@ -193,7 +193,7 @@ constexpr int kListCap = 448;  // (key, mask) entries per wave
 #endif
 __device__ __forceinline__ uint32_t k2_depth(uint32_t npre) { return (uint32_t)AMR_K2_DEPTH + (npre > 2 ? 2u : npre > 1 ? 1u : 0u); }
 
-// NWV waves share one tile (8 when a row has >= 32 words: 24 waves per CU hide the LDS latency of the tap loop,
+// NWV waves share one tile (8 when a row has >= 64 words, so that each wave still gets a whole 8-word step: 24 waves per CU hide the LDS latency of the tap loop,
 // which is what bounds this kernel; 4 for the 512-sample blocks of chip length 8).
 template <int NPRE, int NWV, int JW>
 __global__ __launch_bounds__(64 * NWV) void k2_search_fast(const K2Args a)

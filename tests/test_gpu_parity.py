@@ -58,6 +58,21 @@ def test_scmplus_alone_at_chip_8_has_256_sample_blocks():
         dec.close()
 
 
+@pytest.mark.parametrize("chip,bs", [(32, 1024), (40, 2048), (64, 2048), (72, 4096)])
+def test_scmplus_alone_geometries(chip, bs):
+    """scm+ alone has the shortest preamble window (16 symbols): BlockSize 1024 at chip 32 (32 words per row: the
+    4-wave search variant), 2048 at chip 40..64."""
+    dec = util.make_decoder(["scm+"], chip)
+    try:
+        assert dec.Cfg.BlockSize == bs
+        iq, _ = util.synth_stream(["scm+"], chip, 200, bs, seed=31, n_packets=8)
+        want = util.oracle_run(["scm+"], chip, iq)
+        assert len(want[2]) > 50
+        util.assert_same(want, util.gpu_run(dec, iq, [3, 64, 133]), dec.Cfg.PacketSymbols)
+    finally:
+        dec.close()
+
+
 def test_idm72():
     o, g, _ = _check(["idm"], 72, 140, seed=4, n_packets=6, batches=[5, 135])
     assert len(g[1]) > 50

@@ -1,6 +1,8 @@
 """Seeded randomized parity sweep: random protocol sets, chip lengths, stream lengths, batch splits (including
 single-block calls and splits inside a 64-block wave tile), packet amplitudes and positions, byte distributions --
 the HIP path against the oracle on quantized bits, hit lists and packet bytes, bit for bit."""
+import os
+
 import numpy as np
 import pytest
 
@@ -21,7 +23,7 @@ def _random_split(rng, n):
     return parts
 
 
-@pytest.mark.parametrize("seed", range(48))
+@pytest.mark.parametrize("seed", range(int(os.environ.get("AMR_RANDOM_SEEDS", "48"))))   # soak: AMR_RANDOM_SEEDS=1000
 def test_random_configuration(seed):
     rng = np.random.default_rng(1000 + seed)
     protos = PROTO_SETS[int(rng.integers(len(PROTO_SETS)))]
