@@ -205,11 +205,13 @@ amr_status ensure_qt(amr_handle *h, size_t tiles)
         hipError_t e = hipMalloc((void **)&nq, tiles * tile_words * 4);
         if (e != hipSuccess) return fail(AMR_ENOMEM, "hipMalloc(qt)", e);
         if (s.d_qt) {
+            // stream-ordered on purpose: the handle's stream is non-blocking, so a null-stream hipMemcpy / hipMemset
+            // (asynchronous to the host for device memory) would race with the kernels enqueued right after
+            HIP_TRY(hipMemcpyAsync(nq, s.d_qt, tile_words * 4, hipMemcpyDeviceToDevice, h->stream));
             HIP_TRY(hipStreamSynchronize(h->stream));
-            HIP_TRY(hipMemcpy(nq, s.d_qt, tile_words * 4, hipMemcpyDeviceToDevice));
             HIP_TRY(hipFree(s.d_qt));
         } else {
-            HIP_TRY(hipMemset(nq, 0, tile_words * 4));
+            HIP_TRY(hipMemsetAsync(nq, 0, tile_words * 4, h->stream));
         }
         s.d_qt = nq;
         s.qt_tiles = tiles;
@@ -245,7 +247,7 @@ amr_status ensure_capacity(amr_handle *h, Slot &s, size_t n_blocks)
         if (gw <= sl.gcnt_words) continue;
         HIP_TRY(hipStreamSynchronize(h->stream));
         AMR_TRY(dev_realloc(sl.d_gcnt, gw));
-        HIP_TRY(hipMemset(sl.d_gcnt, 0, (size_t)gw * 4));
+        HIP_TRY(hipMemsetAsync(sl.d_gcnt, 0, (size_t)gw * 4, h->stream));   // ordered before the K2 that adds into it
         sl.gcnt_words = gw;
     }
     if (st > s.staging_tiles) {
@@ -674,6 +676,7 @@ amr_status amr_create(const amr_protocol *protos, int32_t n_protos, int32_t devi
     if (e == hipSuccess) e = hipMalloc((void **)&h->d_carry, h->halo_bytes);
     if (e == hipSuccess) e = hipMemcpy(h->d_lut, h->lut, 1024, hipMemcpyHostToDevice);
     if (e == hipSuccess) e = hipMemset(h->d_carry, 0, h->halo_bytes);
+    if (e == hipSuccess) e = hipDeviceSynchronize();   // the memsets above ran on the null stream; ours is non-blocking
     if (e != hipSuccess) { amr_destroy(h); return fail(AMR_EHIP, "amr_create: device setup", e); }
     *out = h;
     return AMR_OK;
@@ -751,7 +754,7 @@ amr_status amr_r900_enable(amr_handle *h, int32_t proto_index)
     const size_t bytes = 2 * (size_t)h->geom.packet_length;
     for (uint8_t *&p : h->d_iqhist) {
         if (!p) AMR_TRY(dev_realloc(p, bytes));
-        HIP_TRY(hipMemset(p, 0, bytes));
+        HIP_TRY(hipMemsetAsync(p, 0, bytes, h->stream));
     }
     for (Slot &sl : h->slot)
         if (sl.out_cap && !sl.d_r900) AMR_TRY(dev_realloc(sl.d_r900, sl.out_cap * amr::kR900Digits));

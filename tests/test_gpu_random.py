@@ -11,7 +11,8 @@ from tests import util
 
 pytestmark = pytest.mark.gpu
 CHIPS = [8, 32, 40, 48, 56, 64, 72, 80, 88, 96]
-PROTO_SETS = [["scm"], ["scm+"], ["idm"], ["scm", "scm+"], ["scm", "idm"], ["idm", "netidm"], ["scm", "scm+", "idm"]]
+PROTO_SETS = [["scm"], ["scm+"], ["idm"], ["netidm"], ["r900"], ["scm", "scm+"], ["scm", "idm"], ["idm", "netidm"],
+              ["scm+", "idm"], ["scm", "r900"], ["scm", "scm+", "idm"], ["scm", "scm+", "idm", "r900"]]
 
 
 def _random_split(rng, n):
@@ -31,7 +32,7 @@ def test_random_configuration(seed):
     dec = util.make_decoder(protos, chip)
     try:
         bs, pl = dec.Cfg.BlockSize, dec.Cfg.PacketLength
-        longest = max(util.PKT_BUILDERS[p][1] for p in protos) * 2 * chip
+        longest = max([util.PKT_BUILDERS[p][1] for p in protos if p in util.PKT_BUILDERS] or [96]) * 2 * chip
         # keep the oracle's work bounded: ~1.5 M samples at most, at least room for four packets
         n_blocks = int(np.clip(rng.integers(70, 400), (5 * longest) // bs + 2, max(70, 1_500_000 // bs)))
         n_packets = int(min(rng.integers(2, 12), (n_blocks * bs) // (longest + 64) - 1))
