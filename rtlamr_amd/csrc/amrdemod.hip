@@ -77,6 +77,9 @@ struct Slot {
     uint32_t *d_qt = nullptr;     size_t qt_tiles = 0;     // tiled bitstream, tile 0 = history tile
     uint32_t *d_counts = nullptr; size_t cnt_tiles = 0;
     uint32_t *d_gcnt = nullptr; uint32_t gcnt_words = 0;     // hit counts summed over groups of 64 tiles (K2 -> K3)
+    // copy of this slot's history rows (tile 0) taken when the NEXT batch's state update overwrote them while this
+    // slot's batch was still uncollected: a re-run of its search swaps them back in
+    uint32_t *d_hist_save = nullptr; bool tile0_saved = false;
     uint64_t *d_offs_pre = nullptr;                        // [n_pre+1] + overflow word behind it
     uint32_t *d_overflow = nullptr;
     uint32_t *d_staging = nullptr; size_t staging_tiles = 0; uint32_t stage_cap = 1024;
@@ -194,19 +197,20 @@ void launch_k1(int cl, dim3 grid, hipStream_t st, const amr::K1Args &a, hipEvent
     }
 }
 
-// Grow the tiled bitstream of BOTH slots (the history tile of one slot is written by the batch that
-// ran in the other), keeping tile 0.
-amr_status ensure_qt(amr_handle *h, size_t tiles)
+// Make room for `tiles` tiles in the bitstream of slot `s` (the slot being submitted: nothing of it is in flight),
+// keeping its tile 0 = the history the previous batch left there.  The other slot may hold an uncollected batch whose
+// rows a re-run of its search still needs, so it is never reallocated here; it only has to EXIST, because this
+// batch's state update writes the next history tile into it.
+amr_status ensure_qt(amr_handle *h, Slot &s, Slot &other, size_t tiles)
 {
     const size_t tile_words = (size_t)64 * h->sg.wpb;
-    for (Slot &s : h->slot) {
-        if (tiles <= s.qt_tiles) continue;
+    // stream-ordered copies / memsets on purpose: the handle's stream is non-blocking, so a null-stream hipMemcpy /
+    // hipMemset (asynchronous to the host for device memory) would race with the kernels enqueued right after
+    if (tiles > s.qt_tiles) {
         uint32_t *nq = nullptr;
         hipError_t e = hipMalloc((void **)&nq, tiles * tile_words * 4);
         if (e != hipSuccess) return fail(AMR_ENOMEM, "hipMalloc(qt)", e);
         if (s.d_qt) {
-            // stream-ordered on purpose: the handle's stream is non-blocking, so a null-stream hipMemcpy / hipMemset
-            // (asynchronous to the host for device memory) would race with the kernels enqueued right after
             HIP_TRY(hipMemcpyAsync(nq, s.d_qt, tile_words * 4, hipMemcpyDeviceToDevice, h->stream));
             HIP_TRY(hipStreamSynchronize(h->stream));
             HIP_TRY(hipFree(s.d_qt));
@@ -215,6 +219,12 @@ amr_status ensure_qt(amr_handle *h, size_t tiles)
         }
         s.d_qt = nq;
         s.qt_tiles = tiles;
+    }
+    if (!other.d_qt) {
+        hipError_t e = hipMalloc((void **)&other.d_qt, tiles * tile_words * 4);
+        if (e != hipSuccess) { other.d_qt = nullptr; return fail(AMR_ENOMEM, "hipMalloc(qt)", e); }
+        HIP_TRY(hipMemsetAsync(other.d_qt, 0, tile_words * 4, h->stream));
+        other.qt_tiles = tiles;
     }
     return AMR_OK;
 }
@@ -232,10 +242,10 @@ amr_status alloc_hit_buffers(amr_handle *h, Slot &s)
     return AMR_OK;
 }
 
-amr_status ensure_capacity(amr_handle *h, Slot &s, size_t n_blocks)
+amr_status ensure_capacity(amr_handle *h, Slot &s, Slot &other, size_t n_blocks)
 {
     const size_t bt = (n_blocks + 63) / 64;   // batch tiles
-    AMR_TRY(ensure_qt(h, bt + 2));
+    AMR_TRY(ensure_qt(h, s, other, bt + 2));
     const size_t st = bt + 1;                 // tiles searched
     if (st > s.cnt_tiles) {
         AMR_TRY(dev_realloc(s.d_counts, st * h->sg.n_pre));
@@ -353,11 +363,12 @@ amr_status submit(amr_handle *h, const uint8_t *d_iq, size_t n_blocks, bool sear
     if (h->n_pending >= 2) return fail(AMR_EINVAL, "two batches already in flight: call amr_collect first");
     Slot &s = h->slot[h->next_slot];
     Slot &other = h->slot[h->next_slot ^ 1];
-    AMR_TRY(ensure_capacity(h, s, n_blocks));
+    AMR_TRY(ensure_capacity(h, s, other, n_blocks));
     hipStream_t st = h->stream;
     const uint32_t bs = (uint32_t)h->geom.block_size;
     const uint32_t full = (uint32_t)(n_blocks / 64), rem = (uint32_t)(n_blocks % 64);
 
+    s.tile0_saved = false;
     s.d_iq = d_iq;
     s.n_blocks = n_blocks;
     s.n_tiles = (uint32_t)((n_blocks + 63) / 64) + 1;
@@ -399,7 +410,9 @@ amr_status submit(amr_handle *h, const uint8_t *d_iq, size_t n_blocks, bool sear
     // history tile of the OTHER slot (where the next batch runs); last HBA bytes of IQ become the carry
     amr::HistArgs ha{s.d_qt, other.d_qt, (uint32_t)n_blocks, h->hist_rows, h->sg.wpb, h->sg.lg_wpb,
                      d_iq + n_blocks * (size_t)h->geom.block_size2 - h->halo_bytes, h->d_carry, h->halo_bytes, other.d_overflow,
-                     other.d_gcnt, other.gcnt_words, s.h_done, s.ticket = h->next_ticket++};
+                     other.d_gcnt, other.gcnt_words, other.pending ? other.d_hist_save : nullptr,
+                     s.h_done, s.ticket = h->next_ticket++};
+    other.tile0_saved = other.pending;
     hipLaunchKernelGGL(amr::k_hist_update, dim3(1), dim3(1024), (size_t)h->hist_rows * h->sg.wpb * 4, st, ha);
     HIP_TRY(hipGetLastError());
     AMR_DBG(st, "k_hist_update");
@@ -439,7 +452,7 @@ amr_status collect(amr_handle *h, amr_result *res)
     const uint32_t n_pre = h->sg.n_pre;
     AMR_TRY(wait_done(h, s));
     uint64_t total = 0, searched = 0;
-    bool use_dense = s.dense;
+    bool use_dense = s.dense, swapped = false;
     if (s.search) {
         for (int attempt = 0;; ++attempt) {
             const uint32_t ovf = *s.h_ovf;
@@ -471,9 +484,21 @@ amr_status collect(amr_handle *h, amr_result *res)
                 if (attempt) HIP_TRY(hipMemsetAsync(s.d_gcnt, 0, (size_t)s.gcnt_words * 4, h->stream));
                 break;
             }
-            // the slot's bitstream is intact until the slot is reused, so the search can simply run again
+            // The slot's bitstream rows are intact until the slot is reused, so the search can simply run again --
+            // except the history rows of tile 0 when the following batch has already put ITS tail there: swap the
+            // saved rows in for the re-runs (and back afterwards, below)
+            if (s.tile0_saved && !swapped) {
+                hipLaunchKernelGGL(amr::k_hist_swap, dim3(1), dim3(1024), 0, h->stream, s.d_qt, s.d_hist_save, h->hist_rows,
+                                   h->sg.wpb, h->sg.lg_wpb);
+                swapped = true;
+            }
             AMR_TRY(enqueue_search(h, s, true, use_dense));
             HIP_TRY(hipStreamSynchronize(h->stream));
+        }
+        if (swapped) {
+            hipLaunchKernelGGL(amr::k_hist_swap, dim3(1), dim3(1024), 0, h->stream, s.d_qt, s.d_hist_save, h->hist_rows,
+                               h->sg.wpb, h->sg.lg_wpb);
+            HIP_TRY(hipGetLastError());
         }
         if (use_dense && !s.dense) {
             if (++h->dense_streak >= 4) { h->dense_hold = 32; h->dense_streak = 0; }
@@ -666,6 +691,7 @@ amr_status amr_create(const amr_protocol *protos, int32_t n_protos, int32_t devi
         if (e == hipSuccess) *sl.h_done = 0;
         if (e == hipSuccess) e = hipMalloc((void **)&sl.d_offs_pre, (AMR_MAX_PREAMBLES + 1) * 8);
         if (e == hipSuccess) e = hipMalloc((void **)&sl.d_overflow, 4);
+        if (e == hipSuccess) e = hipMalloc((void **)&sl.d_hist_save, (size_t)h->hist_rows * sg.wpb * 4);
         if (e == hipSuccess) e = hipMalloc((void **)&sl.d_offs_val, (AMR_MAX_PREAMBLES + 1) * 8);
         if (e == hipSuccess) e = hipHostMalloc((void **)&sl.h_offv, (AMR_MAX_PREAMBLES + 1) * 8, hipHostMallocDefault);
         if (e == hipSuccess) e = hipMemset(sl.d_overflow, 0, 4);
@@ -692,7 +718,7 @@ amr_status amr_destroy(amr_handle *h)
     for (void *p : ptrs) if (p) (void)hipFree(p);
     for (Slot &sl : h->slot) {
         void *dp[] = {sl.d_qt, sl.d_counts, sl.d_gcnt, sl.d_offs_pre, sl.d_overflow, sl.d_staging, sl.d_out, sl.d_iq_stage, sl.d_r900,
-                      sl.d_val, sl.d_keep, sl.d_chunk, sl.d_offs_val};
+                      sl.d_val, sl.d_keep, sl.d_chunk, sl.d_offs_val, sl.d_hist_save};
         if (sl.h_r900) (void)hipHostFree(sl.h_r900);
         if (sl.ev_h2d) (void)hipEventDestroy(sl.ev_h2d);
         for (void *p : dp) if (p) (void)hipFree(p);

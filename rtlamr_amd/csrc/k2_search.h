@@ -568,6 +568,9 @@ struct HistArgs {
     uint32_t *ovf_next;
     uint32_t *gcnt_next;    // the group sums the next batch's K2 adds into
     uint32_t gcnt_words;
+    // When the batch that ran in the other slot has not been collected yet, its history rows (tile 0 of qt_next) are
+    // saved here before they are overwritten: a re-run of its search (capacity overflow) needs them back.
+    uint32_t *save_next;    // [hr*wpb] or null
     // completion ticket of the batch, stored to pinned host memory by the last thread of this last kernel
     uint64_t *done_flag;
     uint64_t done_value;
@@ -590,11 +593,27 @@ __global__ __launch_bounds__(1024) void k_hist_update(const HistArgs a)
     __syncthreads();
     for (uint32_t i = threadIdx.x; i < n; i += 1024) {
         const uint32_t j = i >> a.lg_wpb, w = i & (a.wpb - 1);
-        a.qt_next[qt_index(64 - a.hr + j, w, a.lg_wpb)] = tmp[i];
+        const size_t di = qt_index(64 - a.hr + j, w, a.lg_wpb);
+        if (a.save_next) a.save_next[i] = a.qt_next[di];
+        a.qt_next[di] = tmp[i];
     }
     __syncthreads();
     // every earlier kernel of the batch has completed (same stream); the host polls this word
     if (threadIdx.x == 0) __hip_atomic_store(a.done_flag, a.done_value, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
+// Exchange the history rows of tile 0 with their saved copy (before and after a re-run of a search whose slot has
+// already received the next-but-one batch's history).
+__global__ __launch_bounds__(1024) void k_hist_swap(uint32_t *qt, uint32_t *save, uint32_t hr, uint32_t wpb, uint32_t lg_wpb)
+{
+    const uint32_t n = hr << lg_wpb;
+    for (uint32_t i = threadIdx.x; i < n; i += 1024) {
+        const uint32_t j = i >> lg_wpb, w = i & (wpb - 1);
+        const size_t di = qt_index(64 - hr + j, w, lg_wpb);
+        const uint32_t t = qt[di];
+        qt[di] = save[i];
+        save[i] = t;
+    }
 }
 
 // Tests: tiled rows 64.. -> linear MSB-first byte stream (decode.go:259-265 packing).

@@ -52,3 +52,91 @@ def test_random_configuration(seed):
         util.assert_same(want, got, dec.Cfg.PacketSymbols)
     finally:
         dec.close()
+
+
+def _stream_for(rng, protos, chip, bs):
+    longest = max([util.PKT_BUILDERS[p][1] for p in protos if p in util.PKT_BUILDERS] or [96]) * 2 * chip
+    n_blocks = int(np.clip(rng.integers(70, 300), (5 * longest) // bs + 2, max(70, 1_000_000 // bs)))
+    n_packets = int(min(rng.integers(2, 10), (n_blocks * bs) // (longest + 64) - 1))
+    iq, pk = util.synth_stream(protos, chip, n_blocks, bs, seed=int(rng.integers(1 << 30)), n_packets=max(n_packets, 1),
+                               edge_every=int(rng.integers(2, 5)), amp=(int(rng.integers(20, 42)), int(rng.integers(-42, -20))))
+    for i, p in enumerate(pk):          # some packets fail their checksum
+        if rng.integers(4) == 0:
+            b = bytearray(p.data); b[int(rng.integers(4, len(b)))] ^= 1 << int(rng.integers(8))
+            synth.plant(iq, [synth.Packet(p.start, p.data, p.n_bits, -p.d_i, -p.d_q)], chip)
+            synth.plant(iq, [synth.Packet(p.start, bytes(b), p.n_bits, p.d_i, p.d_q)], chip)
+    return iq, n_blocks
+
+
+@pytest.mark.parametrize("seed", range(int(os.environ.get("AMR_RANDOM_SEEDS", "24"))))
+def test_random_pipeline_and_validation(seed):
+    """The pipelined entry points (two batches in flight, host or device input) with and without the on-device
+    validation, against the oracle (filtered by oracle/validate_oracle.py when validation is on)."""
+    import ctypes as C
+    from oracle import validate_oracle as vo
+    from oracle.oracle import PROTOCOLS
+    from rtlamr_amd import _lib
+    rng = np.random.default_rng(50_000 + seed)
+    protos = PROTO_SETS[int(rng.integers(len(PROTO_SETS)))]
+    chip = int(rng.choice(CHIPS))
+    validate = bool(rng.integers(2))
+    host_input = bool(rng.integers(2))
+    dec = util.make_decoder(protos, chip)
+    L = _lib.lib()
+    bufs = []
+    try:
+        if validate:
+            dec.EnableValidation()
+        bs, bs2 = dec.Cfg.BlockSize, dec.Cfg.BlockSize2
+        iq, n_blocks = _stream_for(rng, protos, chip, bs)
+        split = _random_split(rng, n_blocks)
+        _, _, oh, op = util.oracle_run(protos, chip, iq)
+        if validate:                                  # per preamble: oracle hits -> the rule of its parser(s)
+            H, P, done = [], [], set()
+            for name in protos:
+                pid = dec._pid_of_preamble[PROTOCOLS[name][0]]
+                if pid in done:
+                    continue
+                done.add(pid)
+                sel = np.flatnonzero(oh[:, 0] == pid)
+                keep = sel[vo.filter_hits(name, oh[sel, 1], op[sel])] if name in vo.RULES and len(sel) else sel
+                H.append(oh[keep]); P.append(op[keep])
+            order = np.argsort([h[0, 0] if len(h) else 99 for h in H], kind="stable")
+            oh, op = np.concatenate([H[i] for i in order]), np.concatenate([P[i] for i in order])
+        got_h, got_p = [], []
+
+        def take(br):
+            for pid in range(dec.n_preambles):
+                blk, idx, pk = br.for_preamble(pid)
+                got_h.append(np.stack([np.full(len(blk), pid, np.int64), blk.astype(np.int64), idx.astype(np.int64)], axis=1))
+                got_p.append(pk)
+
+        pos, inflight = 0, 0
+        for nb in split:
+            part = np.ascontiguousarray(iq[pos * bs2:(pos + nb) * bs2])
+            if host_input:
+                dec.submit_host(part)
+            else:
+                d = C.c_void_p()
+                _lib.check(L.amr_dev_alloc(0, part.size, C.byref(d)), "alloc")
+                _lib.check(L.amr_dev_upload(0, d, part.ctypes.data, part.size), "upload")
+                bufs.append(d)
+                dec.submit_device(d.value, nb)
+            inflight += 1
+            pos += nb
+            if inflight == 2:
+                take(dec.collect()); inflight -= 1
+        while inflight:
+            take(dec.collect()); inflight -= 1
+        gh, gp = np.concatenate(got_h), np.concatenate(got_p)
+        o = np.lexsort((gh[:, 2], gh[:, 1], gh[:, 0]))
+        gh, gp = gh[o], gp[o]
+        oo = np.lexsort((oh[:, 2], oh[:, 1], oh[:, 0]))
+        oh, op = oh[oo], op[oo]
+        assert gh.shape == oh.shape and np.array_equal(gh, oh), f"hits differ: gpu {len(gh)} oracle {len(oh)}"
+        nfull = dec.Cfg.PacketSymbols // 8
+        assert np.array_equal(gp[:, :nfull], op[:, :nfull])
+    finally:
+        dec.close()
+        for d in bufs:
+            L.amr_dev_free(0, d)
