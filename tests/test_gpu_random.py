@@ -140,3 +140,55 @@ def test_random_pipeline_and_validation(seed):
         dec.close()
         for d in bufs:
             L.amr_dev_free(0, d)
+
+
+@pytest.mark.parametrize("seed", range(int(os.environ.get("AMR_RANDOM_SEEDS", "12"))))
+def test_random_r900_digits(seed):
+    """r900 second stage under random burst positions, batch splits and pipelining: hits and their 42 digits against
+    oracle/r900_oracle.py."""
+    from oracle import r900_oracle
+    from rtlamr_amd.parsers import r900
+    rng = np.random.default_rng(90_000 + seed)
+    protos = [["r900"], ["scm", "r900"], ["scm", "scm+", "idm", "r900"]][int(rng.integers(3))]
+    chip = int(rng.choice([8, 32, 48, 72, 96]))
+    dec = util.make_decoder(protos, chip)
+    try:
+        bs, bs2, pl = dec.Cfg.BlockSize, dec.Cfg.BlockSize2, dec.Cfg.PacketLength
+        burst = (64 + 168) * chip
+        n_blocks = int(np.clip(rng.integers(30, 120), (pl + 4 * burst) // bs + 6, max(40, 1_200_000 // bs)))
+        total = n_blocks * bs
+        iq = synth.noise(total, int(rng.integers(1 << 30)))
+        pre = r900_oracle.PROTOCOLS["r900"][0]
+        n_b = int(rng.integers(1, 4))
+        usable = total - pl - 2 * bs - burst
+        slots = np.sort(rng.choice(np.arange(0, max(usable // (burst + 4 * chip), n_b + 1)), size=n_b, replace=False))
+        for i, sl in enumerate(slots):
+            start = int(sl) * (burst + 4 * chip) + int(rng.integers(0, 3 * chip))
+            chips = synth.r900_chips(pre, r900.build_r900_symbols(int(rng.integers(1, 1 << 31)), consumption=int(rng.integers(1 << 24)),
+                                                                  leak=int(rng.integers(16))))
+            sign = 1 if i % 2 else -1
+            synth.plant_chips(iq, start, chips, chip, sign * int(rng.integers(25, 40)), -sign * int(rng.integers(20, 35)))
+        want_hits, want_digits = r900_oracle.digits_for_stream(protos, chip, iq)
+        pid = dec._pid_of_preamble[pre]
+        hits, digits, pend = [], [], 0
+
+        def take(br):
+            blk, idx, _ = br.for_preamble(pid)
+            hits.append(np.stack([blk.astype(np.int64), idx.astype(np.int64)], axis=1))
+            digits.append(br.r900_digits)
+
+        pos = 0
+        for nb in _random_split(rng, n_blocks):
+            dec.submit_host(np.ascontiguousarray(iq[pos * bs2:(pos + nb) * bs2]))
+            pos += nb
+            pend += 1
+            if pend == 2:
+                take(dec.collect()); pend -= 1
+        while pend:
+            take(dec.collect()); pend -= 1
+        hits, digits = np.concatenate(hits), np.concatenate(digits)
+        assert np.array_equal(hits, want_hits), f"hits differ: gpu {len(hits)} oracle {len(want_hits)}"
+        bad = np.flatnonzero((digits != want_digits).any(axis=1))
+        assert len(bad) == 0, f"{len(bad)} of {len(hits)} digit rows differ, first at {hits[bad[0]]}"
+    finally:
+        dec.close()
