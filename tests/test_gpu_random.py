@@ -192,3 +192,41 @@ def test_random_r900_digits(seed):
         assert len(bad) == 0, f"{len(bad)} of {len(hits)} digit rows differ, first at {hits[bad[0]]}"
     finally:
         dec.close()
+
+
+@pytest.mark.parametrize("seed", range(int(os.environ.get("AMR_RANDOM_SEEDS", "12"))))
+def test_random_sharding(seed):
+    """SURVEY 8e with random cut points: 2-5 decoders play the ranks of a multi-GPU job on one GPU; each primes with
+    the blocks before its range (amr_prime + the aligned halo bytes), reports absolute call indices
+    (amr_set_block_base) and decodes its range in random batches; the union must equal the oracle on the whole stream."""
+    from rtlamr_amd import dist
+    rng = np.random.default_rng(130_000 + seed)
+    protos = PROTO_SETS[int(rng.integers(len(PROTO_SETS)))]
+    chip = int(rng.choice(CHIPS))
+    probe = util.make_decoder(protos, chip)
+    bs, bs2, nprime, halo = probe.Cfg.BlockSize, probe.Cfg.BlockSize2, probe.prime_blocks(), probe.halo_bytes()
+    psym = probe.Cfg.PacketSymbols
+    probe.close()
+    iq, n_blocks = _stream_for(rng, protos, chip, bs)
+    want = util.oracle_run(protos, chip, iq)
+    world = int(rng.integers(2, 6))
+    cuts = [0] + sorted(int(c) for c in rng.choice(np.arange(1, n_blocks), size=world - 1, replace=False)) + [n_blocks]
+    got_h, got_p = [], []
+    for r in range(world):
+        k0, k1 = cuts[r], cuts[r + 1]
+        dec = util.make_decoder(protos, chip)
+        try:
+            if k0 > 0:
+                p0, _ = dist.prime_range(k0, nprime)
+                lead = iq[p0 * bs2 - halo: p0 * bs2] if p0 > 0 else None
+                dec.prime(iq[p0 * bs2: k0 * bs2], lead)
+                dec.set_block_base(k0)
+            _, h, p = util.gpu_run(dec, iq[k0 * bs2: k1 * bs2], _random_split(rng, k1 - k0))
+            got_h.append(h); got_p.append(p)
+        finally:
+            dec.close()
+    h, p = np.concatenate(got_h), np.concatenate(got_p)
+    o = np.lexsort((h[:, 2], h[:, 1], h[:, 0]))
+    assert np.array_equal(h[o], want[2]), f"hits differ: shards {len(h)} oracle {len(want[2])} (cuts {cuts})"
+    nfull = psym // 8
+    assert np.array_equal(p[o][:, :nfull], want[3][:, :nfull])
