@@ -49,6 +49,9 @@ def test_mag_lut_matches_survey_vector():
     (72, ["idm"], dict(SL=144, PreL=4608, PL=105984, BS=8192, BS2=16384, Buf=114176)),
     (8, ["scm"], dict(SL=16, PreL=336, PL=1536, BS=512, BS2=1024, Buf=2048)),
     (72, ["scm", "scm+", "idm", "r900"], dict(SL=144, PreL=4608, PL=105984, BS=8192, BS2=16384, Buf=114176)),
+    # the smallest geometries a legal command line produces: scm+ alone (16 preamble symbols, scmplus.go:48-57)
+    (8, ["scm+"], dict(SL=16, PreL=256, PL=2048, BS=256, BS2=512, Buf=2304)),
+    (32, ["scm+"], dict(SL=64, PreL=1024, PL=8192, BS=1024, BS2=2048, Buf=9216)),
 ])
 def test_geometry_table(chip, protos, exp):
     """SURVEY.md section 8 geometry table (Allocate, decode.go:131-141)."""
