@@ -56,3 +56,35 @@ def test_filter_drops_failed_and_adjacent_repeats_only():
     # hit 1 repeats hit 0; hit 2 fails; hit 3 follows a different byte string (kept: only adjacent repeats go);
     # hit 5 is in another block than hit 4 (kept); hit 6 differs from hit 5
     assert vo.filter_hits("scm", blocks, pk).tolist() == [0, 3, 4, 5, 6]
+
+
+def test_parser_validators_state_the_same_rules_as_the_oracle():
+    """rtlamr_amd/parsers/*.VALIDATOR (what Decoder.EnableValidation hands to amr_set_validation) against the
+    independently written rule table of oracle/validate_oracle.py."""
+    import rtlamr_amd as ra
+    for name, (nbytes, checks) in vo.RULES.items():
+        v = ra.new_parser(name, 72).VALIDATOR
+        assert v["dedupe_bytes"] == nbytes
+        assert [(c[0], c[1], c[2], list(c[3])) for c in v["checks"]] == [(i, p, r, list(sp)) for (i, p, r), sp in checks]
+    assert getattr(ra.new_parser("r900", 72), "VALIDATOR", None) is None     # r900 hits carry digits: never filtered
+
+
+def test_netidm_message_layout():
+    """netidm.NewNetIDM (netidm/netidm.go:133-161) on a packet with known field bytes."""
+    import rtlamr_amd as ra
+    from rtlamr_amd.parsers.idm import NetIdmParser
+    pkt = bytearray(build_idm_packet(0x01020304, ert_type=7))
+    pkt[25:28] = (0x0A0B0C).to_bytes(3, "big")     # LastConsumption
+    pkt[28:31] = (0x0D0E0F).to_bytes(3, "big")     # LastGeneration
+    pkt[34:38] = (0x11223344).to_bytes(4, "big")   # LastConsumptionNet
+    crc = CRC("CCITT", 0xFFFF, 0x1021, 0x1D0F)
+    pkt[90:92] = (crc.Checksum(bytes(pkt[4:90])) ^ 0xFFFF).to_bytes(2, "big")
+    msgs = NetIdmParser(72).Parse([ra.new_data(bytes(pkt))])
+    assert len(msgs) == 1
+    m = msgs[0]
+    assert (m.MsgType(), m.MeterID(), m.MeterType()) == ("NetIDM", 0x01020304, 7)
+    assert (m.LastConsumption, m.LastGeneration, m.LastConsumptionNet) == (0x0A0B0C, 0x0D0E0F, 0x11223344)
+    assert len(m.DifferentialConsumptionIntervals) == 27
+    bad = bytearray(pkt); bad[9] ^= 1              # serial number: the serial-number CRC must reject it (netidm.go:93-98)
+    bad[90:92] = (crc.Checksum(bytes(bad[4:90])) ^ 0xFFFF).to_bytes(2, "big")
+    assert NetIdmParser(72).Parse([ra.new_data(bytes(bad))]) == []
