@@ -145,4 +145,26 @@ def symbols_to_chips(symbols: Sequence[int]) -> List[int]:
     return chips
 
 
+class R900BCD(R900):
+    """r900bcd.R900BCD (r900bcd/r900bcd.go:39-45): an R900 whose consumption was transmitted as BCD."""
+
+    def MsgType(self): return "R900BCD"
+
+
+class R900BcdParser(R900Parser):
+    """r900bcd.Parser (r900bcd/r900bcd.go:31-72): the r900 parser (same PacketConfig, so Cfg().Protocol stays "r900"
+    and the second stage on the GPU is the same), consumption re-read as decimal digits of its hex form."""
+
+    def Parse(self, pkts: List[Data]) -> List[Message]:
+        out: List[Message] = []
+        for m in super().Parse(pkts):
+            try:
+                consumption = int(format(m.Consumption, "x"), 10) & 0xFFFFFFFF   # strconv.FormatUint(.., 16) -> ParseUint(.., 10, 32)
+            except ValueError:                                                     # a hex letter: ParseUint fails, Go keeps 0
+                consumption = 0
+            out.append(R900BCD(m.ID, m.Unkn1, m.NoUse, m.BackFlow, consumption, m.Unkn3, m.Leak, m.LeakNow, m.checksum))
+        return out
+
+
 register_parser("r900", R900Parser)
+register_parser("r900bcd", R900BcdParser)

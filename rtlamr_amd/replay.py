@@ -81,7 +81,7 @@ def replay(dec: ra.Decoder, stream: BinaryIO, batch_blocks: int = 16384, unique:
 def main(argv=None) -> int:
     ap = argparse.ArgumentParser(description="replay raw uint8 IQ through the MI355X decoder (rtlamr Decode hot path)")
     ap.add_argument("file", help="raw interleaved uint8 I,Q ('-' = stdin)")
-    ap.add_argument("--msgtype", default="scm", help="comma separated: scm,scm+,idm,netidm,r900 ('all' = scm,scm+,idm,r900)")
+    ap.add_argument("--msgtype", default="scm", help="comma separated: scm,scm+,idm,netidm,r900,r900bcd ('all' = scm,scm+,idm,r900)")
     ap.add_argument("--symbollength", type=int, default=72)
     ap.add_argument("--batch-blocks", type=int, default=16384)
     ap.add_argument("--device", type=int, default=0)

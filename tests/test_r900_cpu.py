@@ -84,3 +84,20 @@ def test_numpy_oracle_equals_literal_c_filter():
             assert tuple(hits[row]) == (k, int(idx)) and np.array_equal(digits[row], want)
             row += 1
     assert row == len(hits)
+
+
+def test_r900bcd_parser_rereads_consumption_as_bcd():
+    """r900bcd/r900bcd.go:47-72: same parser, Consumption = decimal reading of its hex digits; MsgType R900BCD."""
+    import numpy as np
+    import rtlamr_amd as ra
+    from rtlamr_amd.parsers import r900
+    syms = r900.build_r900_symbols(987654, consumption=0x123456)
+    digits = np.array([d for s in syms for d in (s // 6, s % 6)], np.uint8)
+    pkt = ra.new_data(bytes(15))
+    pkt.Digits = digits
+    plain = ra.new_parser("r900", 72).Parse([pkt])
+    bcd = ra.new_parser("r900bcd", 72).Parse([pkt])
+    assert len(plain) == 1 and len(bcd) == 1
+    assert plain[0].Consumption == 0x123456 and plain[0].MsgType() == "R900"
+    assert bcd[0].Consumption == 123456 and bcd[0].MsgType() == "R900BCD" and bcd[0].ID == 987654
+    assert ra.new_parser("r900bcd", 72).Cfg().Protocol == "r900"       # it wraps r900.NewParser (r900bcd.go:35-37)
