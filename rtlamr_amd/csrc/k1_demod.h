@@ -216,8 +216,8 @@ __device__ __forceinline__ void k1_prefetch(const K1Args &a, uint32_t lds_base, 
 // boundary first wait for the tile's DMA (issued one tile-time earlier), then refill the buffer that was
 // drained before it.  Groups past the end of the lane's stream read stale LDS bytes that nobody uses.
 // The LDS address is one v_xor: rdv = lane*128 | swizzle, U.roff = (group in tile)*16 | (tile parity)*8192.
-// Every wave-instruction costs the wave an issue slot of ~4.5 cycles and K1 is issue-bound (tools/dma_bench4.hip:
-// time grows linearly with the instruction count per group), so the common path is 4 scalar ops.
+// Scalar instructions go through the one scalar unit the four SIMDs of a CU share, and trimming them is what paid
+// in this loop (25 -> 15 per group: 0.229 -> 0.218 ms), so the common path is 4 scalar ops.
 template <int CL, bool TAIL>
 __device__ __forceinline__ uint4 k1_fetch_next(K1Uni &U, const K1Args &a, uint32_t tiles_lds, const uint8_t *tiles,
                                                uint32_t wg, uint32_t lane, uint32_t rdv, uint32_t voff_e,
@@ -337,7 +337,7 @@ __device__ __forceinline__ void k1_body(K1Lane<CL> &L, K1Uni &U, const K1Args &a
 #endif
 #endif
 #if AMR_K1_PK
-        // Packed form: a wave is limited by its own issue rate (one instruction per ~5 cycles whatever it is), and
+        // Packed form (an experiment, see AMR_K1_PK above: fewer issue slots, same lane passes, no gain):
         // v_pk_add_f32 does two independent IEEE binary32 adds in one issue slot: the magnitude add and the two
         // differences of samples (2j, 2j+1) pair up (ring slots r, r+1 and ro, ro+1 are adjacent registers, RING
         // is even); the running sum itself stays a serial chain of plain v_add_f32 (in asm: left to itself hipcc
