@@ -117,6 +117,13 @@ typedef struct amr_timing {
 amr_status amr_create(const amr_protocol *protos, int32_t n_protos, int32_t device_id, amr_handle **out);
 amr_status amr_destroy(amr_handle *h);
 
+/*
+ * The arithmetic of RegisterProtocol + Allocate alone (decode.go:100-141), without a device: the geometry amr_create
+ * would arrive at, and (preamble_ids != NULL, n_protos entries) the preamble group of every entry.  Lets a binding
+ * validate a protocol set and size its buffers before a GPU is touched; same argument checks as amr_create.
+ */
+amr_status amr_plan(const amr_protocol *protos, int32_t n_protos, amr_geometry *geom, int32_t *preamble_ids);
+
 /* Forget all history: equivalent to a freshly allocated Decoder (decode.go:144-145 zero buffers). */
 amr_status amr_reset(amr_handle *h);
 

@@ -14,7 +14,7 @@ AMR_OK, AMR_EINVAL, AMR_ENOMEM, AMR_EHIP, AMR_ENODEV, AMR_EOVERFLOW = 0, -1, -2,
 
 # every symbol include/amrdemod.h declares (checked by tests/test_abi.py)
 SYMBOLS = [
-    "amr_create", "amr_destroy", "amr_reset", "amr_get_geometry", "amr_preamble_id", "amr_get_mag_lut", "amr_r900_enable", "amr_set_validation",
+    "amr_create", "amr_plan", "amr_destroy", "amr_reset", "amr_get_geometry", "amr_preamble_id", "amr_get_mag_lut", "amr_r900_enable", "amr_set_validation",
     "amr_set_stream", "amr_set_block_base", "amr_decode_batch", "amr_decode_batch_device", "amr_submit_device", "amr_collect", "amr_submit_host", "amr_host_alloc", "amr_host_free", "amr_result_device", "amr_prime",
     "amr_halo_bytes", "amr_prime_blocks", "amr_copy_quantized", "amr_set_timing", "amr_get_timing", "amr_strerror",
     "amr_last_error", "amr_describe", "amr_dev_alloc", "amr_dev_free", "amr_dev_upload", "amr_dev_download",
@@ -87,6 +87,7 @@ def lib() -> C.CDLL:
     L = C.CDLL(path)
     vp, u8p = C.c_void_p, C.POINTER(C.c_uint8)
     L.amr_create.argtypes = [C.POINTER(AmrProtocol), C.c_int32, C.c_int32, C.POINTER(vp)]
+    L.amr_plan.argtypes = [C.POINTER(AmrProtocol), C.c_int32, C.POINTER(AmrGeometry), C.POINTER(C.c_int32)]
     L.amr_destroy.argtypes = [vp]
     L.amr_reset.argtypes = [vp]
     L.amr_get_geometry.argtypes = [vp, C.POINTER(AmrGeometry)]

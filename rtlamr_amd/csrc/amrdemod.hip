@@ -581,6 +581,77 @@ amr_status drain(amr_handle *h)
     return AMR_OK;
 }
 
+// RegisterProtocol for every entry + the arithmetic of Allocate (decode.go:100-141): no device involved.
+amr_status plan_geometry(const amr_protocol *protos, int32_t n_protos, amr_geometry &g, amr::SearchGeom &sg,
+                         std::vector<int> &proto_pid, uint32_t &halo_bytes, uint32_t &hist_rows)
+{
+    g = amr_geometry{};
+    sg = amr::SearchGeom{};
+    proto_pid.clear();
+    // RegisterProtocol, decode.go:100-128: field-wise max, preambles grouped by value
+    for (int i = 0; i < n_protos; ++i) {
+        const amr_protocol &p = protos[i];
+        if (!p.preamble || !legal_chip_length(p.chip_length) || p.preamble_symbols <= 0 || p.packet_symbols <= 0 ||
+            (g.chip_length && p.chip_length != g.chip_length)) {
+            return fail(AMR_EINVAL, "amr_create: bad protocol entry (chip length must be one of flags.go:127-132)");
+        }
+        const size_t len = strlen(p.preamble);
+        if (len == 0 || len > AMR_MAX_PREAMBLE_BITS) { return fail(AMR_EINVAL, "preamble length"); }
+        g.data_rate = std::max(g.data_rate, p.data_rate);
+        g.chip_length = std::max(g.chip_length, p.chip_length);
+        g.preamble_symbols = std::max(g.preamble_symbols, p.preamble_symbols);
+        g.packet_symbols = std::max(g.packet_symbols, p.packet_symbols);
+        uint64_t bits = 0;
+        for (size_t b = 0; b < len; ++b) {
+            if (p.preamble[b] != '0' && p.preamble[b] != '1') { return fail(AMR_EINVAL, "preamble must be 0/1"); }
+            if (p.preamble[b] == '1') bits |= 1ull << b;
+        }
+        int pid = -1;
+        for (uint32_t q = 0; q < sg.n_pre; ++q)
+            if (sg.pre_len[q] == len && sg.pre_bits[q] == bits) pid = (int)q;
+        if (pid < 0) {
+            if (sg.n_pre == AMR_MAX_PREAMBLES) { return fail(AMR_EINVAL, "too many distinct preambles"); }
+            pid = (int)sg.n_pre++;
+            sg.pre_len[pid] = (uint32_t)len;
+            sg.pre_bits[pid] = bits;
+        }
+        proto_pid.push_back(pid);
+    }
+    // Allocate, decode.go:131-141
+    g.symbol_length = g.chip_length << 1;
+    g.sample_rate = g.data_rate * g.chip_length;
+    g.preamble_length = g.preamble_symbols * g.symbol_length;
+    g.packet_length = g.packet_symbols * g.symbol_length;
+    g.block_size = 1 << (unsigned)std::ceil(std::log2((double)g.preamble_length));  // NextPowerOf2, decode.go:377-379
+    g.block_size2 = g.block_size << 1;
+    g.buffer_length = g.packet_length + g.block_size;
+    g.n_preambles = (int32_t)sg.n_pre;
+    g.pkt_bytes = (g.packet_symbols + 7) >> 3;
+
+    sg.block_size = (uint32_t)g.block_size;
+    sg.lg_block_size = ilog2(sg.block_size);
+    sg.wpb = sg.block_size >> 5;
+    sg.lg_wpb = sg.lg_block_size - 5;
+    sg.symbol_length = (uint32_t)g.symbol_length;
+    sg.packet_length = (uint32_t)g.packet_length;
+    sg.packet_symbols = (uint32_t)g.packet_symbols;
+    sg.pkt_bytes = (uint32_t)g.pkt_bytes;
+    sg.max_pre_len = 0;
+    for (uint32_t q = 0; q < sg.n_pre; ++q) sg.max_pre_len = std::max(sg.max_pre_len, sg.pre_len[q]);
+    halo_bytes = (uint32_t)((4 * g.chip_length + 127) & ~127);
+    hist_rows = (uint32_t)((g.packet_length + g.block_size - 1) / g.block_size);
+    // every preamble must fit the search window the geometry provides (true for all rtlamr parsers,
+    // where PreambleSymbols >= len(Preamble)); the tiled search needs <= 63 history rows and
+    // word-aligned PacketLength
+    for (uint32_t q = 0; q < sg.n_pre; ++q)
+        if ((int)sg.pre_len[q] > g.preamble_symbols) { return fail(AMR_EINVAL, "preamble longer than PreambleSymbols"); }
+    if (hist_rows > 63 || (g.packet_length & 63) || g.block_size < 256 || g.packet_symbols < g.preamble_symbols) {
+        return fail(AMR_EINVAL, "geometry outside the supported range");
+    }
+
+    return AMR_OK;
+}
+
 }  // namespace
 
 extern "C" {
@@ -604,71 +675,13 @@ amr_status amr_create(const amr_protocol *protos, int32_t n_protos, int32_t devi
     h->dense_search = getenv("AMR_DENSE_SEARCH") != nullptr;   // test hook: force the fallback search kernel
     if (const char *hc = getenv("AMR_HIT_CAP")) h->init_hit_cap = std::max<uint64_t>(256, strtoull(hc, nullptr, 10));
 
-    // RegisterProtocol, decode.go:100-128: field-wise max, preambles grouped by value
+    {
+        amr_status ps = plan_geometry(protos, n_protos, h->geom, h->sg, h->proto_pid, h->halo_bytes, h->hist_rows);
+        if (ps != AMR_OK) { delete h; return ps; }
+    }
     amr_geometry &g = h->geom;
     amr::SearchGeom &sg = h->sg;
-    for (int i = 0; i < n_protos; ++i) {
-        const amr_protocol &p = protos[i];
-        if (!p.preamble || !legal_chip_length(p.chip_length) || p.preamble_symbols <= 0 || p.packet_symbols <= 0 ||
-            (g.chip_length && p.chip_length != g.chip_length)) {
-            delete h;
-            return fail(AMR_EINVAL, "amr_create: bad protocol entry (chip length must be one of flags.go:127-132)");
-        }
-        const size_t len = strlen(p.preamble);
-        if (len == 0 || len > AMR_MAX_PREAMBLE_BITS) { delete h; return fail(AMR_EINVAL, "preamble length"); }
-        g.data_rate = std::max(g.data_rate, p.data_rate);
-        g.chip_length = std::max(g.chip_length, p.chip_length);
-        g.preamble_symbols = std::max(g.preamble_symbols, p.preamble_symbols);
-        g.packet_symbols = std::max(g.packet_symbols, p.packet_symbols);
-        uint64_t bits = 0;
-        for (size_t b = 0; b < len; ++b) {
-            if (p.preamble[b] != '0' && p.preamble[b] != '1') { delete h; return fail(AMR_EINVAL, "preamble must be 0/1"); }
-            if (p.preamble[b] == '1') bits |= 1ull << b;
-        }
-        int pid = -1;
-        for (uint32_t q = 0; q < sg.n_pre; ++q)
-            if (sg.pre_len[q] == len && sg.pre_bits[q] == bits) pid = (int)q;
-        if (pid < 0) {
-            if (sg.n_pre == AMR_MAX_PREAMBLES) { delete h; return fail(AMR_EINVAL, "too many distinct preambles"); }
-            pid = (int)sg.n_pre++;
-            sg.pre_len[pid] = (uint32_t)len;
-            sg.pre_bits[pid] = bits;
-        }
-        h->proto_pid.push_back(pid);
-    }
-    // Allocate, decode.go:131-141
-    g.symbol_length = g.chip_length << 1;
-    g.sample_rate = g.data_rate * g.chip_length;
-    g.preamble_length = g.preamble_symbols * g.symbol_length;
-    g.packet_length = g.packet_symbols * g.symbol_length;
-    g.block_size = 1 << (unsigned)std::ceil(std::log2((double)g.preamble_length));  // NextPowerOf2, decode.go:377-379
-    g.block_size2 = g.block_size << 1;
-    g.buffer_length = g.packet_length + g.block_size;
-    g.n_preambles = (int32_t)sg.n_pre;
-    g.pkt_bytes = (g.packet_symbols + 7) >> 3;
-
-    sg.block_size = (uint32_t)g.block_size;
-    sg.lg_block_size = ilog2(sg.block_size);
-    sg.wpb = sg.block_size >> 5;
-    sg.lg_wpb = sg.lg_block_size - 5;
-    sg.symbol_length = (uint32_t)g.symbol_length;
-    sg.packet_length = (uint32_t)g.packet_length;
-    sg.packet_symbols = (uint32_t)g.packet_symbols;
-    sg.pkt_bytes = (uint32_t)g.pkt_bytes;
-    sg.max_pre_len = 0;
-    for (uint32_t q = 0; q < sg.n_pre; ++q) sg.max_pre_len = std::max(sg.max_pre_len, sg.pre_len[q]);
-    h->halo_bytes = (uint32_t)((4 * g.chip_length + 127) & ~127);
-    h->hist_rows = (uint32_t)((g.packet_length + g.block_size - 1) / g.block_size);
-    // every preamble must fit the search window the geometry provides (true for all rtlamr parsers,
-    // where PreambleSymbols >= len(Preamble)); the tiled search needs <= 63 history rows and
-    // word-aligned PacketLength
-    for (uint32_t q = 0; q < sg.n_pre; ++q)
-        if ((int)sg.pre_len[q] > g.preamble_symbols) { delete h; return fail(AMR_EINVAL, "preamble longer than PreambleSymbols"); }
-    if (h->hist_rows > 63 || (g.packet_length & 63) || g.block_size < 256 || g.packet_symbols < g.preamble_symbols) {
-        delete h;
-        return fail(AMR_EINVAL, "geometry outside the supported range");
-    }
-
+    (void)g;
     // NewMagLUT, decode.go:209-216: float32 divide then float32 square, two roundings per entry.
     for (int i = 0; i < 256; ++i) {
         volatile float q = (127.5f - (float)i) / 127.5f;
@@ -705,6 +718,18 @@ amr_status amr_create(const amr_protocol *protos, int32_t n_protos, int32_t devi
     if (e == hipSuccess) e = hipDeviceSynchronize();   // the memsets above ran on the null stream; ours is non-blocking
     if (e != hipSuccess) { amr_destroy(h); return fail(AMR_EHIP, "amr_create: device setup", e); }
     *out = h;
+    return AMR_OK;
+}
+
+amr_status amr_plan(const amr_protocol *protos, int32_t n_protos, amr_geometry *geom, int32_t *preamble_ids)
+{
+    if (!protos || n_protos <= 0 || !geom) return fail(AMR_EINVAL, "amr_plan: null argument");
+    amr::SearchGeom sg;
+    std::vector<int> pid;
+    uint32_t halo = 0, hist = 0;
+    AMR_TRY(plan_geometry(protos, n_protos, *geom, sg, pid, halo, hist));
+    if (preamble_ids)
+        for (int32_t i = 0; i < n_protos; ++i) preamble_ids[i] = pid[(size_t)i];
     return AMR_OK;
 }
 

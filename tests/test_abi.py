@@ -80,3 +80,38 @@ def test_product_package_never_imports_oracle():
             if f.endswith((".py", ".h", ".hip", ".cpp")):
                 txt = open(os.path.join(dirpath, f)).read()
                 assert "import oracle" not in txt and "from oracle" not in txt and "liboracle" not in txt, f
+
+
+def test_plan_geometry_equals_oracle_for_every_protocol_set_and_chip_length(amr_lib):
+    """amr_plan = RegisterProtocol + Allocate arithmetic in the library (decode.go:100-141), no device needed: against
+    the oracle's geometry for every combination of reference parsers and legal chip length; and its argument checks."""
+    import itertools
+    from oracle.oracle import PROTOCOLS, OracleDecoder
+    import rtlamr_amd as ra
+    names = ["scm", "scm+", "idm", "netidm", "r900"]
+    for r in range(1, len(names) + 1):
+        for protos in itertools.combinations(names, r):
+            for chip in (8, 32, 40, 48, 56, 64, 72, 80, 88, 96):
+                cfgs = [ra.new_parser(n, chip).Cfg() for n in protos]
+                arr = (_lib.AmrProtocol * len(cfgs))()
+                keep = []
+                for i, c in enumerate(cfgs):
+                    s = c.Preamble.encode(); keep.append(s)
+                    arr[i] = _lib.AmrProtocol(s, c.DataRate, c.ChipLength, c.PreambleSymbols, c.PacketSymbols)
+                g = _lib.AmrGeometry()
+                pids = (C.c_int32 * len(cfgs))()
+                assert amr_lib.amr_plan(arr, len(cfgs), C.byref(g), pids) == _lib.AMR_OK, (protos, chip)
+                o = OracleDecoder(list(protos), chip).geom
+                assert (g.symbol_length, g.preamble_length, g.packet_length, g.block_size, g.block_size2, g.buffer_length,
+                        g.sample_rate) == (o.symbol_length, o.preamble_length, o.packet_length, o.block_size, o.block_size2,
+                                           o.buffer_length, o.sample_rate), (protos, chip)
+                distinct = []
+                for c in cfgs:
+                    if c.Preamble not in distinct:
+                        distinct.append(c.Preamble)
+                assert g.n_preambles == len(distinct)
+                assert list(pids) == [distinct.index(c.Preamble) for c in cfgs]        # idm and netidm share one
+    bad = (_lib.AmrProtocol * 1)(_lib.AmrProtocol(b"1010", 32768, 78, 4, 16))        # 78 is not a legal -symbollength
+    g = _lib.AmrGeometry()
+    assert amr_lib.amr_plan(bad, 1, C.byref(g), None) == _lib.AMR_EINVAL
+    assert amr_lib.amr_plan(None, 1, C.byref(g), None) == _lib.AMR_EINVAL
