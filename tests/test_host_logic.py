@@ -110,3 +110,29 @@ def test_decode_short_input_mirrors_go_panic():
     d.RegisterProtocol(ra.new_parser("scm", 72))
     with pytest.raises(RuntimeError, match="Allocate"):
         d.decode_batch(np.zeros(8192, np.uint8))
+
+
+def test_run_parsers_groups_hits_per_block_and_preamble():
+    """decode.go:177-187 in the mirror, without a device: hits of a batch are handed to the parsers block by block and
+    preamble by preamble (idm and netidm share one preamble: both parsers see the same packets), with Data.Idx set."""
+    import numpy as np
+    from rtlamr_amd.protocol import BatchResult
+    d = ra.new_decoder()
+    for n in ("scm", "idm", "netidm"):
+        d.RegisterProtocol(ra.new_parser(n, 72))
+    pre_scm, pre_idm = ra.new_parser("scm", 72).Cfg().Preamble, ra.new_parser("idm", 72).Cfg().Preamble
+    d._pid_of_preamble = {pre_scm: 0, pre_idm: 1}      # what Allocate reads back from amr_preamble_id
+    d.n_preambles = 2
+    scm_a, scm_b = build_packet(111, 4, 5), build_packet(222, 7, 9)
+    idm_a = build_idm_packet(333, consumption=1)
+    pkt = np.zeros((5, 92), np.uint8)
+    for i, b in enumerate((scm_a, scm_a, scm_b, idm_a, idm_a)):
+        pkt[i, : len(b)] = np.frombuffer(b, np.uint8)
+    br = BatchResult(n_blocks=3, first_block=10, preamble_offset=np.array([0, 3, 5], np.uint64),
+                     hit_block=np.array([10, 10, 12, 11, 11], np.uint64), hit_idx=np.array([5, 6, 9, 70, 71], np.uint32),
+                     pkt=pkt)
+    per_block = d.run_parsers(br)
+    assert [sorted((m.MsgType(), m.MeterID()) for m in b) for b in per_block] == [
+        [("SCM", 111)],                              # block 10: two hits, identical bytes -> one message (seen map)
+        [("IDM", 333), ("NetIDM", 333)],             # block 11: the shared preamble feeds both parsers
+        [("SCM", 222)]]                              # block 12
