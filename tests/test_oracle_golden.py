@@ -159,3 +159,32 @@ def test_stream_start_zero_history():
     pl = d.geom.packet_length
     early = [h for h in hits.tolist() if h[0] * bs + h[2] - pl < 0]
     assert early, "expected hits whose first taps lie in the zero history"
+
+
+@pytest.mark.parametrize("seed", range(24))
+def test_c_and_numpy_restatements_agree_on_random_configurations(seed):
+    """The two independent restatements (literal per-call C, stream-global numpy) against each other on random
+    protocol/chip/length/byte-distribution draws: quantized bits, literal == semantic search, search and slice."""
+    rng = np.random.default_rng(700 + seed)
+    name = ["scm", "scm+", "idm", "r900"][int(rng.integers(4))]
+    chip = int(rng.choice([8, 32, 40, 48, 56, 64, 72, 80, 88, 96]))
+    d = OracleDecoder([name], chip)
+    g = d.geom
+    n_blocks = int(np.clip(rng.integers(20, 120), (3 * g.packet_length) // g.block_size + 3, 600_000 // g.block_size + 20))
+    npk = 0 if name == "r900" else int(rng.integers(1, 4))
+    iq, _ = util.synth_stream([name], chip, n_blocks, g.block_size, seed=int(rng.integers(1 << 30)), n_packets=npk)
+    if rng.integers(2):
+        a = int(rng.integers(0, iq.size // 2))
+        iq[a:a + 50_000] = rng.integers(0, 256, min(50_000, iq.size - a), dtype=np.uint8)
+    o, q, h, p = util.oracle_run([name], chip, iq)
+    _, q2, h2, p2 = util.oracle_run([name], chip, iq, mode=1)
+    assert np.array_equal(q, q2) and np.array_equal(h, h2) and np.array_equal(p, p2)
+    qn = npo.quantize_stream(iq, chip, g.block_size)
+    assert np.array_equal(np.packbits(qn), q)
+    pre, pre_sym, pkt_sym = PROTOCOLS[name][0], PROTOCOLS[name][1], PROTOCOLS[name][2]
+    gg = npo.geometry(chip, pre_sym, pkt_sym)
+    hits, qq = npo.search_stream(qn, pre, gg)
+    assert np.array_equal(hits, h[:, 1:3])
+    if len(hits):
+        nfull = pkt_sym // 8
+        assert np.array_equal(npo.slice_packets(qq, hits, gg, pkt_sym)[:, :nfull], p[:, :nfull])
