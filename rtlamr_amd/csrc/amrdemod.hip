@@ -19,6 +19,7 @@
 
 #include "amrdemod.h"
 #include "k1_demod.h"
+#include "k1_tile.h"
 #include "k2_search.h"
 #include "k4_r900.h"
 #include "k5_validate.h"
@@ -185,11 +186,32 @@ amr_status host_realloc(T *&p, size_t count)
 
 // Timing events ride on the kernel dispatches themselves (hipExtLaunchKernelGGL start/stop events): a separate
 // hipEventRecord costs a ~6 us bubble on the stream each, four of them per batch were 6 % of a 1 GiB step.
+// K1 comes in two generations: k1t_demod (k1_tile.h: register-resident staging tile, two DMA tiles in flight, static
+// super-body) for every chip length whose csum rings leave room for it, k1_demod (k1_demod.h) for the rest
+// (chip 80/88/96).  AMR_K1_IMPL=old forces the first generation everywhere (A/B measurements, tests).
+bool k1_use_tile()
+{
+    static const bool on = [] { const char *e = getenv("AMR_K1_IMPL"); return !(e && strcmp(e, "old") == 0); }();
+    return on;
+}
+
+template <int CL, bool TAIL>
+void launch_k1_cl(dim3 grid, hipStream_t st, const amr::K1Args &a, hipEvent_t start, hipEvent_t stop)
+{
+    if constexpr (amr::K1TGeom<CL>::supported) {
+        if (k1_use_tile()) {
+            hipExtLaunchKernelGGL((amr::k1t_demod<CL, TAIL, amr::K1TDefault>), grid, dim3(64), amr::K1TDefault::kLds, st, start, stop, 0, a);
+            return;
+        }
+    }
+    hipExtLaunchKernelGGL((amr::k1_demod<CL, TAIL>), grid, dim3(64), 0, st, start, stop, 0, a);
+}
+
 template <bool TAIL>
 void launch_k1(int cl, dim3 grid, hipStream_t st, const amr::K1Args &a, hipEvent_t start, hipEvent_t stop)
 {
     switch (cl) {
-#define AMR_K1_CASE(N) case N: hipExtLaunchKernelGGL((amr::k1_demod<N, TAIL>), grid, dim3(64), 0, st, start, stop, 0, a); break;
+#define AMR_K1_CASE(N) case N: launch_k1_cl<N, TAIL>(grid, st, a, start, stop); break;
         AMR_K1_CASE(8) AMR_K1_CASE(32) AMR_K1_CASE(40) AMR_K1_CASE(48) AMR_K1_CASE(56)
         AMR_K1_CASE(64) AMR_K1_CASE(72) AMR_K1_CASE(80) AMR_K1_CASE(88) AMR_K1_CASE(96)
 #undef AMR_K1_CASE

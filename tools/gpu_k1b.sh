@@ -1,0 +1,5 @@
+#!/bin/bash
+cd $GRAFT_REPO_ROOT; mkdir -p gpurun_out; O=gpurun_out/k1b.log; : > $O
+run() { echo "## $*" >> $O; timeout 200 "$@" >> $O 2>&1; }
+run build/k1b_diag all 131072 15 0 2
+cat $O
