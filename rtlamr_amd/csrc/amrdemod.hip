@@ -21,6 +21,7 @@
 #include "k1_demod.h"
 #include "k1_tile.h"
 #include "k2_search.h"
+#include "k2_stream.h"
 #include "k4_r900.h"
 #include "k5_validate.h"
 #include "synth.h"
@@ -291,6 +292,13 @@ amr_status ensure_capacity(amr_handle *h, Slot &s, Slot &other, size_t n_blocks)
     return AMR_OK;
 }
 
+// AMR_K2_IMPL=old: the first-generation search everywhere
+bool k2_use_stream()
+{
+    static const bool on = [] { const char *e = getenv("AMR_K2_IMPL"); return !(e && strcmp(e, "old") == 0); }();
+    return on;
+}
+
 // K2 + K3 (+ K4, K5) for the batch held by slot s (may be re-run after a capacity overflow).
 amr_status enqueue_search(amr_handle *h, Slot &s, bool rerun = false, bool dense = false)
 {
@@ -308,15 +316,49 @@ amr_status enqueue_search(amr_handle *h, Slot &s, bool rerun = false, bool dense
     k2.n_lo = -(int64_t)h->geom.packet_length;
     k2.n_hi = (int64_t)s.n_blocks * bs - (int64_t)h->geom.packet_length;
     k2.g = h->sg;
+    k2.dbg = nullptr;
+    static unsigned long long *k2dbg = nullptr;
+    static int k2dbg_calls = 0;
+    if (getenv("AMR_K2_DBG")) {
+        if (!k2dbg) HIP_TRY(hipMalloc((void **)&k2dbg, (size_t)s.n_tiles * 64 + 64));
+        k2.dbg = k2dbg;
+        HIP_TRY(hipMemsetAsync(k2dbg, 0, (size_t)s.n_tiles * 64, st));
+    }
     const bool t2 = s.timed >= 2;
     // the overflow word is zeroed by the previous batch's k_hist_update; only a re-run has to do it here
     if (rerun) {
         HIP_TRY(hipMemsetAsync(s.d_overflow, 0, 4, st));
         HIP_TRY(hipMemsetAsync(s.d_gcnt, 0, (size_t)s.gcnt_words * 4, st));
     }
+    // second-generation search (k2_stream.h): every preamble at least 16 symbols long, rows of 64..256 words
+    bool stream_ok = !h->dense_search && !dense && k2_use_stream() && n_pre <= 4 && h->sg.wpb >= 64 && h->sg.wpb <= 256;
+    for (uint32_t q = 0; q < n_pre; ++q) stream_ok = stream_ok && h->sg.pre_len[q] >= AMR_K2S_D;
+    if (stream_ok) {
+        const int nwv = amr::k2_stream_waves(h->sg.wpb);
+        const size_t lds2 = amr::k2_stream_lds_bytes(h->sg.wpb, n_pre);
+        bool launched = true;
+#define AMR_K2S_LAUNCH(S, W)                                                                                           \
+    do {                                                                                                             \
+        HIP_TRY(hipFuncSetAttribute((const void *)amr::k2_search_stream<S, AMR_K2S_D, W>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2)); \
+        hipExtLaunchKernelGGL((amr::k2_search_stream<S, AMR_K2S_D, W>), dim3(s.n_tiles), dim3(64 * W), lds2, st, t2 ? s.ev_s : nullptr, nullptr, 0, k2); \
+    } while (0)
+#define AMR_K2S_CASE(S)                                                                                               \
+    case S:                                                                                                          \
+        if (nwv == 2) AMR_K2S_LAUNCH(S, 2); else if (nwv == 4) AMR_K2S_LAUNCH(S, 4); else AMR_K2S_LAUNCH(S, 8);      \
+        break;
+        switch (h->sg.symbol_length) {
+            AMR_K2S_CASE(64) AMR_K2S_CASE(80) AMR_K2S_CASE(96) AMR_K2S_CASE(112) AMR_K2S_CASE(128)
+            AMR_K2S_CASE(144) AMR_K2S_CASE(160) AMR_K2S_CASE(176) AMR_K2S_CASE(192)
+        default: launched = false; break;
+        }
+#undef AMR_K2S_CASE
+#undef AMR_K2S_LAUNCH
+        stream_ok = launched;
+    }
     // the list-based kernel splits a row's words over 4 or 8 waves, 4 or 8 words per step: rows of fewer than 16 words
     // (BlockSize 256: scm+ alone at chip length 8) go through the dense kernel
-    if (!h->dense_search && !dense && n_pre <= 4 && h->sg.wpb >= 16) {
+    if (stream_ok) {
+    } else if (!h->dense_search && !dense && n_pre <= 4 && h->sg.wpb >= 16) {
         const int nwv = h->sg.wpb >= 64 ? 8 : 4;   // a wave needs at least JW words of a row: 8 x 8 or 4 x 4
         const size_t lds2 = amr::k2_fast_lds_bytes(h->sg.wpb, (int)n_pre, nwv);
 #define AMR_K2_LAUNCH(N, W, J)                                                                                        \
@@ -339,6 +381,21 @@ amr_status enqueue_search(amr_handle *h, Slot &s, bool rerun = false, bool dense
         HIP_TRY(hipFuncSetAttribute((const void *)amr::k2_search_dense, hipFuncAttributeMaxDynamicSharedMemorySize,
                                     (int)lds2));
         hipExtLaunchKernelGGL(amr::k2_search_dense, dim3(s.n_tiles), dim3(256), lds2, st, t2 ? s.ev_s : nullptr, nullptr, 0, k2);
+    }
+    if (k2.dbg && ++k2dbg_calls == 6) {   // phase timestamps of the 6th search: mean duration of each phase over the workgroups
+        HIP_TRY(hipStreamSynchronize(st));
+        std::vector<unsigned long long> d((size_t)s.n_tiles * 8);
+        HIP_TRY(hipMemcpy(d.data(), k2dbg, d.size() * 8, hipMemcpyDeviceToHost));
+        double ph[6] = {0, 0, 0, 0, 0, 0}, tot = 0, cand = 0, keep = 0; unsigned long long t0 = ~0ull, t1 = 0; size_t n = 0;
+        for (size_t T = 0; T < s.n_tiles; ++T) {
+            const unsigned long long *x = &d[T * 8];
+            if (!x[0] || !x[6]) continue;
+            for (int i = 0; i < 6; ++i) ph[i] += (double)(x[i + 1] - x[i]);
+            tot += (double)(x[6] - x[0]); cand += (double)(x[7] >> 32); keep += (double)(x[7] & 0xffffffffu);
+            t0 = std::min(t0, x[0]); t1 = std::max(t1, x[6]); ++n;
+        }
+        fprintf(stderr, "[amr] k2 phases (mean ticks over %zu WGs): prologue %.0f sweep %.0f stage2 %.0f barrier %.0f scan %.0f emit %.0f | total %.0f, kernel span %llu ticks, cand %.1f keep %.1f per WG\n",
+                n, ph[0] / n, ph[1] / n, ph[2] / n, ph[3] / n, ph[4] / n, ph[5] / n, tot / n, t1 - t0, cand / n, keep / n);
     }
     AMR_DBG(st, "k2_search");
     amr::K3Args k3{};

@@ -54,6 +54,7 @@ struct K2Args {
     uint32_t n_tiles;      // tiles searched: ceil(n_blocks/64) + 1 (history tile first)
     uint32_t cap;
     int64_t n_lo, n_hi;    // valid positions: n_lo <= n < n_hi, n relative to batch sample 0
+    unsigned long long *dbg;   // developer diagnostics (AMR_K2_DBG): 8 timestamps per workgroup, or null
     SearchGeom g;
 };
 
