@@ -1,13 +1,25 @@
 #!/usr/bin/env python
-"""bench.py -- IQ Msamples/s through Decoder.Decode semantics (SCM, chip 72) on N MI355X.
+"""bench.py -- IQ Msamples/s through Decoder.Decode semantics on N MI355X (BASELINE.json metric and configs).
 
-One "step" = one pass of the whole hot path (K1 demod + K2 search + scan + K3 slice + hit
-read-back) over one batch of 1 GiB synthetic uint8 IQ per GPU (2^29 samples = 131072 reference
-blocks of 4096 samples), resident in HBM before the timed region starts.  Weak scaling: every rank
-owns 1 GiB of an N GiB stream; ranks > 0 prime their decoder with the blocks preceding their shard;
-hits are all-gathered over RCCL every step (N > 1).
+One "step" = one pass of the whole hot path (K1 demod + K2 search + K3 slice + hit read-back) over one batch of
+synthetic uint8 IQ per GPU, resident in HBM before the timed region starts.  Weak scaling: every rank owns one
+batch-sized shard of an N-shard stream; ranks > 0 prime their decoder with the blocks preceding their shard; hits are
+gathered on rank 0 over RCCL every step (N > 1).
 
-Launch:  python bench.py [--gpus 1] [--steps K] [--warmup W]
+Workloads (--workload, BASELINE.json configs 2-5; cfg1 is the CPU-only plumbing case, covered by the tests):
+  cfg2          SCM, chip 72, 1 GiB per GPU, 4096 planted CRC-valid SCM packets            (default: the headline metric)
+  cfg3          IDM, chip 72, 4 GiB per GPU, 4096 planted IDM packets
+  cfg4:<chip>   SCM at chip length <chip> (8 32 40 48 56 64 72 80 88 96), 1 GiB per GPU
+  cfg5          scm + scm+ + idm + r900 ("all" geometry), chip 72, 4 GiB per GPU, 4096 planted packets of the three
+                Manchester protocols (parsers and the r900 second stage are outside the timed region)
+
+Before the warm-up the GPU is spun up with untimed passes for --spinup-ms: the shader clock of an idle MI355X needs
+tens of milliseconds of load to reach its steady value (K1 measured at 1.6 GHz in the first 5 ms of a fresh process,
+2.4 GHz after 60 ms), and a 20-step timed region is only 6 ms long.  After the timed region the step's hit count is
+compared with the committed golden count of the workload (tests/golden/bench_counts.json) and, on rank 0, a validating
+decoder must turn the batch into exactly the planted messages; a mismatch makes the exit code non-zero.
+
+Launch:  python bench.py [--gpus 1] [--steps K] [--warmup W] [--workload cfg2]
          python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 Prints ONE JSON line on rank 0.
 """
@@ -24,41 +36,69 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-CHIP = 72
-PROTOS = ["scm"]
-GIB_BLOCKS = 131072          # 1 GiB of SCM chip-72 blocks (8192 bytes each)
-N_PACKETS = 4096             # planted CRC-valid SCM packets per GiB
+GIB = 1 << 30
 HBM_PEAK_GBS = 8000.0        # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
 ALG_BYTES_PER_SAMPLE = 2.0   # K1 reads one (I,Q) uint8 pair per sample
+GOLDEN = os.path.join(ROOT, "tests", "golden", "bench_counts.json")
+LEGAL_CHIPS = (8, 32, 40, 48, 56, 64, 72, 80, 88, 96)
 
 
-def build_packets(rank: int, bs: int, n_samples: int):
-    from rtlamr_amd import synth
+def workload(spec: str) -> dict:
+    if spec == "cfg2":
+        return dict(name="cfg2", protos=["scm"], chip=72, nbytes=1 * GIB, kinds=["scm"], n_packets=4096)
+    if spec == "cfg3":
+        return dict(name="cfg3", protos=["idm"], chip=72, nbytes=4 * GIB, kinds=["idm"], n_packets=4096)
+    if spec.startswith("cfg4:"):
+        chip = int(spec.split(":", 1)[1])
+        if chip not in LEGAL_CHIPS:
+            raise SystemExit(f"cfg4: chip length {chip} is not a legal -symbollength (flags.go:127-132)")
+        return dict(name=f"cfg4:{chip}", protos=["scm"], chip=chip, nbytes=1 * GIB, kinds=["scm"], n_packets=4096)
+    if spec == "cfg5":
+        return dict(name="cfg5", protos=["scm", "scm+", "idm", "r900"], chip=72, nbytes=4 * GIB,
+                    kinds=["scm", "scm+", "idm"], n_packets=4096)
+    raise SystemExit(f"unknown workload {spec!r} (cfg2, cfg3, cfg4:<chip>, cfg5)")
+
+
+def packet_builders():
+    from rtlamr_amd.parsers.idm import build_idm_packet, build_scmplus_packet
     from rtlamr_amd.parsers.scm import build_packet
-    base = rank * n_samples
-    starts = synth.packet_schedule(N_PACKETS, n_samples, 96 * 2 * CHIP, seed=1 + rank, edge_every=64, block_size=bs)
+    return {
+        "scm": (lambda i: build_packet(100000 + i, (i % 12) + 1, i * 37), 96),
+        "idm": (lambda i: build_idm_packet(200000 + i, consumption=i * 31), 736),
+        "scm+": (lambda i: build_scmplus_packet(300000 + i, consumption=i * 13), 128),
+    }
+
+
+def build_packets(wl: dict, shard: int, bs: int, n_samples: int):
+    """The planted packets of one shard: CRC-valid, hash-chosen offsets, every 64th straddling a block edge."""
+    from rtlamr_amd import synth
+    B = packet_builders()
+    kinds = wl["kinds"]
+    longest = max(B[k][1] for k in kinds) * 2 * wl["chip"]
+    base = shard * n_samples
+    starts = synth.packet_schedule(wl["n_packets"], n_samples, longest, seed=1 + shard, edge_every=64, block_size=bs)
     pk = []
     for i, s in enumerate(starts):
+        fn, nbits = B[kinds[i % len(kinds)]]
         sign = 1 if i % 2 else -1
-        pk.append(synth.Packet(int(base + s), build_packet(100000 + rank * N_PACKETS + i, (i % 12) + 1, i * 37),
-                               96, sign * (22 + i % 17), -sign * (21 + i % 13)))
+        pk.append(synth.Packet(int(base + s), fn(shard * wl["n_packets"] + i), nbits, sign * (22 + i % 17), -sign * (21 + i % 13)))
     return pk
 
 
-def cpu_baseline(dec, d_iq, bs2, seconds=12.0):
+def cpu_baseline(wl, dec, d_iq, bs2, seconds=12.0):
     """The C restatement of the reference Go path (oracle/decode_oracle.c, kind "port") timed on this
     host: same IQ bytes (first 64 MiB of rank 0's shard), one independent stream per thread."""
     import numpy as np
     from oracle.oracle import OracleDecoder
     from rtlamr_amd import _lib
-    nblk = 8192  # 64 MiB
+    nblk = (64 << 20) // bs2
     sample = np.empty(nblk * bs2, np.uint8)
     _lib.check(_lib.lib().amr_dev_download(dec.device_id, sample.ctypes.data, C.c_void_p(d_iq), sample.size), "download")
     ncores = os.cpu_count() or 1
 
     def run(nthreads, budget):
         done = [0] * nthreads
-        decs = [OracleDecoder(PROTOS, CHIP) for _ in range(nthreads)]
+        decs = [OracleDecoder(wl["protos"], wl["chip"]) for _ in range(nthreads)]
         t_end = time.perf_counter() + budget
 
         def work(i):
@@ -80,20 +120,53 @@ def cpu_baseline(dec, d_iq, bs2, seconds=12.0):
                       "C restatement of protocol/decode.go (gcc -O2 -ffp-contract=off), one stream per thread"}
 
 
+def verify_batch(ra, wl, local_rank, d_iq, n_blocks, pk, bs, n_samples):
+    """A second, validating decoder turns the batch into messages: exactly the planted meters must come out."""
+    dec = ra.new_decoder(local_rank)
+    try:
+        for p in wl["protos"]:
+            dec.RegisterProtocol(ra.new_parser(p, wl["chip"]))
+        dec.Allocate()
+        dec.EnableValidation()
+        br = dec.decode_batch_device(d_iq, n_blocks)
+        got = set()
+        for msgs in dec.run_parsers(br):
+            for m in msgs:
+                got.add((m.MsgType(), m.MeterID()))
+        pl = dec.Cfg.PacketLength
+        want = set()
+        ids = {"scm": "SCM", "idm": "IDM", "scm+": "SCM+"}
+        B = packet_builders()
+        for i, p in enumerate(pk):
+            if p.start + 2 * wl["chip"] + pl + bs > n_samples:   # its last call lies beyond the batch
+                continue
+            kind = wl["kinds"][i % len(wl["kinds"])]
+            base = {"scm": 100000, "idm": 200000, "scm+": 300000}[kind]
+            want.add((ids[kind], base + i))
+        missing = want - got
+        extra = {g for g in got if g not in want and g[0] in ids.values()}
+        return len(want), len(missing), len(extra)
+    finally:
+        dec.close()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--blocks", type=int, default=GIB_BLOCKS, help="blocks per GPU per step (default 1 GiB)")
+    ap.add_argument("--workload", default="cfg2", help="cfg2 (default), cfg3, cfg4:<chip>, cfg5")
+    ap.add_argument("--blocks", type=int, default=0, help="blocks per GPU per step (default: the workload's size)")
+    ap.add_argument("--spinup-ms", type=float, default=250.0, help="untimed passes before the warm-up (shader clock ramp)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--iq-candidates", type=int, default=1,
-                    help="allocate this many candidate IQ buffers, keep the one K1 runs fastest on (1 = take the first)")
+    ap.add_argument("--no-verify", action="store_true", help="skip the golden hit count / planted message check")
+    ap.add_argument("--write-golden", action="store_true", help="record this run's hit count as the workload's golden count")
     ap.add_argument("--k1-events", type=int, default=4,
                     help="HIP events around the K1 dispatch of every N-th timed step (0 = none: roofline fields are NaN)")
     ap.add_argument("--validate", action="store_true",
                     help="also run the parsers' checksum tests + repeat removal on the GPU (K5); only surviving hits are read back")
     args = ap.parse_args()
+    wl = workload(args.workload)
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -112,60 +185,36 @@ def main():
     from rtlamr_amd import _lib, dist as shard, synth
 
     L = _lib.lib()
+    chip = wl["chip"]
     dec = ra.new_decoder(local_rank)
-    for p in PROTOS:
-        dec.RegisterProtocol(ra.new_parser(p, CHIP))
+    for p in wl["protos"]:
+        dec.RegisterProtocol(ra.new_parser(p, chip))
     dec.Allocate()
     if args.validate:
         dec.EnableValidation()
     bs, bs2 = dec.Cfg.BlockSize, dec.Cfg.BlockSize2
-    n_blocks = args.blocks
+    n_blocks = args.blocks or wl["nbytes"] // bs2
     n_samples = n_blocks * bs
     nbytes = n_blocks * bs2
 
-    # ---- where the IQ batch lives ----
-    # K1's duration depends on where the driver places the 1 GiB buffer physically (0.20 ms or
-    # 0.22 ms, stable per allocation, both modes inside one process).  A caller that keeps its IQ buffers for the
-    # life of the process can choose: allocate a few candidates, time K1 on each, keep the fastest (--iq-candidates N;
-    # off by default: the bench takes the first allocation, whatever mode it lands in).
-    probe_ms = []
-    cands = []
-    for _ in range(max(1, args.iq_candidates)):
-        d = C.c_void_p()
-        _lib.check(L.amr_dev_alloc(local_rank, nbytes, C.byref(d)), "amr_dev_alloc")
-        if args.iq_candidates > 1:
-            synth.device_fill(local_rank, d.value, n_samples, seed=3, first_sample=0, packets=[], chip_length=CHIP)
-            dec.set_timing(1)
-            ts = []
-            for _ in range(6):
-                dec.submit_device(d.value, n_blocks)
-                dec.collect(copy=False)
-                ts.append(dec.timing()["demod_ms"])
-            probe_ms.append(round(float(np.mean(ts[2:])), 4))
-        cands.append(d)
-    best = int(np.argmin(probe_ms)) if probe_ms else 0
-    d_iq = cands[best]
-    for k, d in enumerate(cands):
-        if k != best:
-            _lib.check(L.amr_dev_free(local_rank, d), "amr_dev_free")
-    dec.set_timing(0)
-    dec.reset()          # the probe ran batches through the decoder: back to a fresh Decoder
+    d_iq = C.c_void_p()
+    _lib.check(L.amr_dev_alloc(local_rank, nbytes, C.byref(d_iq)), "amr_dev_alloc")
 
     # ---- synthetic workload, generated in HBM (K0) ----
     # developer hook: build the workload of shard AMR_BENCH_SHARD on a single GPU (exercises the priming path of
     # ranks > 0 without a second GPU); the process stays rank 0 of a world of 1
     shard_idx = int(os.environ.get("AMR_BENCH_SHARD", rank))
-    pk = build_packets(shard_idx, bs, n_samples)
+    pk = build_packets(wl, shard_idx, bs, n_samples)
     synth.device_fill(local_rank, d_iq.value, n_samples, seed=1, first_sample=shard_idx * n_samples, packets=pk,
-                      chip_length=CHIP)
+                      chip_length=chip)
     if shard_idx > 0:   # rebuild the history a single decoder would carry into this shard
         pb = dec.prime_blocks()
         hb = pb + 1
         d_h = C.c_void_p()
         _lib.check(L.amr_dev_alloc(local_rank, hb * bs2, C.byref(d_h)), "amr_dev_alloc")
-        prev = build_packets(shard_idx - 1, bs, n_samples)
+        prev = build_packets(wl, shard_idx - 1, bs, n_samples)
         synth.device_fill(local_rank, d_h.value, hb * bs, seed=1, first_sample=shard_idx * n_samples - hb * bs,
-                          packets=prev[-8:] + pk[:1], chip_length=CHIP)
+                          packets=prev[-8:] + pk[:1], chip_length=chip)
         dec.prime_device(d_h.value + bs2, pb, d_lead=d_h.value + bs2 - dec.halo_bytes())
         dec.set_block_base(shard_idx * n_blocks)
         _lib.check(L.amr_dev_free(local_rank, d_h), "amr_dev_free")
@@ -184,7 +233,7 @@ def main():
     state = {"gather_truncated": False}
 
     def finish():
-        """Collect the oldest batch: read back its hits and (N > 1) all-gather them over RCCL."""
+        """Collect the oldest batch: read back its hits and (N > 1) gather them over RCCL."""
         br = dec.collect(copy=False)
         if distributed:   # records go device -> RCCL -> rank 0, asynchronously; the capacity is re-agreed when outgrown
             d_ptr, _ = dec.result_device()
@@ -217,6 +266,24 @@ def main():
     if distributed:   # one untimed batch tells every rank how many hit records a batch yields
         dec.submit_device(d_iq.value, n_blocks)
         gatherer.negotiate(len(dec.collect(copy=False).hit_idx))
+
+    # ---- spin-up: untimed passes until the shader clock has ramped; they also give the steady-state step time ----
+    spin_steps, steady_ms = 0, float("nan")
+    if args.spinup_ms > 0:
+        chunk = max(8, int(8e-3 / max(1e-6, 0.28e-3 * nbytes / GIB)))     # ~8 ms of batches per chunk
+        t_spin = time.perf_counter()
+        last = []
+        while (time.perf_counter() - t_spin) * 1e3 < args.spinup_ms:
+            sync_all()
+            t1 = time.perf_counter()
+            run(chunk, 0, 0)
+            if distributed:
+                gatherer.wait()
+            sync_all()
+            last.append((time.perf_counter() - t1) * 1e3 / chunk)
+            spin_steps += chunk
+        steady_ms = float(np.min(last[-3:])) if last else float("nan")
+
     warm = run(max(args.warmup, 1), 2) if args.warmup else []
     sync_all()
     t0 = time.perf_counter()
@@ -234,46 +301,85 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
 
+    # ---- what was timed is checked: golden hit count of this (workload, size, shard), planted messages on rank 0 ----
+    rc = 0
+    check = {"hit_count": "skipped", "planted": "skipped"}
+    if not args.no_verify and not args.validate:
+        key = f"{wl['name']}|blocks={n_blocks}|shard={shard_idx}"
+        try:
+            gold = json.load(open(GOLDEN))
+        except Exception:
+            gold = {}
+        if args.write_golden:
+            gold[key] = int(n_searched)
+            json.dump(gold, open(GOLDEN, "w"), indent=1, sort_keys=True)
+        if key in gold:
+            ok = int(gold[key]) == int(n_searched)
+            check["hit_count"] = f"{n_searched} == golden" if ok else f"MISMATCH: {n_searched} != golden {gold[key]}"
+            rc = rc or (0 if ok else 3)
+        else:
+            check["hit_count"] = f"{n_searched} (no golden count for {key})"
+        if rank == 0 and shard_idx == 0:
+            n_want, n_missing, n_extra = verify_batch(ra, wl, local_rank, d_iq.value, n_blocks, pk, bs, n_samples)
+            ok = n_missing == 0 and n_extra == 0 and n_want > 0
+            check["planted"] = (f"{n_want} planted messages recovered, none missing, none unexpected" if ok else
+                                f"MISMATCH: {n_missing} of {n_want} planted messages missing, {n_extra} unexpected")
+            rc = rc or (0 if ok else 4)
+
     if rank == 0:
         total_samples = float(world) * args.steps * n_samples
         k1_ms = float(np.mean(demod_ms))
         achieved = ALG_BYTES_PER_SAMPLE * n_samples / (k1_ms * 1e-3) / 1e9
-        traffic = None
+        traffic, traffic_src = None, None
         tf = os.path.join(ROOT, "profiles", "k1_hbm_traffic.json")
-        if os.path.exists(tf):   # written from a rocprofv3 --pmc pass of this same command (see profiles/README.md)
+        if wl["name"] == "cfg2" and n_blocks == GIB // bs2 and os.path.exists(tf):
             try:
-                traffic = json.load(open(tf)).get("bytes_per_launch")
+                tj = json.load(open(tf))
+                traffic = tj.get("bytes_per_launch")
+                traffic_src = f"profiles/k1_hbm_traffic.json (static: rocprofv3 --pmc passes of this command, {tj.get('tag', 'see profiles/README.md')}); not measured in this run"
             except Exception:
                 traffic = None
+        # chip lengths up to 72 run the second-generation kernel (k1_tile.h), 80/88/96 the first (k1_demod.h)
+        k1_name = (f"k1t_demod<{chip}>" if chip <= 72 and os.environ.get("AMR_K1_IMPL") != "old" else f"k1_demod<{chip}>")
+        ms_step = dt / args.steps * 1e3
         out = {
-            "metric": "IQ Msamples/s through Decoder.Decode (SCM, 72 sym/len)",
+            "metric": "IQ Msamples/s through Decoder.Decode (SCM, 72 sym/len)" if wl["name"] == "cfg2" else
+                      f"IQ Msamples/s through Decoder.Decode ({'+'.join(wl['protos'])}, {chip} sym/len)",
             "value": round(total_samples / dt / 1e6, 1),
             "unit": "Msamples/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(dt / args.steps * 1e3, 4),
+            "ms_per_step": round(ms_step, 4),
+            "steady_ms_per_step": round(steady_ms, 4),
+            "pipeline_fill_ms": round(dt * 1e3 - args.steps * steady_ms, 4),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"scm_chip72_{n_blocks}_blocks_per_gpu", "protocols": PROTOS, "chip_length": CHIP,
-                       "block_size": bs, "bytes_per_gpu_per_step": nbytes, "planted_packets_per_gpu": N_PACKETS,
+            "config": {"workload": f"{wl['name']}: {'+'.join(wl['protos'])} chip {chip}, {n_blocks} blocks of {bs2} B per GPU",
+                       "protocols": wl["protos"], "chip_length": chip,
+                       "block_size": bs, "bytes_per_gpu_per_step": nbytes, "planted_packets_per_gpu": wl["n_packets"],
                        "hits_per_step_rank0": n_hits, "hits_searched_per_step_rank0": n_searched,
                        "gpu_validation": bool(args.validate),
-                       "iq_buffer": (f"fastest of {len(probe_ms)} device allocations by a 6-step K1 probe, ms: {probe_ms}"
-                                     if probe_ms else "first device allocation"), "parallelism": f"block-range shards x{world}",
+                       "spin_up": f"{spin_steps} untimed steps (~{args.spinup_ms:.0f} ms) before the warm-up: shader clock ramp",
+                       "checks": check,
+                       "iq_buffer": "first device allocation", "parallelism": f"block-range shards x{world}",
                        "hit_gather": ("RCCL gather of (block, idx) records to rank 0, one async collective per step"
                                       if distributed else "none (single GPU)"),
                        "hit_gather_truncated": state["gather_truncated"]},
-            "roofline": {"bound": "hbm", "kernel": "k1_demod<72>", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
+            "roofline": {"bound": "hbm", "kernel": k1_name, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
+                         "traffic_source": traffic_src,
                          "k1_ms": round(k1_ms, 4), "k1_timing": ("HIP events on the K1 dispatch of every timed step" if args.k1_events == 1 else
                                        f"HIP events on the K1 dispatch of every {args.k1_events}th timed step ({len(demod_ms)} launches)"),
                          "search_ms": round(float(np.mean(search_ms)), 4), "search_timing": "warm-up steps",
                          "algorithmic_bytes_per_launch": ALG_BYTES_PER_SAMPLE * n_samples},
         }
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(dec, d_iq.value, bs2)
+            out["cpu_baseline"] = cpu_baseline(wl, dec, d_iq.value, bs2)
     else:
         out = None
     if distributed:
+        rcs = torch.tensor([rc], dtype=torch.int32, device=dev)
+        dist.all_reduce(rcs, op=dist.ReduceOp.MAX)
+        rc = int(rcs.item())
         dist.barrier()
         dist.destroy_process_group()
     if out is not None:
@@ -284,7 +390,10 @@ def main():
         except Exception:
             pass
         print(json.dumps(out), flush=True)
+    if rc:
+        print(f"bench.py: verification failed (rc {rc}): {check}", file=sys.stderr)
+    return rc
 
 
 if __name__ == "__main__":
-    main()
+    raise SystemExit(main())

@@ -8,6 +8,8 @@
 #include <hip/hip_runtime.h>
 #include <hip/hip_ext.h>
 
+#include <sched.h>
+
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
@@ -409,7 +411,7 @@ amr_status enqueue_search(amr_handle *h, Slot &s, bool rerun = false, bool dense
     if (h->r900_pid >= 0) {
         amr::K4Args k4{};
         k4.iq = s.d_iq; k4.hist = h->d_iqhist[s.iqhist_buf]; k4.lut = h->d_lut; k4.out_packed = s.d_out;
-        k4.offs_pre = s.d_offs_pre; k4.digits = s.d_r900; k4.cap = s.out_cap; k4.block_base = s.calls_base;
+        k4.offs_pre = s.d_offs_pre; k4.overflow = s.d_overflow; k4.digits = s.d_r900; k4.cap = s.out_cap; k4.block_base = s.calls_base;
         k4.n_pre = n_pre; k4.pid = (uint32_t)h->r900_pid; k4.hist_valid = s.iqhist_valid;
         k4.block_size = bs; k4.lg_block_size = h->sg.lg_block_size; k4.packet_length = (uint32_t)h->geom.packet_length;
         k4.preamble_length = (uint32_t)h->geom.preamble_length; k4.symbol_length = (uint32_t)h->geom.symbol_length;
@@ -505,11 +507,24 @@ amr_status submit(amr_handle *h, const uint8_t *d_iq, size_t n_blocks, bool sear
 
 // Completion of a batch = its last kernel stored the batch ticket into pinned host memory.  No event on the
 // stream (each costs a ~5 us bubble); the stream is polled now and then so that a device fault ends the wait.
+static inline void cpu_relax()
+{
+#if defined(__x86_64__) || defined(__i386__)
+    __builtin_ia32_pause();
+#elif defined(__aarch64__)
+    __asm__ __volatile__("yield");
+#endif
+}
+
 amr_status wait_done(amr_handle *h, Slot &s)
 {
+    // three stages: a short busy spin (a batch in steady state completes within tens of microseconds of the call),
+    // then spinning with sched_yield so that parser threads and the other ranks' hosts get the core, and after ~2 ms a
+    // blocking hipStreamSynchronize (which also surfaces a device fault)
     for (uint64_t spin = 0;; ++spin) {
         if (__atomic_load_n(s.h_done, __ATOMIC_ACQUIRE) >= s.ticket) return AMR_OK;
-        if ((spin & 0x3ff) == 0x3ff) {
+        if (spin < 4096) { cpu_relax(); continue; }
+        if ((spin & 0xff) == 0) {
             hipError_t e = hipStreamQuery(h->stream);
             if (e == hipSuccess) {   // everything submitted has run: the ticket must be there now
                 if (__atomic_load_n(s.h_done, __ATOMIC_ACQUIRE) >= s.ticket) return AMR_OK;
@@ -517,7 +532,12 @@ amr_status wait_done(amr_handle *h, Slot &s)
             }
             if (e != hipErrorNotReady) return fail(AMR_EHIP, "hipStreamQuery", e);
         }
-        __builtin_ia32_pause();
+        if (spin > 4096 + 20000) {
+            HIP_TRY(hipStreamSynchronize(h->stream));
+            if (__atomic_load_n(s.h_done, __ATOMIC_ACQUIRE) >= s.ticket) return AMR_OK;
+            return fail(AMR_EHIP, "batch finished without publishing its ticket");
+        }
+        sched_yield();
     }
 }
 
@@ -724,7 +744,8 @@ amr_status plan_geometry(const amr_protocol *protos, int32_t n_protos, amr_geome
     // word-aligned PacketLength
     for (uint32_t q = 0; q < sg.n_pre; ++q)
         if ((int)sg.pre_len[q] > g.preamble_symbols) { return fail(AMR_EINVAL, "preamble longer than PreambleSymbols"); }
-    if (hist_rows > 63 || (g.packet_length & 63) || g.block_size < 256 || g.packet_symbols < g.preamble_symbols) {
+    // the kernels index a row's words with 8 bits and stage whole rows in LDS: BlockSize <= 8192
+    if (hist_rows > 63 || (g.packet_length & 63) || g.block_size < 256 || g.block_size > 8192 || g.packet_symbols < g.preamble_symbols) {
         return fail(AMR_EINVAL, "geometry outside the supported range");
     }
 
@@ -877,7 +898,9 @@ amr_status amr_get_mag_lut(const amr_handle *h, float *out256)
 amr_status amr_r900_enable(amr_handle *h, int32_t proto_index)
 {
     if (!h || proto_index < 0 || (size_t)proto_index >= h->proto_pid.size()) return fail(AMR_EINVAL, "bad protocol index");
-    if (h->calls_done != 0 || h->n_pending != 0) return fail(AMR_EINVAL, "amr_r900_enable: call before the first batch");
+    // zero_halo is cleared by every submit, also by amr_prime (which does not advance calls_done): enabling afterwards
+    // would zero the IQ history the primed blocks left
+    if (h->calls_done != 0 || h->n_pending != 0 || !h->zero_halo) return fail(AMR_EINVAL, "amr_r900_enable: call before the first batch");
     HIP_TRY(hipSetDevice(h->device));
     h->r900_pid = h->proto_pid[(size_t)proto_index];
     h->rules[h->r900_pid] = amr::ValRule{};   // its hits carry digits by position: never filtered

@@ -26,6 +26,7 @@ struct K4Args {
     const float *lut;         // NewMagLUT
     const uint8_t *out_packed;   // packed result of K3: [hit_block u64 x n | hit_idx u32 x n | ...]
     const uint64_t *offs_pre;    // [n_pre+1]
+    const uint32_t *overflow;    // K2's overflow word: non-zero = K3 left the packed result unwritten, the host searches again
     uint8_t *digits;          // [cap][42]
     uint64_t cap;             // hits `digits` and out_packed hold
     uint64_t block_base;      // call index of batch block 0
@@ -39,6 +40,9 @@ __global__ __launch_bounds__(64) void k4_r900_digits(const K4Args a)
     __shared__ float lut[256];
     for (int i = threadIdx.x; i < 256; i += 64) lut[i] = a.lut[i];
     __syncthreads();
+    // after an overflow K3 has published counts but no hit records: the positions in out_packed are stale or
+    // uninitialised and must not be turned into addresses
+    if (*a.overflow) return;
     const uint64_t total = a.offs_pre[a.n_pre];
     if (total > a.cap) return;                       // the host grows the buffers and runs the search again
     const uint64_t lo = a.offs_pre[a.pid], n = a.offs_pre[a.pid + 1] - lo;

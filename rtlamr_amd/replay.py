@@ -74,6 +74,14 @@ def replay(dec: ra.Decoder, stream: BinaryIO, batch_blocks: int = 16384, unique:
             if pending:
                 yield from drain_one()
     finally:
+        # a generator closed early (or a parser that raised) leaves up to two batches in flight whose host-to-device
+        # copies still read the pinned buffers: collect them before the buffers go
+        while pending:
+            try:
+                dec.collect(copy=False)
+            except Exception:      # the handle is beyond use; freeing the buffers is all that is left to do
+                break
+            pending.pop(0)
         for b in bufs:
             b.free()
 

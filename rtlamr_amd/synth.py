@@ -107,9 +107,12 @@ def device_fill(device_id: int, d_ptr: int, n_samples: int, seed: int, first_sam
     from . import _lib
     L = _lib.lib()
     _lib.check(L.amr_synth_noise(device_id, C.c_void_p(d_ptr), n_samples, seed, first_sample), "amr_synth_noise")
-    if packets:
-        start, bits, n_bits, stride, di, dq = packet_arrays(packets)
-        _lib.check(L.amr_synth_plant(device_id, C.c_void_p(d_ptr), n_samples, first_sample, chip_length, len(packets),
+    by_len = {}
+    for p in packets:                      # one plant call per packet length (scm 96, scm+ 128, idm 736 bits)
+        by_len.setdefault(p.n_bits, []).append(p)
+    for group in by_len.values():
+        start, bits, n_bits, stride, di, dq = packet_arrays(group)
+        _lib.check(L.amr_synth_plant(device_id, C.c_void_p(d_ptr), n_samples, first_sample, chip_length, len(group),
                                      start.ctypes.data, bits.ctypes.data, n_bits, stride, di.ctypes.data,
                                      dq.ctypes.data), "amr_synth_plant")
 
