@@ -150,6 +150,60 @@ def verify_batch(ra, wl, local_rank, d_iq, n_blocks, pk, bs, n_samples):
         dec.close()
 
 
+def sharded_gather_check(ra, shard, wl, local_rank, rank, world, n_blocks=256):
+    """Every rank decodes its block range of one small stream (primed with the blocks before it), the hits are gathered
+    through the C ABI, and rank 0 compares them with its own single-decoder result for the whole stream."""
+    import numpy as np
+    import torch.distributed as dist
+    from rtlamr_amd import synth
+
+    def mk():
+        d = ra.new_decoder(local_rank)
+        for p in wl["protos"]:
+            d.RegisterProtocol(ra.new_parser(p, wl["chip"]))
+        d.Allocate()
+        return d
+    dec = mk()
+    try:
+        bs, bs2 = dec.Cfg.BlockSize, dec.Cfg.BlockSize2
+        iq = synth.noise(n_blocks * bs, seed=77)
+        B = packet_builders()
+        kinds = wl["kinds"]
+        longest = max(B[k][1] for k in kinds) * 2 * wl["chip"]
+        starts = synth.packet_schedule(12, n_blocks * bs, longest, seed=5, edge_every=3, block_size=bs)
+        pk = []
+        for i, s in enumerate(starts):
+            fn, nbits = B[kinds[i % len(kinds)]]
+            pk.append(synth.Packet(int(s), fn(900 + i), nbits, 27 if i % 2 else -27, -25 if i % 2 else 25))
+        synth.plant(iq, pk, wl["chip"])
+        g = shard.CommGatherer(dec, cap_hits=1 << 16)
+        k0, k1 = shard.shard_range(n_blocks, world, rank)
+        p0, _ = shard.prime_range(k0, dec.prime_blocks())
+        if k0 > p0:
+            dec.prime(iq[p0 * bs2: k0 * bs2], iq[p0 * bs2 - dec.halo_bytes(): p0 * bs2] if p0 > 0 else None)
+        dec.set_block_base(k0)
+        dec.decode_batch(iq[k0 * bs2: k1 * bs2])
+        g.post()
+        got = g.result()
+        ok, detail = True, f"{n_blocks}-block stream over {world} rank(s): gathered hits == single decoder"
+        if rank == 0:
+            one = mk()
+            try:
+                br = one.decode_batch(iq)
+                want = shard.batch_hits_array(br, one.n_preambles)
+            finally:
+                one.close()
+            order = np.lexsort((got[:, 2], got[:, 1], got[:, 0]))
+            ok = len(want) > 0 and np.array_equal(got[order], want)
+            if not ok:
+                detail = f"MISMATCH: gathered {len(got)} hit records, single decoder {len(want)}"
+        flag = [ok]
+        dist.broadcast_object_list(flag, src=0)
+        return bool(flag[0]), detail
+    finally:
+        dec.close()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -220,7 +274,8 @@ def main():
         _lib.check(L.amr_dev_free(local_rank, d_h), "amr_dev_free")
 
     dev = torch.device("cuda", local_rank) if distributed else None
-    gatherer = shard.HitGatherer(dec.n_preambles, device=dev) if distributed else None
+    gatherer = None
+    gather_kind = "none (single GPU)"
 
     def sync_all():
         if distributed:
@@ -233,12 +288,15 @@ def main():
     state = {"gather_truncated": False}
 
     def finish():
-        """Collect the oldest batch: read back its hits and (N > 1) gather them over RCCL."""
+        """Collect the oldest batch: read back its hits and (N > 1) gather them on rank 0 over RCCL."""
         br = dec.collect(copy=False)
-        if distributed:   # records go device -> RCCL -> rank 0, asynchronously; the capacity is re-agreed when outgrown
-            d_ptr, _ = dec.result_device()
-            if not gatherer.post(br, d_ptr):
-                state["gather_truncated"] = True   # sent truncated; every rank keeps issuing the same collectives
+        if distributed:   # records go device -> RCCL -> rank 0, asynchronously, behind the kernels of the next batch
+            if isinstance(gatherer, shard.CommGatherer):
+                gatherer.post()                    # C ABI: amr_gather_hits, no host synchronisation
+            else:
+                d_ptr, _ = dec.result_device()
+                if not gatherer.post(br, d_ptr):
+                    state["gather_truncated"] = True   # sent truncated; every rank keeps issuing the same collectives
         return br
 
     def run(n, level, every=1):
@@ -263,9 +321,31 @@ def main():
     # (K1 + search); of the timed steps every --k1-events-th carries K1's start/stop pair, which the roofline figure
     # needs (measured: events on every step cost 2 % of the step, on every 4th 0.5 %; the K1 average is the same).
     dec.set_timing(2)
-    if distributed:   # one untimed batch tells every rank how many hit records a batch yields
+    check = {"hit_count": "skipped", "planted": "skipped"}
+    rc = 0
+    if distributed:
+        # one untimed batch tells every rank how many hit records a batch yields; the capacity of the gather is agreed once
         dec.submit_device(d_iq.value, n_blocks)
-        gatherer.negotiate(len(dec.collect(copy=False).hit_idx))
+        n_first = len(dec.collect(copy=False).hit_idx)
+        t = torch.tensor([n_first], dtype=torch.int64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        cap = max(1024, int(int(t.item()) * 1.5))
+        if os.environ.get("AMR_BENCH_GATHER", "cabi") == "cabi":
+            try:
+                # before anything is timed: a 256-block stream sharded over the ranks (HIP engine + amr_prime +
+                # the C-ABI gather) must give exactly what rank 0's single decoder gives for the whole stream
+                ok, detail = sharded_gather_check(ra, shard, wl, local_rank, rank, world)
+                check["sharded_gather"] = detail
+                rc = rc or (0 if ok else 5)
+                gatherer = shard.CommGatherer(dec, cap_hits=cap)
+                gather_kind = ("C ABI amr_gather_hits: RCCL send/recv of (block, idx) records to rank 0 on the library's own "
+                               "stream, one per step, no host synchronisation")
+            except Exception as e:       # e.g. librccl not loadable: keep the job alive on the torch.distributed path
+                check["sharded_gather"] = f"C-ABI gather unavailable ({e}); torch.distributed gather used instead"
+        if gatherer is None:
+            gatherer = shard.HitGatherer(dec.n_preambles, device=dev)
+            gatherer.negotiate(n_first)
+            gather_kind = "torch.distributed.gather (RCCL) of (block, idx) records to rank 0, one async collective per step"
 
     # ---- spin-up: untimed passes until the shader clock has ramped; they also give the steady-state step time ----
     spin_steps, steady_ms = 0, float("nan")
@@ -302,8 +382,13 @@ def main():
         dt = float(tt.item())
 
     # ---- what was timed is checked: golden hit count of this (workload, size, shard), planted messages on rank 0 ----
-    rc = 0
-    check = {"hit_count": "skipped", "planted": "skipped"}
+    if distributed and isinstance(gatherer, shard.CommGatherer) and rank == 0:
+        try:        # the last step's gather on the root: every rank's records arrived untruncated
+            got = gatherer.result()
+            check["gathered_last_step"] = f"{len(got)} records from {world} rank(s)"
+        except OverflowError as e:
+            state["gather_truncated"] = True
+            check["gathered_last_step"] = str(e)
     if not args.no_verify and not args.validate:
         key = f"{wl['name']}|blocks={n_blocks}|shard={shard_idx}"
         try:
@@ -361,8 +446,7 @@ def main():
                        "spin_up": f"{spin_steps} untimed steps (~{args.spinup_ms:.0f} ms) before the warm-up: shader clock ramp",
                        "checks": check,
                        "iq_buffer": "first device allocation", "parallelism": f"block-range shards x{world}",
-                       "hit_gather": ("RCCL gather of (block, idx) records to rank 0, one async collective per step"
-                                      if distributed else "none (single GPU)"),
+                       "hit_gather": gather_kind,
                        "hit_gather_truncated": state["gather_truncated"]},
             "roofline": {"bound": "hbm", "kernel": k1_name, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,

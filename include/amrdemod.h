@@ -275,6 +275,34 @@ amr_status amr_synth_plant(int32_t device_id, void *d_iq, uint64_t n_samples, ui
                            const uint8_t *bits, uint32_t n_bits, uint32_t stride,
                            const int8_t *d_i, const int8_t *d_q);
 
+/* ---- multi-GPU: gather of the hit records on one rank -------------------------------------------------
+ * One process per GPU, each decoding a contiguous range of whole blocks (amr_prime rebuilds the history the reference
+ * Decoder would carry into the range, decode.go:165-166; amr_set_block_base makes the call indices global).  No
+ * data-path collective exists; the only exchange is this gather of (call index, idx) records, through RCCL
+ * point-to-point calls on a stream of its own, enqueued without any host synchronisation and overlapping the next
+ * batches.  RCCL is bound with dlopen at amr_comm_init: a host that does not call these needs no librccl.
+ * A cgo host: rank 0 calls amr_comm_unique_id and hands the 128 bytes to the other processes (any transport), every
+ * rank calls amr_comm_init, then after each amr_collect one amr_gather_hits. */
+#define AMR_COMM_ID_BYTES 128
+typedef struct amr_gathered {
+    uint64_t n_true;                  /* hits the source rank had */
+    uint64_t n_hits;                  /* records received = min(n_true, capacity); n_true > n_hits: raise the capacity */
+    uint32_t n_preambles;
+    const uint64_t *preamble_offset;  /* [n_preambles+1] into the source rank's (untruncated) hit arrays */
+    const uint64_t *hit_block;        /* [n_hits] global call indices */
+    const uint32_t *hit_idx;          /* [n_hits] */
+} amr_gathered;
+amr_status amr_comm_unique_id(void *id128);   /* ncclGetUniqueId */
+amr_status amr_comm_init(amr_handle *h, const void *id128, int32_t rank, int32_t world, int32_t root, uint64_t cap_hits);
+amr_status amr_comm_destroy(amr_handle *h);
+/* Enqueue the gather of the batch amr_collect returned last (with amr_set_validation: of its surviving hits).
+ * Collective: every rank calls it once per batch, in the same order.  Returns at once. */
+amr_status amr_gather_hits(amr_handle *h);
+amr_status amr_gather_wait(amr_handle *h);    /* block until every gather enqueued so far has completed */
+/* Root only: the records rank src_rank contributed to the last gather, copied to host memory owned by the handle
+ * (valid until the next amr_gather_fetch). */
+amr_status amr_gather_fetch(amr_handle *h, int32_t src_rank, amr_gathered *out);
+
 #ifdef __cplusplus
 }
 #endif

@@ -19,6 +19,7 @@ SYMBOLS = [
     "amr_halo_bytes", "amr_prime_blocks", "amr_copy_quantized", "amr_set_timing", "amr_get_timing", "amr_strerror",
     "amr_last_error", "amr_describe", "amr_dev_alloc", "amr_dev_free", "amr_dev_upload", "amr_dev_download",
     "amr_dev_sync", "amr_synth_noise", "amr_synth_plant",
+    "amr_comm_unique_id", "amr_comm_init", "amr_comm_destroy", "amr_gather_hits", "amr_gather_wait", "amr_gather_fetch",
 ]
 
 
@@ -57,13 +58,20 @@ class AmrValidator(C.Structure):
     _fields_ = [("n_checks", C.c_int32), ("dedupe_bytes", C.c_int32), ("checks", AmrCrcCheck * 2)]
 
 
+class AmrGathered(C.Structure):
+    _fields_ = [("n_true", C.c_uint64), ("n_hits", C.c_uint64), ("n_preambles", C.c_uint32),
+                ("preamble_offset", C.POINTER(C.c_uint64)), ("hit_block", C.POINTER(C.c_uint64)),
+                ("hit_idx", C.POINTER(C.c_uint32))]
+
+
 class AmrTiming(C.Structure):
     _fields_ = [("demod_ms", C.c_float), ("search_ms", C.c_float), ("total_ms", C.c_float)]
 
 
 def build(force: bool = False) -> str:
     """Compile libamrdemod.so in-tree with hipcc for gfx950 (cross-compiles without a GPU)."""
-    srcs = [os.path.join(CSRC, f) for f in ("amrdemod.hip", "k1_demod.h", "k2_search.h", "k4_r900.h", "k5_validate.h", "synth.h")]
+    srcs = [os.path.join(CSRC, f) for f in ("amrdemod.hip", "k1_demod.h", "k1_tile.h", "k2_search.h", "k2_stream.h", "k4_r900.h",
+                                            "k5_validate.h", "synth.h")]
     srcs.append(os.path.join(_HERE, "..", "include", "amrdemod.h"))
     stale = (not os.path.exists(SO_PATH)) or any(os.path.getmtime(s) > os.path.getmtime(SO_PATH) for s in srcs)
     if force or stale:
@@ -126,6 +134,12 @@ def lib() -> C.CDLL:
     L.amr_synth_noise.argtypes = [C.c_int32, vp, C.c_uint64, C.c_uint64, C.c_uint64]
     L.amr_synth_plant.argtypes = [C.c_int32, vp, C.c_uint64, C.c_uint64, C.c_int32, C.c_uint32, vp, vp,
                                   C.c_uint32, C.c_uint32, vp, vp]
+    L.amr_comm_unique_id.argtypes = [vp]
+    L.amr_comm_init.argtypes = [vp, vp, C.c_int32, C.c_int32, C.c_int32, C.c_uint64]
+    L.amr_comm_destroy.argtypes = [vp]
+    L.amr_gather_hits.argtypes = [vp]
+    L.amr_gather_wait.argtypes = [vp]
+    L.amr_gather_fetch.argtypes = [vp, C.c_int32, C.POINTER(AmrGathered)]
     for name in SYMBOLS:
         fn = getattr(L, name)
         if name not in ("amr_preamble_id", "amr_halo_bytes", "amr_prime_blocks", "amr_strerror", "amr_last_error"):

@@ -8,6 +8,7 @@
 #include <hip/hip_runtime.h>
 #include <hip/hip_ext.h>
 
+#include <dlfcn.h>
 #include <sched.h>
 
 #include <algorithm>
@@ -115,6 +116,8 @@ struct Slot {
     int iqhist_buf = 0;           // which history buffer it reads
 };
 
+struct Comm;
+
 struct amr_handle {
     int device = 0;
     amr_geometry geom{};
@@ -139,6 +142,8 @@ struct amr_handle {
     int dense_hold = 0;          // batches left in which the dense kernel is used straight away
     uint8_t *d_iq = nullptr;      size_t iq_cap = 0;       // staging for host input
     uint32_t *d_untile = nullptr; size_t untile_words = 0;
+
+    struct Comm *comm = nullptr;   // multi-GPU hit gather (amr_comm_init), see the section at the end of this file
 
     Slot slot[2];
     int next_slot = 0;           // slot the next submit uses
@@ -853,6 +858,7 @@ amr_status amr_destroy(amr_handle *h)
         if (sl.h_done) (void)hipHostFree(sl.h_done);
         for (hipEvent_t ev : evs) if (ev) (void)hipEventDestroy(ev);
     }
+    if (h->comm) (void)amr_comm_destroy(h);
     if (h->own_stream) (void)hipStreamDestroy(h->own_stream);
     if (h->copy_stream) (void)hipStreamDestroy(h->copy_stream);
     if (h->h2d_stream) (void)hipStreamDestroy(h->h2d_stream);
@@ -1191,3 +1197,195 @@ amr_status amr_synth_plant(int32_t device_id, void *d_iq, uint64_t n_samples, ui
 }
 
 }  // extern "C"
+
+
+// =====================================================================================================================
+// Multi-GPU: gather of the hit records on one rank.  One process per GPU; independent shards of whole
+// blocks need no data-path collective, the only exchange is this gather.  It runs on its own stream through RCCL
+// point-to-point calls (every peer sends its few MB to the root over its own xGMI link; no ring), is enqueued from the
+// host without any synchronisation -- amr_collect has already seen the batch complete, its packed result stays valid
+// until the slot is submitted again, two batches later -- and overlaps the kernels of the following batches.
+// RCCL is bound at run time (dlopen): libamrdemod.so has no link-time dependency on it, and a process that already
+// carries a copy (PyTorch ships one) keeps using that one.
+// =====================================================================================================================
+namespace {
+
+struct Id128 { char b[128]; };   // ncclUniqueId (rccl.h: char internal[128]), passed by value
+
+struct Rccl {
+    void *so = nullptr;
+    int (*GetUniqueId)(void *) = nullptr;
+    int (*CommInitRank)(void **, int, Id128, int) = nullptr;
+    int (*CommDestroy)(void *) = nullptr;
+    int (*GroupStart)() = nullptr;
+    int (*GroupEnd)() = nullptr;
+    int (*Send)(const void *, size_t, int, int, void *, hipStream_t) = nullptr;
+    int (*Recv)(void *, size_t, int, int, void *, hipStream_t) = nullptr;
+    const char *(*GetErrorString)(int) = nullptr;
+};
+
+Rccl *rccl()
+{
+    static Rccl r;
+    static bool tried = false;
+    if (tried) return r.so ? &r : nullptr;
+    tried = true;
+    // a copy already in the process first (torch's librccl.so), then the ROCm one
+    const char *names[] = {"librccl.so", "librccl.so.1"};
+    for (const char *n : names) if (!r.so) r.so = dlopen(n, RTLD_NOW | RTLD_NOLOAD | RTLD_GLOBAL);
+    for (const char *n : names) if (!r.so) r.so = dlopen(n, RTLD_NOW | RTLD_GLOBAL);
+    if (!r.so) r.so = dlopen("/opt/rocm/lib/librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
+    if (!r.so) return nullptr;
+#define AMR_SYM(field, name) *(void **)(&r.field) = dlsym(r.so, name)
+    AMR_SYM(GetUniqueId, "ncclGetUniqueId"); AMR_SYM(CommInitRank, "ncclCommInitRank"); AMR_SYM(CommDestroy, "ncclCommDestroy");
+    AMR_SYM(GroupStart, "ncclGroupStart"); AMR_SYM(GroupEnd, "ncclGroupEnd"); AMR_SYM(Send, "ncclSend"); AMR_SYM(Recv, "ncclRecv");
+    AMR_SYM(GetErrorString, "ncclGetErrorString");
+#undef AMR_SYM
+    if (!r.GetUniqueId || !r.CommInitRank || !r.CommDestroy || !r.GroupStart || !r.GroupEnd || !r.Send || !r.Recv) { r.so = nullptr; return nullptr; }
+    return &r;
+}
+
+constexpr int kNcclUint8 = 1;              // ncclDataType_t: ncclInt8 0, ncclUint8 1 (rccl.h)
+constexpr uint32_t kGatherHdr = 16;        // u64 words in front of the records: [n_true, n_sent, n_pre, offs[0..n_pre]]
+
+amr_status nccl_fail(const char *what, int rc)
+{
+    Rccl *r = rccl();
+    char buf[256];
+    snprintf(buf, sizeof buf, "%s: %s", what, (r && r->GetErrorString) ? r->GetErrorString(rc) : "RCCL error");
+    return fail(AMR_EHIP, buf);
+}
+#define NCCL_TRY(expr) do { int rc_ = (expr); if (rc_ != 0) return nccl_fail(#expr, rc_); } while (0)
+
+// header + the first min(n, cap) (block, idx) records of a packed result -> one contiguous send buffer
+__global__ void k_gather_pack(const uint8_t *packed, const uint64_t *offs, uint32_t n_pre, uint64_t cap, uint64_t *send)
+{
+    const uint64_t n = offs[n_pre], m = n < cap ? n : cap;
+    const uint64_t *blk = reinterpret_cast<const uint64_t *>(packed);
+    const uint32_t *idx = reinterpret_cast<const uint32_t *>(packed + n * 8);
+    uint64_t *rb = send + kGatherHdr;
+    uint32_t *ri = reinterpret_cast<uint32_t *>(rb + m);
+    const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x, stride = (uint64_t)gridDim.x * blockDim.x;
+    if (t == 0) { send[0] = n; send[1] = m; send[2] = n_pre; }
+    if (t <= n_pre) send[3 + t] = offs[t];
+    for (uint64_t i = t; i < m; i += stride) { rb[i] = blk[i]; ri[i] = idx[i]; }
+}
+
+}  // namespace
+
+struct Comm {
+    void *comm = nullptr;
+    int rank = 0, world = 1, root = 0;
+    uint64_t cap = 0;            // records a slot holds
+    size_t slot_bytes = 0;
+    hipStream_t stream = nullptr;
+    uint8_t *d_send[2] = {nullptr, nullptr};
+    uint8_t *d_recv[2] = {nullptr, nullptr};   // root: world slots each
+    int next = 0, last = -1;
+    std::vector<uint8_t> host;   // amr_gather_fetch staging
+};
+
+amr_status amr_comm_unique_id(void *id128)
+{
+    if (!id128) return fail(AMR_EINVAL, "null argument");
+    Rccl *r = rccl();
+    if (!r) return fail(AMR_ENODEV, "RCCL (librccl.so) not found");
+    NCCL_TRY(r->GetUniqueId(id128));
+    return AMR_OK;
+}
+
+amr_status amr_comm_init(amr_handle *h, const void *id128, int32_t rank, int32_t world, int32_t root, uint64_t cap_hits)
+{
+    if (!h || !id128) return fail(AMR_EINVAL, "null argument");
+    if (world < 1 || rank < 0 || rank >= world || root < 0 || root >= world || cap_hits == 0) return fail(AMR_EINVAL, "amr_comm_init: bad rank / world / capacity");
+    if (h->comm) return fail(AMR_EINVAL, "amr_comm_init: communicator exists already");
+    Rccl *r = rccl();
+    if (!r) return fail(AMR_ENODEV, "RCCL (librccl.so) not found");
+    HIP_TRY(hipSetDevice(h->device));
+    Comm *c = new (std::nothrow) Comm();
+    if (!c) return fail(AMR_ENOMEM, "Comm");
+    c->rank = rank; c->world = world; c->root = root; c->cap = cap_hits;
+    c->slot_bytes = ((size_t)kGatherHdr * 8 + (size_t)cap_hits * 12 + 255) & ~(size_t)255;
+    Id128 id;
+    memcpy(id.b, id128, 128);
+    int rc = r->CommInitRank(&c->comm, world, id, rank);
+    if (rc != 0) { delete c; return nccl_fail("ncclCommInitRank", rc); }
+    hipError_t e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
+    for (int k = 0; k < 2 && e == hipSuccess; ++k) {
+        e = hipMalloc((void **)&c->d_send[k], c->slot_bytes);
+        if (e == hipSuccess && rank == root) e = hipMalloc((void **)&c->d_recv[k], c->slot_bytes * (size_t)world);
+    }
+    h->comm = c;
+    if (e != hipSuccess) { (void)amr_comm_destroy(h); return fail(AMR_ENOMEM, "amr_comm_init: buffers", e); }
+    return AMR_OK;
+}
+
+amr_status amr_comm_destroy(amr_handle *h)
+{
+    if (!h || !h->comm) return AMR_OK;
+    Comm *c = h->comm;
+    (void)hipSetDevice(h->device);
+    if (c->stream) (void)hipStreamSynchronize(c->stream);
+    Rccl *r = rccl();
+    if (r && c->comm) (void)r->CommDestroy(c->comm);
+    for (int k = 0; k < 2; ++k) { if (c->d_send[k]) (void)hipFree(c->d_send[k]); if (c->d_recv[k]) (void)hipFree(c->d_recv[k]); }
+    if (c->stream) (void)hipStreamDestroy(c->stream);
+    delete c;
+    h->comm = nullptr;
+    return AMR_OK;
+}
+
+amr_status amr_gather_hits(amr_handle *h)
+{
+    if (!h || !h->comm) return fail(AMR_EINVAL, "amr_gather_hits: amr_comm_init first");
+    if (h->last_slot < 0) return fail(AMR_EINVAL, "amr_gather_hits: no batch collected yet");
+    Rccl *r = rccl();
+    Comm *c = h->comm;
+    HIP_TRY(hipSetDevice(h->device));
+    const Slot &s = h->slot[h->last_slot];
+    const uint8_t *packed = h->validate ? s.d_val : s.d_out;
+    const uint64_t *offs = h->validate ? s.d_offs_val : s.d_offs_pre;
+    const int k = c->next;
+    // everything below is ordered by the communicator's stream: the pack kernel of this gather runs behind the
+    // collective that last used buffer set k
+    hipLaunchKernelGGL(k_gather_pack, dim3(64), dim3(256), 0, c->stream, packed, offs, h->sg.n_pre, c->cap,
+                       reinterpret_cast<uint64_t *>(c->d_send[k]));
+    HIP_TRY(hipGetLastError());
+    NCCL_TRY(r->GroupStart());
+    NCCL_TRY(r->Send(c->d_send[k], c->slot_bytes, kNcclUint8, c->root, c->comm, c->stream));
+    if (c->rank == c->root)
+        for (int p = 0; p < c->world; ++p)
+            NCCL_TRY(r->Recv(c->d_recv[k] + (size_t)p * c->slot_bytes, c->slot_bytes, kNcclUint8, p, c->comm, c->stream));
+    NCCL_TRY(r->GroupEnd());
+    c->last = k;
+    c->next ^= 1;
+    return AMR_OK;
+}
+
+amr_status amr_gather_wait(amr_handle *h)
+{
+    if (!h || !h->comm) return fail(AMR_EINVAL, "amr_gather_wait: amr_comm_init first");
+    HIP_TRY(hipSetDevice(h->device));
+    HIP_TRY(hipStreamSynchronize(h->comm->stream));
+    return AMR_OK;
+}
+
+amr_status amr_gather_fetch(amr_handle *h, int32_t src_rank, amr_gathered *out)
+{
+    if (!h || !h->comm || !out) return fail(AMR_EINVAL, "amr_gather_fetch: null argument / no communicator");
+    Comm *c = h->comm;
+    if (c->rank != c->root) return fail(AMR_EINVAL, "amr_gather_fetch: only the root holds the gathered records");
+    if (c->last < 0 || src_rank < 0 || src_rank >= c->world) return fail(AMR_EINVAL, "amr_gather_fetch: nothing gathered / bad rank");
+    HIP_TRY(hipSetDevice(h->device));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    c->host.resize(c->slot_bytes);
+    HIP_TRY(hipMemcpy(c->host.data(), c->d_recv[c->last] + (size_t)src_rank * c->slot_bytes, c->slot_bytes, hipMemcpyDeviceToHost));
+    const uint64_t *hdr = reinterpret_cast<const uint64_t *>(c->host.data());
+    out->n_true = hdr[0];
+    out->n_hits = hdr[1];
+    out->n_preambles = (uint32_t)hdr[2];
+    out->preamble_offset = hdr + 3;
+    out->hit_block = hdr + kGatherHdr;
+    out->hit_idx = reinterpret_cast<const uint32_t *>(hdr + kGatherHdr + hdr[1]);
+    return AMR_OK;
+}

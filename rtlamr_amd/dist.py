@@ -77,7 +77,10 @@ class _DevBuf:
 
 
 class HitGatherer:
-    """Gather of the per-rank hit records (call index u64, idx u32) on rank 0, once per batch, without a host
+    """(Fallback path; the production gather is CommGatherer below, behind the C ABI and without the host-side stream
+    synchronisation this one needs to protect the library's result slot.)
+
+    Gather of the per-rank hit records (call index u64, idx u32) on rank 0, once per batch, without a host
     round trip: the records are copied device-to-device out of the library's packed result buffer into a
     fixed-capacity send buffer and gathered with ONE collective (torch.distributed.gather, backend "nccl" =
     RCCL: on the fully connected xGMI fabric every peer sends its few MB to rank 0 over its own link).  The
@@ -179,4 +182,53 @@ class HitGatherer:
             for q in range(n_pre):
                 pid[offs[q]:offs[q + 1]] = q
             rows.append(np.stack([pid, blk, idx], axis=1))
+        return np.concatenate(rows) if rows else np.zeros((0, 3), np.int64)
+
+
+def comm_unique_id() -> bytes:
+    """ncclGetUniqueId through the library (rank 0 calls it and hands the 128 bytes to the other ranks)."""
+    import ctypes as C
+    from . import _lib
+    buf = C.create_string_buffer(128)
+    _lib.check(_lib.lib().amr_comm_unique_id(buf), "amr_comm_unique_id")
+    return buf.raw
+
+
+class CommGatherer:
+    """The hit gather of the C ABI (amr_comm_init / amr_gather_hits: RCCL point-to-point on a stream of the
+    library's own, no host synchronisation), for hosts that are Python.  The unique id travels over whatever the
+    caller has -- here torch.distributed (any backend), because bench.py and the tests have it anyway; a cgo host
+    would use its own transport."""
+
+    def __init__(self, dec, cap_hits: int, root: int = 0, group=None):
+        import torch
+        import torch.distributed as dist
+        self.dec, self.root = dec, root
+        self.world, self.rank = dist.get_world_size(group), dist.get_rank(group)
+        box = [comm_unique_id() if self.rank == root else None]
+        dist.broadcast_object_list(box, src=root, group=group)
+        dec.comm_init(box[0], self.rank, self.world, root, cap_hits)
+        self.cap = cap_hits
+
+    def post(self) -> None:
+        self.dec.gather_hits()
+
+    def wait(self) -> None:
+        self.dec.gather_wait()
+
+    def result(self):
+        """Root: int64[n,3] rows (pid, block, idx) of the last gather, all ranks in rank order."""
+        import numpy as np
+        self.wait()
+        if self.rank != self.root:
+            return np.zeros((0, 3), np.int64)
+        rows = []
+        for r in range(self.world):
+            n_true, off, blk, idx = self.dec.gather_fetch(r)
+            if n_true > len(blk):
+                raise OverflowError(f"rank {r} had {n_true} hit records, the gather capacity is {self.cap}")
+            pid = np.zeros(len(blk), np.int64)
+            for q in range(len(off) - 1):
+                pid[int(off[q]):int(off[q + 1])] = q
+            rows.append(np.stack([pid, blk.astype(np.int64), idx.astype(np.int64)], axis=1))
         return np.concatenate(rows) if rows else np.zeros((0, 3), np.int64)

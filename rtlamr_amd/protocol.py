@@ -217,6 +217,28 @@ class Decoder:
             done.append(pre)
         return done
 
+    # ---- multi-GPU hit gather behind the C ABI (include/amrdemod.h, "multi-GPU" section) ----
+    def comm_init(self, unique_id: bytes, rank: int, world: int, root: int = 0, cap_hits: int = 1 << 20) -> None:
+        buf = C.create_string_buffer(bytes(unique_id), 128)
+        _lib.check(_lib.lib().amr_comm_init(self._require(), buf, rank, world, root, cap_hits), "amr_comm_init")
+
+    def gather_hits(self) -> None:
+        """Enqueue the gather of the batch collected last (every rank, once per batch); returns at once."""
+        _lib.check(_lib.lib().amr_gather_hits(self._require()), "amr_gather_hits")
+
+    def gather_wait(self) -> None:
+        _lib.check(_lib.lib().amr_gather_wait(self._require()), "amr_gather_wait")
+
+    def gather_fetch(self, src_rank: int):
+        """Root: (n_true, preamble_offset[n_pre+1], hit_block u64[n], hit_idx u32[n]) rank src_rank sent last."""
+        g = _lib.AmrGathered()
+        _lib.check(_lib.lib().amr_gather_fetch(self._require(), src_rank, C.byref(g)), "amr_gather_fetch")
+        n, n_pre = int(g.n_hits), int(g.n_preambles)
+        off = np.ctypeslib.as_array(g.preamble_offset, shape=(n_pre + 1,)).copy()
+        blk = np.ctypeslib.as_array(g.hit_block, shape=(n,)).copy() if n else np.zeros(0, np.uint64)
+        idx = np.ctypeslib.as_array(g.hit_idx, shape=(n,)).copy() if n else np.zeros(0, np.uint32)
+        return int(g.n_true), off, blk, idx
+
     def close(self) -> None:
         if self._handle is not None:
             _lib.lib().amr_destroy(self._handle)

@@ -29,7 +29,8 @@ def test_struct_layouts_match_header(tmp_path):
     """sizeof / offsetof as a C compiler sees include/amrdemod.h == the ctypes mirrors in rtlamr_amd/_lib.py."""
     import subprocess
     structs = {"amr_geometry": _lib.AmrGeometry, "amr_protocol": _lib.AmrProtocol, "amr_timing": _lib.AmrTiming,
-               "amr_result": _lib.AmrResult, "amr_crc_check": _lib.AmrCrcCheck, "amr_validator": _lib.AmrValidator}
+               "amr_result": _lib.AmrResult, "amr_crc_check": _lib.AmrCrcCheck, "amr_validator": _lib.AmrValidator,
+               "amr_gathered": _lib.AmrGathered}
     lines = ['#include <stdio.h>', '#include <stddef.h>', '#include "amrdemod.h"', 'int main(void){']
     for cname, ct in structs.items():
         lines.append(f'printf("{cname} %zu\\n", sizeof({cname}));')
