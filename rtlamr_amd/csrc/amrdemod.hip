@@ -422,7 +422,7 @@ amr_status enqueue_search(amr_handle *h, Slot &s, bool rerun = false, bool dense
         k4.preamble_length = (uint32_t)h->geom.preamble_length; k4.symbol_length = (uint32_t)h->geom.symbol_length;
         k4.chip_length = (uint32_t)h->geom.chip_length;
         // the hit count is only known on the device: one 64-lane block per 64 possible hits, the surplus exits at once
-        hipLaunchKernelGGL(amr::k4_r900_digits, dim3((unsigned)((s.out_cap + 63) / 64)), dim3(64), 0, st, k4);
+        hipLaunchKernelGGL(amr::k4_r900_digits, dim3((unsigned)((s.out_cap + 63) / 64), amr::kK4Split), dim3(64), 0, st, k4);
         HIP_TRY(hipGetLastError());
         AMR_DBG(st, "k4_r900_digits");
     }

@@ -4,9 +4,9 @@
 // magnitudes (r900.go:168-170), recomputes a sequential float32 running sum over all of it (r900.go:96-100),
 // quantizes every position into one of six symbols (r900.go:119-149) and then reads 42 of those symbols per
 // preamble hit, 4 chips apart (r900.go:187-193).  Only those 42 values per hit are observable, so this kernel
-// computes exactly them: one lane = one r900 preamble hit; the lane replays the call's running sum from the
-// start of the parser's buffer -- same order, same float32 roundings -- samples it at the 169 chip boundaries
-// its 42 symbols span, and applies the reference's a0/a1/a2 arithmetic operation for operation.
+// computes exactly them: one lane = one r900 preamble hit; the call's running sum is replayed from the start of
+// the parser's buffer -- same order, same float32 roundings, once per wave and call -- the lane samples it at the
+// 169 chip boundaries its 42 symbols span, and applies the reference's a0/a1/a2 arithmetic operation for operation.
 //
 // The parser's buffer at call k holds the samples [k*BS - PL, k*BS + BS) of the stream (zero magnitude before
 // the stream starts, r900.go:163-165 allocates zeros); samples before the current batch come from `hist`, the
@@ -19,6 +19,7 @@
 namespace amr {
 
 constexpr int kR900Digits = 42;   // PayloadSymbols, r900.go:30
+constexpr uint32_t kK4Split = 4;   // waves per 64-hit chunk, one distinct Decode call each
 
 struct K4Args {
     const uint8_t *iq;        // batch block 0 (device)
@@ -35,6 +36,27 @@ struct K4Args {
     uint32_t block_size, lg_block_size, packet_length, preamble_length, symbol_length, chip_length;
 };
 
+// One wave = 64 consecutive r900 hits (sorted by call, idx).  All hits of one Decode call need the SAME running sum
+// (r900.go:96-100 restarts it at the start of the parser's buffer on every call), so the wave computes it once per
+// distinct call among its hits, cooperatively: 64 lanes load 64 consecutive samples (one coalesced 128-byte read), take
+// their magnitudes from the LUT in parallel, and a 64-step chain of v_add_f32 with the DPP wave shift -- lane i adds its
+// magnitude to the sum of lane i-1 -- reproduces the reference's sequential float32 additions exactly, one instruction
+// per sample.  A hit's lane then picks the sums at its chip boundaries out of the tile with ds_bpermute (lane index =
+// csum index - tile start - 1) and applies a0/a1/a2 every fourth boundary.  (The first version replayed the sum in
+// every lane, ~15 instructions per sample and lane: 1.5 ms per GiB at 36 k hits.)
+__device__ __forceinline__ float k4_chain(float carry, float mag)
+{
+    // p(lane) = csum after this lane's sample.  Lane 0 first (carry + m0, computed by every lane, right in lane 0);
+    // then 63 steps "p = p(lane-1) + m": lane i is final after step i, later steps recompute the same value; lane 0 has
+    // no lane below it and is left alone by the shift (bound_ctrl 0).  s_nop 1: VALU write -> DPP read of the same VGPR.
+    float p;
+    asm volatile("v_add_f32 %0, %1, %2" : "=v"(p) : "v"(carry), "v"(mag));
+#pragma unroll
+    for (int i = 0; i < 63; ++i)
+        asm volatile("s_nop 1\n\tv_add_f32_dpp %0, %0, %1 wave_shr:1 row_mask:0xf bank_mask:0xf" : "+v"(p) : "v"(mag));
+    return p;
+}
+
 __global__ __launch_bounds__(64) void k4_r900_digits(const K4Args a)
 {
     __shared__ float lut[256];
@@ -48,26 +70,21 @@ __global__ __launch_bounds__(64) void k4_r900_digits(const K4Args a)
     const uint64_t lo = a.offs_pre[a.pid], n = a.offs_pre[a.pid + 1] - lo;
     const uint64_t gid = (uint64_t)blockIdx.x * 64 + threadIdx.x;
     const bool active = gid < n;
-    const uint64_t slot = lo + (active ? gid : 0);
     if ((uint64_t)blockIdx.x * 64 >= n) return;
+    const uint32_t lane = threadIdx.x;
+    const uint64_t slot = lo + (active ? gid : 0);
     const uint64_t *hit_block = reinterpret_cast<const uint64_t *>(a.out_packed);
     const uint32_t *hit_idx = reinterpret_cast<const uint32_t *>(a.out_packed + total * 8);
-    const int64_t k = (int64_t)(hit_block[slot] - a.block_base);          // call index inside the batch
+    const int64_t k = active ? (int64_t)(hit_block[slot] - a.block_base) : -1;   // call index inside the batch
     const uint32_t idx = hit_idx[slot];
     const uint32_t CL = a.chip_length, PL = a.packet_length;
     const uint32_t payload = idx + a.preamble_length - a.symbol_length;   // r900.go:183
-    const uint32_t last = active ? payload + 168 * CL : 0;                 // csum index of the last chip boundary
-    // sample j of the parser's buffer = batch sample k*BS - PL + j; nothing exists before the stream start
-    const int64_t n0 = (k << a.lg_block_size) - (int64_t)PL;              // batch-relative sample of buffer index 0
-    int64_t first_real = -(int64_t)a.hist_valid - n0;                     // first buffer index with a real sample
-    const uint32_t j0 = first_real < 0 ? 0u : (uint32_t)first_real;
+    const uint32_t last = payload + 168 * CL;                              // csum index of the last chip boundary
+    uint8_t *dg = a.digits + gid * kR900Digits;
 
     float c[5] = {0.f, 0.f, 0.f, 0.f, 0.f};   // running-sum samples at the last five chip boundaries
     uint32_t m = 0;                            // boundaries recorded so far (boundary m sits at csum index payload + m*CL)
     uint32_t next_pt = payload;
-    uint8_t *dg = a.digits + gid * kR900Digits;
-    float sum = 0.f;
-
     auto record = [&](float v) {
         c[0] = c[1]; c[1] = c[2]; c[2] = c[3]; c[3] = c[4]; c[4] = v;
         if (m >= 4 && (m & 3) == 0) {          // boundaries m-4..m = one symbol: r900.go:119-148, operation for operation
@@ -84,61 +101,69 @@ __global__ __launch_bounds__(64) void k4_r900_digits(const K4Args a)
             if (fabsf(a1) > max_abs) { max_abs = fabsf(a1); arg = 1; val = a1; }
             if (fabsf(a2) > max_abs) { max_abs = fabsf(a2); arg = 2; val = a2; }
             if (val > 0.f) arg += 3;
-            if (active) dg[(m >> 2) - 1] = (uint8_t)arg;
+            dg[(m >> 2) - 1] = (uint8_t)arg;
         }
         m += 1;
         next_pt += CL;
     };
-    // chip boundaries that lie in the all-zero prefix (before the stream start): the running sum is still 0 there
-    while (active && m <= 168 && next_pt <= j0) record(0.f);
 
-    // walk the buffer 8 samples (16 bytes, never straddling the batch start: PL and BS are multiples of 16) at a time
-    uint32_t wave_last = last;
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-        const uint32_t o = __shfl_xor(wave_last, d);
-        wave_last = o > wave_last ? o : wave_last;
-    }
-    // The walk.  Chip boundaries are CL samples apart, so in ANY window of CL consecutive samples a lane meets exactly
-    // one of its own; the lanes of a wave meet theirs at different samples (adjacent hits), which would run the
-    // record() body -- under a one-lane mask -- for almost every sample.  Instead a boundary is only CAPTURED when it
-    // passes (two predicated moves) and all lanes record together once per CL samples.  32 samples per round, the four
-    // 16-byte loads issued together.
-    const uint32_t chunks_per_epoch = CL >> 3;       // every legal chip length is a multiple of 8
-    uint32_t cc = 0;
-    float cap = 0.f;
-    bool pending = false;
-    for (uint32_t j32 = j0 & ~31u; j32 < wave_last; j32 += 32) {
-        uint4 w[4];
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const int64_t nb = n0 + j32 + 8 * q;     // batch-relative sample of the chunk; chunks past `last` are not used
-            const bool need = active && j32 + 8 * q < last && j32 + 8 * q + 8 > j0;
-            w[q] = !need ? make_uint4(0, 0, 0, 0)
-                 : nb >= 0 ? *reinterpret_cast<const uint4 *>(a.iq + 2 * nb)
-                           : *reinterpret_cast<const uint4 *>(a.hist + 2 * ((int64_t)PL + nb));
+    // A walk costs ~0.3 ms of latency whatever the number of hits that share it (tools/chain_bench.hip: 1050 cycles per
+    // 64 samples for the chain), so the distinct calls of a 64-hit chunk are spread over the kK4Split waves launched
+    // for it (blockIdx.y): wave r takes the r-th distinct call, the last one also whatever remains.
+    uint64_t todo = __ballot(active);
+    for (uint32_t round = 0; todo; ++round) {
+        const int lead = __ffsll((unsigned long long)todo) - 1;
+        const uint32_t k_lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)k, lead);
+        const uint32_t k_hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)((uint64_t)k >> 32), lead);
+        const int64_t kc = (int64_t)(((uint64_t)k_hi << 32) | k_lo);
+        const bool mine = active && k == kc;
+        if (round != blockIdx.y && !(blockIdx.y == kK4Split - 1 && round >= kK4Split)) {   // another wave's call
+            todo &= ~__ballot(mine);
+            continue;
         }
+        // sample j of the parser's buffer = batch sample kc*BS - PL + j; nothing exists before the stream start
+        const int64_t n0 = (kc << a.lg_block_size) - (int64_t)PL;
+        const int64_t first_real = -(int64_t)a.hist_valid - n0;           // first buffer index with a real sample
+        const uint32_t j0 = first_real < 0 ? 0u : (uint32_t)first_real;
+        // chip boundaries that lie in the all-zero prefix (before the stream start): the running sum is still 0 there
+        while (mine && m <= 168 && next_pt <= j0) record(0.f);
+        uint32_t wave_last = mine ? last : 0u;
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const uint32_t dw[4] = {w[q].x, w[q].y, w[q].z, w[q].w};
-#pragma unroll
-            for (int s = 0; s < 8; ++s) {
-                const uint32_t j = j32 + 8 * q + s;
-                const uint32_t v = dw[s >> 1] >> ((s & 1) * 16);
-                const float mag = lut[v & 0xff] + lut[(v >> 8) & 0xff];       // decode.go:222
-                const bool in = j >= j0 && j < last;
-                sum = in ? sum + mag : sum;                                   // r900.go:97-99
-                const bool at = in && j + 1 == next_pt;
-                cap = at ? sum : cap;
-                pending = pending || at;
-            }
-            if (++cc == chunks_per_epoch) {          // wave-uniform
-                cc = 0;
-                if (pending) { record(cap); pending = false; }
+        for (int d = 1; d < 64; d <<= 1) {
+            const uint32_t o = __shfl_xor(wave_last, d);
+            wave_last = o > wave_last ? o : wave_last;
+        }
+        float carry = 0.f;
+        // the samples of a tile: one 16-bit load per lane (128 contiguous bytes per wave), issued two tiles ahead of
+        // their chain so that the memory latency hides behind two chains
+        auto fetch = [&](uint32_t tile) -> uint32_t {
+            const uint32_t j = tile + lane;
+            const int64_t nb = n0 + j;
+            if (j >= j0 && j < wave_last)
+                return nb >= 0 ? *reinterpret_cast<const uint16_t *>(a.iq + 2 * nb)
+                               : *reinterpret_cast<const uint16_t *>(a.hist + 2 * ((int64_t)PL + nb));
+            return 0xffffffffu;                        // no sample here (before the stream start / past the last boundary)
+        };
+        const uint32_t t0 = j0 & ~63u;
+        uint32_t v0 = fetch(t0), v1 = fetch(t0 + 64);
+        for (uint32_t tile = t0; tile < wave_last; tile += 64) {
+            const uint32_t v = v0;
+            v0 = v1;
+            v1 = fetch(tile + 128);
+            // samples before the stream start add nothing (x + 0.0 is exact)
+            const float mag = v == 0xffffffffu ? 0.f : lut[v & 0xff] + lut[v >> 8];      // decode.go:222
+            const float p = k4_chain(carry, mag);     // p(lane) = csum[tile + lane + 1]   (r900.go:97-99)
+            carry = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(p), 63));   // (the builtin is typed int)
+            for (;;) {                                // boundaries inside (tile, tile + 64]: several when CL < 64
+                const bool at = mine && m <= 168 && next_pt > tile && next_pt <= tile + 64;
+                if (!__any(at)) break;
+                const int src = at ? (int)(next_pt - tile - 1) : 0;
+                const float cv = __int_as_float(__builtin_amdgcn_ds_bpermute(src << 2, __float_as_int(p)));
+                if (at) record(cv);
             }
         }
+        todo &= ~__ballot(mine);
     }
-    if (pending) record(cap);
 }
 
 // The last PL samples that precede the next batch: new[i] = sample (i - PL + n_batch) of the batch just processed,
