@@ -352,17 +352,20 @@ def main():
     if args.spinup_ms > 0:
         chunk = max(8, int(8e-3 / max(1e-6, 0.28e-3 * nbytes / GIB)))     # ~8 ms of batches per chunk
         t_spin = time.perf_counter()
-        last = []
+        pairs = []                       # (ms for c steps, ms for 2c steps): the slope is the steady step, fill excluded
         while (time.perf_counter() - t_spin) * 1e3 < args.spinup_ms:
-            sync_all()
-            t1 = time.perf_counter()
-            run(chunk, 0, 0)
-            if distributed:
-                gatherer.wait()
-            sync_all()
-            last.append((time.perf_counter() - t1) * 1e3 / chunk)
-            spin_steps += chunk
-        steady_ms = float(np.min(last[-3:])) if last else float("nan")
+            t_pair = []
+            for n in (chunk, 2 * chunk):
+                sync_all()
+                t1 = time.perf_counter()
+                run(n, 0, 0)
+                if distributed:
+                    gatherer.wait()
+                sync_all()
+                t_pair.append((time.perf_counter() - t1) * 1e3)
+                spin_steps += n
+            pairs.append((t_pair[1] - t_pair[0]) / chunk)
+        steady_ms = float(np.median(pairs[-3:])) if pairs else float("nan")
 
     warm = run(max(args.warmup, 1), 2) if args.warmup else []
     sync_all()

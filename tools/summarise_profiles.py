@@ -28,19 +28,21 @@ for sub in ('pmc_fetch', 'pmc_write', 'pmc_sq_a', 'pmc_sq_b'):
 json.dump(summary, open(os.path.join(dst, 'pmc_summary.json'), 'w'), indent=1, sort_keys=True)
 for f in glob.glob(os.path.join(src, 'stats', '**', '*kernel_stats.csv'), recursive=True):
     shutil.copy(f, os.path.join(dst, 'kernel_stats.csv'))
-for name in ('bench_line.log', 'bench_unprofiled.log'):
+import re
+names = [os.path.basename(p) for p in glob.glob(os.path.join(src, 'bench_*.log'))]
+for name in names:
     p = os.path.join(src, name)
     if os.path.exists(p):
         lines = [l for l in open(p) if l.startswith('{')]
         if lines: open(os.path.join(dst, name.replace('.log', '.json')), 'w').write(lines[-1])
-k1 = next((k for k in summary if 'k1_demod<72, false>' in k), None)
+k1 = next((k for k in summary if 'k1t_demod<72, false' in k), None) or next((k for k in summary if 'k1_demod<72, false>' in k), None)
 if k1 and 'FETCH_SIZE' in summary[k1] and 'WRITE_SIZE' in summary[k1]:
     fetch_kib, write_kib = summary[k1]['FETCH_SIZE']['mean'], summary[k1]['WRITE_SIZE']['mean']
     rd, wr = fetch_kib * 1024 * 2, write_kib * 1024
     out = {'kernel': k1, 'bytes_per_launch': rd + wr, 'read_bytes': rd, 'write_bytes': wr,
            'FETCH_SIZE_KiB_raw': fetch_kib, 'WRITE_SIZE_KiB_raw': write_kib,
            'correction': 'FETCH_SIZE x2 (gfx950 reports half of wide coalesced reads), WRITE_SIZE x1; separate --pmc passes',
-           'profile': 'profiles/' + tag + '/pmc_summary.json'}
+           'profile': 'profiles/' + tag + '/pmc_summary.json', 'tag': tag}
     json.dump(out, open(os.path.join(root, 'profiles', 'k1_hbm_traffic.json'), 'w'), indent=1)
     print(json.dumps(out))
 print(open(os.path.join(dst, 'kernel_stats.csv')).read())
