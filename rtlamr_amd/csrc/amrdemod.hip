@@ -327,9 +327,9 @@ amr_status enqueue_search(amr_handle *h, Slot &s, bool rerun = false, bool dense
     static unsigned long long *k2dbg = nullptr;
     static int k2dbg_calls = 0;
     if (getenv("AMR_K2_DBG")) {
-        if (!k2dbg) HIP_TRY(hipMalloc((void **)&k2dbg, (size_t)s.n_tiles * 64 + 64));
+        if (!k2dbg) HIP_TRY(hipMalloc((void **)&k2dbg, (size_t)s.n_tiles * 128 + 128));
         k2.dbg = k2dbg;
-        HIP_TRY(hipMemsetAsync(k2dbg, 0, (size_t)s.n_tiles * 64, st));
+        HIP_TRY(hipMemsetAsync(k2dbg, 0, (size_t)s.n_tiles * 128, st));
     }
     const bool t2 = s.timed >= 2;
     // the overflow word is zeroed by the previous batch's k_hist_update; only a re-run has to do it here
@@ -337,21 +337,31 @@ amr_status enqueue_search(amr_handle *h, Slot &s, bool rerun = false, bool dense
         HIP_TRY(hipMemsetAsync(s.d_overflow, 0, 4, st));
         HIP_TRY(hipMemsetAsync(s.d_gcnt, 0, (size_t)s.gcnt_words * 4, st));
     }
-    // second-generation search (k2_stream.h): every preamble at least 16 symbols long, rows of 64..256 words
+    // second-generation search (k2_stream.h): rows of 64..256 words, every preamble at least D symbols long, D = taps
+    // applied to every position before the candidate lists take over: 10 for one preamble (2^-10 of the positions
+    // survive: ~20 list entries per wave in noise), 12 when several preambles share the sweep and the lists
+    const int k2d = n_pre == 1 ? AMR_K2S_D1 : AMR_K2S_DN;
     bool stream_ok = !h->dense_search && !dense && k2_use_stream() && n_pre <= 4 && h->sg.wpb >= 64 && h->sg.wpb <= 256;
-    for (uint32_t q = 0; q < n_pre; ++q) stream_ok = stream_ok && h->sg.pre_len[q] >= AMR_K2S_D;
+    for (uint32_t q = 0; q < n_pre; ++q) stream_ok = stream_ok && (int)h->sg.pre_len[q] >= k2d;
     if (stream_ok) {
         const int nwv = amr::k2_stream_waves(h->sg.wpb);
         const size_t lds2 = amr::k2_stream_lds_bytes(h->sg.wpb, n_pre);
+        static const bool xcd = [] { const char *e = getenv("AMR_K2_XCD"); return !(e && e[0] == '0'); }();
+        k2.xcd = xcd ? 1u : 0u;
+        const uint32_t grid = xcd ? 8u * ((s.n_tiles + 7u) / 8u) : s.n_tiles;
         bool launched = true;
-#define AMR_K2S_LAUNCH(S, W)                                                                                           \
+#define AMR_K2S_LAUNCH(S, DD, W)                                                                                       \
     do {                                                                                                             \
-        HIP_TRY(hipFuncSetAttribute((const void *)amr::k2_search_stream<S, AMR_K2S_D, W>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2)); \
-        hipExtLaunchKernelGGL((amr::k2_search_stream<S, AMR_K2S_D, W>), dim3(s.n_tiles), dim3(64 * W), lds2, st, t2 ? s.ev_s : nullptr, nullptr, 0, k2); \
+        HIP_TRY(hipFuncSetAttribute((const void *)amr::k2_search_stream<S, DD, W>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2)); \
+        hipExtLaunchKernelGGL((amr::k2_search_stream<S, DD, W>), dim3(grid), dim3(64 * W), lds2, st, t2 ? s.ev_s : nullptr, nullptr, 0, k2); \
+    } while (0)
+#define AMR_K2S_W(S, DD)                                                                                             \
+    do {                                                                                                             \
+        if (nwv == 2) AMR_K2S_LAUNCH(S, DD, 2); else if (nwv == 4) AMR_K2S_LAUNCH(S, DD, 4); else AMR_K2S_LAUNCH(S, DD, 8); \
     } while (0)
 #define AMR_K2S_CASE(S)                                                                                               \
     case S:                                                                                                          \
-        if (nwv == 2) AMR_K2S_LAUNCH(S, 2); else if (nwv == 4) AMR_K2S_LAUNCH(S, 4); else AMR_K2S_LAUNCH(S, 8);      \
+        if (n_pre == 1) AMR_K2S_W(S, AMR_K2S_D1); else AMR_K2S_W(S, AMR_K2S_DN);                                      \
         break;
         switch (h->sg.symbol_length) {
             AMR_K2S_CASE(64) AMR_K2S_CASE(80) AMR_K2S_CASE(96) AMR_K2S_CASE(112) AMR_K2S_CASE(128)
@@ -359,6 +369,7 @@ amr_status enqueue_search(amr_handle *h, Slot &s, bool rerun = false, bool dense
         default: launched = false; break;
         }
 #undef AMR_K2S_CASE
+#undef AMR_K2S_W
 #undef AMR_K2S_LAUNCH
         stream_ok = launched;
     }
@@ -389,20 +400,44 @@ amr_status enqueue_search(amr_handle *h, Slot &s, bool rerun = false, bool dense
                                     (int)lds2));
         hipExtLaunchKernelGGL(amr::k2_search_dense, dim3(s.n_tiles), dim3(256), lds2, st, t2 ? s.ev_s : nullptr, nullptr, 0, k2);
     }
-    if (k2.dbg && ++k2dbg_calls == 6) {   // phase timestamps of the 6th search: mean duration of each phase over the workgroups
+    if (k2.dbg && (++k2dbg_calls == 6 || k2dbg_calls == 400)) {   // phase timestamps of the 6th search: mean duration of each phase over the workgroups
         HIP_TRY(hipStreamSynchronize(st));
-        std::vector<unsigned long long> d((size_t)s.n_tiles * 8);
+        std::vector<unsigned long long> d((size_t)s.n_tiles * 16);
         HIP_TRY(hipMemcpy(d.data(), k2dbg, d.size() * 8, hipMemcpyDeviceToHost));
-        double ph[6] = {0, 0, 0, 0, 0, 0}, tot = 0, cand = 0, keep = 0; unsigned long long t0 = ~0ull, t1 = 0; size_t n = 0;
+        double ph[6] = {0, 0, 0, 0, 0, 0}, tot = 0, cand = 0, keep = 0; unsigned long long r0 = ~0ull, r1 = 0; size_t n = 0;
+        std::vector<double> starts, durs;
         for (size_t T = 0; T < s.n_tiles; ++T) {
-            const unsigned long long *x = &d[T * 8];
+            const unsigned long long *x = &d[T * 16];
             if (!x[0] || !x[6]) continue;
             for (int i = 0; i < 6; ++i) ph[i] += (double)(x[i + 1] - x[i]);
             tot += (double)(x[6] - x[0]); cand += (double)(x[7] >> 32); keep += (double)(x[7] & 0xffffffffu);
-            t0 = std::min(t0, x[0]); t1 = std::max(t1, x[6]); ++n;
+            r0 = std::min(r0, x[8]); r1 = std::max(r1, x[9]); ++n;
         }
-        fprintf(stderr, "[amr] k2 phases (mean ticks over %zu WGs): prologue %.0f sweep %.0f stage2 %.0f barrier %.0f scan %.0f emit %.0f | total %.0f, kernel span %llu ticks, cand %.1f keep %.1f per WG\n",
-                n, ph[0] / n, ph[1] / n, ph[2] / n, ph[3] / n, ph[4] / n, ph[5] / n, tot / n, t1 - t0, cand / n, keep / n);
+        for (size_t T = 0; T < s.n_tiles; ++T) {
+            const unsigned long long *x = &d[T * 16];
+            if (!x[0] || !x[6]) continue;
+            starts.push_back((double)(x[8] - r0) * 0.01); durs.push_back((double)(x[9] - x[8]) * 0.01);
+        }
+        for (int grp = 0; grp < 2; ++grp) {     // workgroups of the first wave of dispatches vs the ones that follow
+            double g[6] = {0, 0, 0, 0, 0, 0}, gd = 0; size_t gn = 0;
+            for (size_t T = 0; T < s.n_tiles; ++T) {
+                const unsigned long long *x = &d[T * 16];
+                if (!x[0] || !x[6]) continue;
+                const bool late = (double)(x[8] - r0) * 0.01 > 3.0;
+                if ((int)late != grp) continue;
+                for (int i = 0; i < 6; ++i) g[i] += (double)(x[i + 1] - x[i]);
+                gd += (double)(x[9] - x[8]) * 0.01; ++gn;
+            }
+            if (gn) fprintf(stderr, "[amr] k2 %s workgroups (%zu): prologue %.0f sweep %.0f stage2 %.0f barrier %.0f scan %.0f emit %.0f ticks, duration %.2f us\n",
+                            grp ? "later" : "first-round", gn, g[0] / gn, g[1] / gn, g[2] / gn, g[3] / gn, g[4] / gn, g[5] / gn, gd / gn);
+        }
+        std::sort(starts.begin(), starts.end()); std::sort(durs.begin(), durs.end());
+        auto pc = [](const std::vector<double> &v, double f) { return v.empty() ? 0.0 : v[(size_t)(f * (v.size() - 1))]; };
+        fprintf(stderr, "[amr] k2 phases (mean ticks over %zu WGs): prologue %.0f sweep %.0f stage2 %.0f barrier %.0f scan %.0f emit %.0f | total %.0f, cand %.1f keep %.1f per WG\n",
+                n, ph[0] / n, ph[1] / n, ph[2] / n, ph[3] / n, ph[4] / n, ph[5] / n, tot / n, cand / n, keep / n);
+        fprintf(stderr, "[amr] k2 timeline (us, 100 MHz clock): first start -> last end %.2f; WG start p25 %.2f p50 %.2f p75 %.2f p90 %.2f p99 %.2f max %.2f; WG duration p10 %.2f p50 %.2f p90 %.2f max %.2f\n",
+                (double)(r1 - r0) * 0.01, pc(starts, .25), pc(starts, .5), pc(starts, .75), pc(starts, .9), pc(starts, .99), pc(starts, 1.0),
+                pc(durs, .1), pc(durs, .5), pc(durs, .9), pc(durs, 1.0));
     }
     AMR_DBG(st, "k2_search");
     amr::K3Args k3{};
@@ -410,7 +445,9 @@ amr_status enqueue_search(amr_handle *h, Slot &s, bool rerun = false, bool dense
     k3.out = s.d_out; k3.offs_pre = s.d_offs_pre; k3.h_offs_pre = s.h_off; k3.h_overflow = s.h_ovf;
     k3.out_cap = s.out_cap; k3.overflow = s.d_overflow;
     k3.block_base = s.calls_base; k3.n_tiles = s.n_tiles; k3.cap = s.stage_cap; k3.g = h->sg;
-    hipExtLaunchKernelGGL(amr::k3_slice, dim3(s.n_tiles, n_pre), dim3(256), 0, st, nullptr, t2 ? s.ev2 : nullptr, 0, k3);
+    static const bool k3_old = [] { const char *e = getenv("AMR_K3_IMPL"); return e && strcmp(e, "old") == 0; }();
+    if (k3_old) hipExtLaunchKernelGGL(amr::k3_slice, dim3(s.n_tiles, n_pre), dim3(256), 0, st, nullptr, t2 ? s.ev2 : nullptr, 0, k3);
+    else hipExtLaunchKernelGGL(amr::k3_slice_words, dim3(s.n_tiles, n_pre), dim3(256), 0, st, nullptr, t2 ? s.ev2 : nullptr, 0, k3);
     HIP_TRY(hipGetLastError());
     AMR_DBG(st, "k3_slice");
     if (h->r900_pid >= 0) {

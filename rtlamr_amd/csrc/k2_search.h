@@ -54,7 +54,8 @@ struct K2Args {
     uint32_t n_tiles;      // tiles searched: ceil(n_blocks/64) + 1 (history tile first)
     uint32_t cap;
     int64_t n_lo, n_hi;    // valid positions: n_lo <= n < n_hi, n relative to batch sample 0
-    unsigned long long *dbg;   // developer diagnostics (AMR_K2_DBG): 8 timestamps per workgroup, or null
+    unsigned long long *dbg;   // developer diagnostics (AMR_K2_DBG): 16 words of timestamps per workgroup, or null
+    uint32_t xcd;              // stream kernel: XCD-contiguous tile order (the grid is then 8 * ceil(n_tiles / 8))
     SearchGeom g;
 };
 
@@ -548,6 +549,141 @@ __global__ __launch_bounds__(256) void k3_slice(const K3Args a)
                 const uint32_t valid = g.packet_symbols - bj * 8;     // symbols that exist in this byte
                 if (valid < 8) byte >>= (8 - valid);                  // PacketSymbols % 8 != 0: right-aligned like Go's shift-in
                 out[bj] = (uint8_t)byte;
+            }
+        }
+    }
+}
+
+// K3, second generation.  The hits of a real packet (and most noise hits' neighbours) come in runs of adjacent
+// positions, so the per-hit slicing above reads every bitstream word ~20 times and spends ~13 VALU operations per
+// (hit, symbol).  Here the unit of work is a bitstream WORD that holds hits: for symbol p the 32 positions of the word
+// need the 32 stream bits starting at word*32 + p*SL -- one window, one or two word loads (SL is a multiple of 16) --
+// and the packets of all 32 positions are the columns of the bit matrix [symbol][position].  A wave takes 64 symbols
+// at a time, lane = symbol (two 32 x 32 blocks), transposes the blocks in five exchange steps (ds_swizzle, no LDS
+// memory), after which lane c of a block holds 32 consecutive packet bits of position 31-c: one dword of that packet,
+// already in the byte order of Decoder.Slice (decode.go:363-366) because the symbols were dealt to the lanes
+// bit-reversed inside every byte.  Positions that are hits store their dword, the others are dropped.
+// Input and output are those of k3_slice (positions in the staging slots, ascending; packed result).
+__device__ __forceinline__ uint32_t k3_transpose32(uint32_t x, uint32_t lane)
+{
+#define K3_TSTEP(S, M)                                                                                                \
+    {                                                                                                                 \
+        const uint32_t y = (uint32_t)__builtin_amdgcn_ds_swizzle((int)x, ((S) << 10) | 0x1f);   /* lane ^ S */       \
+        x = (lane & (S)) ? ((x & ~(M)) | ((y >> (S)) & (M))) : ((x & (M)) | ((y << (S)) & ~(M)));                     \
+    }
+    K3_TSTEP(16, 0x0000ffffu) K3_TSTEP(8, 0x00ff00ffu) K3_TSTEP(4, 0x0f0f0f0fu) K3_TSTEP(2, 0x33333333u) K3_TSTEP(1, 0x55555555u)
+#undef K3_TSTEP
+    return x;
+}
+
+__global__ __launch_bounds__(256) void k3_slice_words(const K3Args a)
+{
+    const SearchGeom &g = a.g;
+    const uint32_t T = blockIdx.x, q = blockIdx.y;
+    __shared__ uint64_t red[2][4];
+    __shared__ uint32_t tab[4][32];          // per wave: staging index of the hit at bit b of the current word, or ~0
+    const uint32_t cnt = a.counts[q * a.n_tiles + T];
+    if (cnt == 0 && T != 0) return;
+    // slot of this (tile, preamble) list and the grand total: as in k3_slice
+    const uint32_t n_groups = k2_groups(a.n_tiles), my_g = q * n_groups + (T >> 6);
+    uint64_t before = 0, all = 0;
+    for (uint32_t i = threadIdx.x; i < g.n_pre * n_groups; i += 256) {
+        const uint32_t c = a.gcnt[i];
+        all += c;
+        before += i < my_g ? c : 0u;
+    }
+    if (threadIdx.x < (T & 63)) before += a.counts[q * a.n_tiles + (T & ~63u) + threadIdx.x];
+    for (int d = 32; d; d >>= 1) {
+        before += __shfl_down((unsigned long long)before, d);
+        all += __shfl_down((unsigned long long)all, d);
+    }
+    if ((threadIdx.x & 63) == 0) { red[0][threadIdx.x >> 6] = before; red[1][threadIdx.x >> 6] = all; }
+    __syncthreads();
+    const uint64_t off = red[0][0] + red[0][1] + red[0][2] + red[0][3];
+    const uint64_t total = red[1][0] + red[1][1] + red[1][2] + red[1][3];
+    if (T == 0 && threadIdx.x == 0) {
+        a.offs_pre[q] = off;
+        a.h_offs_pre[q] = off;
+        if (q == 0) { a.offs_pre[g.n_pre] = total; a.h_offs_pre[g.n_pre] = total; *a.h_overflow = *a.overflow; }
+    }
+    if (*a.overflow || cnt == 0) return;
+    if (total > a.out_cap) return;   // the host grows the buffer and searches again
+    uint64_t *hit_block = reinterpret_cast<uint64_t *>(a.out);
+    uint32_t *hit_idx = reinterpret_cast<uint32_t *>(a.out + total * 8);
+    uint8_t *pkt = a.out + total * 12;
+    const uint32_t *src = a.staging + ((size_t)T * g.n_pre + q) * a.cap;
+    const uint32_t *__restrict__ tbase = a.qt + ((size_t)T << (6 + g.lg_wpb));
+    const uint32_t lg_bs = g.lg_block_size, bs_mask = g.block_size - 1, lg_tw = 6 + g.lg_wpb;
+    const uint32_t lane = threadIdx.x & 63, wv = threadIdx.x >> 6, l32 = lane & 31, half = lane >> 5;
+    const uint32_t PS = g.packet_symbols, SL = g.symbol_length, PB = g.pkt_bytes;
+    // symbol offset of this lane inside a 64-symbol step: the 32 lanes of a block take the symbols bit-reversed
+    // within every byte, so that bit i of the transposed dword is the symbol Decoder.Slice puts into bit i
+    const uint32_t sym_lane = half * 32 + ((l32 & ~7u) | (7u - (l32 & 7u)));
+    const uint32_t bad = 64u << lg_bs;                 // defensive bound for positions, as in k3_slice
+    auto word_at = [&](uint32_t v) {                   // bitstream word holding bit v (counted from row 0 of tile T)
+        const uint32_t row = v >> lg_bs, w = (v & bs_mask) >> 5;
+        return tbase[((row >> 6) << lg_tw) + ((w >> 2) << 8) + ((row & 63) << 2) + (w & 3)];
+    };
+    for (uint32_t i0 = wv * 64; i0 < cnt; i0 += 256) {
+        const uint32_t i = i0 + lane;
+        const bool have = i < cnt;
+        const uint32_t local = have ? src[i] : 0xffffffffu;
+        const bool ok = have && local < bad;
+        if (ok) {
+            const int64_t n = ((int64_t)T * 64 - 64) * (int64_t)g.block_size + local;
+            const uint64_t pos = (uint64_t)(n + g.packet_length);
+            hit_block[off + i] = a.block_base + (pos >> lg_bs);
+            hit_idx[off + i] = (uint32_t)pos & bs_mask;
+        }
+        const uint32_t key = ok ? local >> 5 : 0xffffffffu;
+        const uint32_t prev = __shfl_up(key, 1);
+        uint64_t leaders = __ballot(ok && (lane == 0 || key != prev));
+        while (leaders) {
+            const uint32_t L = (uint32_t)__ffsll((unsigned long long)leaders) - 1;
+            leaders &= leaders - 1;
+            const uint32_t key_s = __builtin_amdgcn_readlane(key, L);
+            if (lane < 32) tab[wv][lane] = 0xffffffffu;
+            if (ok && key == key_s) tab[wv][local & 31] = i;          // same wave: LDS operations execute in order
+            const uint32_t slot = tab[wv][31 - l32];                  // lane c of a block ends up with position 31-c
+            uint8_t *out = pkt + (off + slot) * (uint64_t)PB;
+            const uint32_t v0 = key_s << 5;
+            for (uint32_t p0 = 0; p0 < PS; p0 += 256) {               // four 64-symbol steps per round: 8 loads in flight
+                uint32_t A[4], B[4];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    A[k] = 0; B[k] = 0;
+                    if (p0 + 64 * k < PS) {
+                        const uint32_t sy = p0 + 64 * k + sym_lane;
+                        const uint32_t v = v0 + (sy < PS ? sy : PS - 1) * SL;
+                        A[k] = word_at(v);
+                        B[k] = word_at(v + 32);
+                    }
+                }
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    if (p0 + 64 * k >= PS) break;
+                    const uint32_t sy = p0 + 64 * k + sym_lane;
+                    const uint32_t v = v0 + (sy < PS ? sy : PS - 1) * SL;
+                    const uint32_t W = (v & 16) ? __builtin_amdgcn_alignbit(A[k], B[k], 16) : A[k];
+                    const uint32_t Y = k3_transpose32(W, lane);
+                    const uint32_t b0 = (p0 + 64 * k) / 8 + half * 4;   // first packet byte of this lane's dword
+                    if (slot != 0xffffffffu && b0 < PB) {
+                        if (b0 + 4 <= PB && (PB & 3) == 0 && (PS & 7) == 0) {
+                            *reinterpret_cast<uint32_t *>(out + b0) = Y;
+                        } else {
+#pragma unroll
+                            for (uint32_t j = 0; j < 4; ++j) {
+                                const uint32_t bj = b0 + j;
+                                if (bj < PB) {
+                                    uint32_t byte = (Y >> (8 * j)) & 0xffu;
+                                    const uint32_t valid = PS - bj * 8;
+                                    if (valid < 8) byte >>= (8 - valid);   // PacketSymbols % 8 != 0: right-aligned like Go's shift-in
+                                    out[bj] = (uint8_t)byte;
+                                }
+                            }
+                        }
+                    }
+                }
             }
         }
     }

@@ -22,8 +22,11 @@
 #pragma once
 #include "k2_search.h"
 
-#ifndef AMR_K2S_D
-#define AMR_K2S_D 16
+#ifndef AMR_K2S_D1
+#define AMR_K2S_D1 10   // taps of the register sweep, one preamble
+#endif
+#ifndef AMR_K2S_DN
+#define AMR_K2S_DN 12   // taps of the register sweep, several preambles
 #endif
 #ifndef AMR_K2S_OCC
 #define AMR_K2S_OCC 4   // waves per SIMD the register allocation aims at (launch bound)
@@ -51,11 +54,27 @@ constexpr int kK2SWords = 32;             // words of a row per wave
 constexpr int kK2SList = 128;             // (key, mask) entries per wave: with D = 16 a wave of noise yields < 1, a packet a few
 
 inline int k2_stream_waves(uint32_t wpb) { return (int)(wpb / kK2SWords); }
+// LDS per workgroup: the tile, the per-wave candidate lists, the hit counts per (row, wave) -- two preambles share a
+// word (16 bits each: a wave's 32 words of a row hold at most 1024 hits) -- and the per-wave totals of the scan.  The
+// ranks (bases) reuse the tile's space once the sweep and stage 2 are done.  Rows of 256 words with four preambles come
+// to 78.9 KB: two workgroups per CU.
 inline size_t k2_stream_lds_bytes(uint32_t wpb, uint32_t n_pre)
 {
     const int nwv = k2_stream_waves(wpb);
     const size_t tile = nwv == 8 ? (size_t)(wpb / 4) * (1024 + 16) : (size_t)(wpb / 4) * 1040;   // same bytes, different layout
-    return tile + ((size_t)nwv * kK2SList * 2 + 2 * (size_t)n_pre * 64 * nwv + 8) * 4;
+    return tile + ((size_t)nwv * kK2SList * 2 + (size_t)((n_pre + 1) / 2) * 64 * nwv + 4 * 8) * 4;
+}
+
+// inclusive prefix sum over the 64 lanes of a wave: four row_shr steps inside the rows of 16, then the two row broadcasts
+__device__ __forceinline__ uint32_t k2s_wave_scan(uint32_t x)
+{
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x111, 0xf, 0xf, true);    // row_shr:1
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x112, 0xf, 0xf, true);    // row_shr:2
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x114, 0xf, 0xf, true);    // row_shr:4
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x118, 0xf, 0xf, true);    // row_shr:8
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x142, 0xa, 0xf, false);   // row_bcast:15 into rows 1 and 3
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x143, 0xc, 0xf, false);   // row_bcast:31 into rows 2 and 3
+    return x;
 }
 
 typedef uint32_t k2s_v4u __attribute__((ext_vector_type(4)));
@@ -127,7 +146,7 @@ __device__ __forceinline__ void k2s_sweep(K2SRing<SL, D> &R, K2SCtx &cx, uint32_
                 for (int j = 0; j < 4; ++j) {
                     const int i0 = (GG * 4 + j + x) % G::RW, i1 = (i0 + 1) % G::RW;
                     const uint32_t W = half ? __builtin_amdgcn_alignbit(R.c[i0 >> 2][i0 & 3], R.c[i1 >> 2][i1 & 3], 16) : R.c[i0 >> 2][i0 & 3];
-                    M[j] &= W ^ inv;
+                    M[j] = __builtin_amdgcn_bitop3_b32(M[j], W, inv, 0x60);   // M & (W ^ inv) in one pass
                 }
             }
             if (__ballot((M[0] | M[1] | M[2] | M[3]) != 0)) {  // rare: record the non-zero masks of valid words
@@ -162,9 +181,13 @@ __global__ __launch_bounds__(64 * NWV, AMR_K2S_OCC) void k2_search_stream(const 
     constexpr int MAXP = 4;
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
     if ((uint32_t)(uintptr_t)(__attribute__((address_space(3))) void *)lds != 0) __builtin_trap();   // the M0 values below
-#define K2S_STAMP(i) do { if (a.dbg && threadIdx.x == 0) a.dbg[(size_t)blockIdx.x * 8 + (i)] = __builtin_readcyclecounter(); } while (0)
+#define K2S_STAMP(i) do { if (a.dbg && threadIdx.x == 0) a.dbg[(size_t)blockIdx.x * 16 + (i)] = __builtin_readcyclecounter(); } while (0)
+    // a.xcd: workgroup b runs on XCD b % 8; give every XCD one contiguous run of tiles (the grid is rounded up to 8 runs)
+    const uint32_t T = a.xcd ? (blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3) : blockIdx.x;
+    if (T >= a.n_tiles) return;
     K2S_STAMP(0);
-    const uint32_t T = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
+    if (a.dbg && threadIdx.x == 0) a.dbg[(size_t)blockIdx.x * 16 + 8] = __builtin_amdgcn_s_memrealtime();
+    const uint32_t tid = threadIdx.x, lane = tid & 63;
     const uint32_t v = __builtin_amdgcn_readfirstlane(tid >> 6);
     const uint32_t wpb = a.g.wpb, lg_wpb = a.g.lg_wpb, wpb_mask = wpb - 1;
     const uint32_t lg_bs = a.g.lg_block_size;
@@ -177,9 +200,10 @@ __global__ __launch_bounds__(64 * NWV, AMR_K2S_OCC) void k2_search_stream(const 
     constexpr bool kExtra = K2SLds<NWV>::kExtra;
     uint8_t *tileb = reinterpret_cast<uint8_t *>(lds);  // [cpr][65][16 B], or [cpr][64][16 B] + [cpr][16 B]
     uint32_t *lists = lds + cpr * 260;                 // [NWV][LCAP][2]
-    uint32_t *cnts = lists + NWV * LCAP * 2;           // [n_pre][NT], index row*NWV+wave
-    uint32_t *bases = cnts + n_pre * NT;               // [n_pre][NT]
-    uint32_t *wtot = bases + n_pre * NT;               // [NWV]
+    const uint32_t planes = (n_pre + 1) >> 1;
+    uint32_t *cnts = lists + NWV * LCAP * 2;           // [planes][NT], index row*NWV+wave; preamble q in half q&1 of plane q>>1
+    uint32_t *wtot = cnts + planes * NT;               // [MAXP][NWV]
+    uint32_t *bases = lds;                             // [n_pre][NT]: over the tile, once nothing reads it any more
 
     // ---- stage the tile: chunk c of all 64 rows is 1 KiB contiguous in memory and in LDS ----
     {
@@ -194,7 +218,7 @@ __global__ __launch_bounds__(64 * NWV, AMR_K2S_OCC) void k2_search_stream(const 
             const k2s_v4u x = *reinterpret_cast<const k2s_v4u *>(a.qt + (size_t)(T + 1) * tile_words + (size_t)tid * 256);
             *reinterpret_cast<k2s_v4u *>(tileb + (kExtra ? cpr * CS + tid * 16 : tid * CS + 1024)) = x;
         }
-        for (uint32_t q = 0; q < n_pre; ++q) cnts[q * NT + tid] = 0;
+        for (uint32_t q = 0; q < planes; ++q) cnts[q * NT + tid] = 0;
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
     __syncthreads();
@@ -241,23 +265,28 @@ __global__ __launch_bounds__(64 * NWV, AMR_K2S_OCC) void k2_search_stream(const 
 #pragma unroll
         for (int qq = 1; qq < MAXP; ++qq)
             if (q == (uint32_t)qq) { pb = pbits[qq]; pl = plen[qq]; }
-        for (uint32_t p = D; p < maxL; ++p) {
+        for (uint32_t p = D; p < maxL; p += 4) {        // four taps per round: their eight LDS reads are in flight together
             if (!__any(m != 0)) break;
-            const uint32_t o = p * SL;
-            const uint32_t x = w + (o >> 5);
-            uint32_t Wd = *reinterpret_cast<const uint32_t *>(tileb + k2s_off<NWV>(l, x, wpb_mask, lg_wpb));
-            if (o & 31) {
+            uint32_t Wd[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const uint32_t pk = p + k < maxL ? p + k : maxL - 1;
+                const uint32_t o = pk * SL;
+                const uint32_t x = w + (o >> 5);
+                const uint32_t A = *reinterpret_cast<const uint32_t *>(tileb + k2s_off<NWV>(l, x, wpb_mask, lg_wpb));
                 const uint32_t B = *reinterpret_cast<const uint32_t *>(tileb + k2s_off<NWV>(l, x + 1, wpb_mask, lg_wpb));
-                Wd = __builtin_amdgcn_alignbit(Wd, B, 16);
+                Wd[k] = (o & 31) ? __builtin_amdgcn_alignbit(A, B, 16) : A;
             }
-            if (p < pl) m &= ((pb >> p) & 1) ? Wd : ~Wd;
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+                if (p + k < pl) m &= ((pb >> (p + k)) & 1) ? Wd[k] : ~Wd[k];
         }
         const uint64_t b = __ballot(m != 0);
         if (m != 0) {   // survivors move to the front, order preserved (slot <= e, earlier chunks already read)
             const uint32_t slot = n_keep + __builtin_amdgcn_mbcnt_hi((uint32_t)(b >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)b, 0));
             mylist[slot * 2] = key;
             mylist[slot * 2 + 1] = m;
-            atomicAdd(&cnts[q * NT + l * NWV + v], __popc(m));
+            atomicAdd(&cnts[(q >> 1) * NT + l * NWV + v], (uint32_t)__popc(m) << ((q & 1) * 16));
         }
         n_keep += __popcll(b);
     }
@@ -265,30 +294,30 @@ __global__ __launch_bounds__(64 * NWV, AMR_K2S_OCC) void k2_search_stream(const 
     __syncthreads();
     K2S_STAMP(4);
 
-    // ---- ranks: exclusive scan over (row, wave) in stream order, per preamble ----
-    uint32_t total[MAXP];
+    // ---- ranks: exclusive scan over (row, wave) in stream order, all preambles in one pass ----
+    uint32_t total[MAXP], val[MAXP], inc[MAXP];
+#pragma unroll
+    for (int q = 0; q < MAXP; ++q) {
+        val[q] = q < (int)n_pre ? (cnts[(q >> 1) * NT + tid] >> ((q & 1) * 16)) & 0xffffu : 0u;
+        inc[q] = k2s_wave_scan(val[q]);
+        if (lane == 63) wtot[q * NWV + v] = inc[q];
+    }
+    __syncthreads();
 #pragma unroll
     for (int q = 0; q < MAXP; ++q) {
         total[q] = 0;
         if (q >= (int)n_pre) continue;
-        const uint32_t val = cnts[q * NT + tid];
-        uint32_t inc = val;
+        uint32_t base = 0, tot = 0;
 #pragma unroll
-        for (int d = 1; d < 64; d <<= 1) {
-            const uint32_t t = __shfl_up(inc, d);
-            if (lane >= (uint32_t)d) inc += t;
+        for (int u = 0; u < NWV; ++u) {
+            const uint32_t t = wtot[q * NWV + u];
+            tot += t;
+            base += (uint32_t)u < v ? t : 0u;
         }
-        if (lane == 63) wtot[v] = inc;
-        __syncthreads();
-        uint32_t base = 0;
-        for (uint32_t u = 0; u < v; ++u) base += wtot[u];
-        uint32_t tot = 0;
-#pragma unroll
-        for (int u = 0; u < NWV; ++u) tot += wtot[u];
         total[q] = tot;
-        bases[q * NT + tid] = base + inc - val;
-        __syncthreads();
+        bases[q * NT + tid] = base + inc[q] - val[q];
     }
+    __syncthreads();
     K2S_STAMP(5);
 
     // ---- emit: every surviving entry by 32 lanes at once, lane b = bit b (MSB first = stream order) ----
@@ -315,7 +344,10 @@ __global__ __launch_bounds__(64 * NWV, AMR_K2S_OCC) void k2_search_stream(const 
             if (q == (uint32_t)qq) run[qq] += add;
     }
     K2S_STAMP(6);
-    if (a.dbg && tid == 0) a.dbg[(size_t)T * 8 + 7] = ((unsigned long long)n_cand << 32) | n_keep;
+    if (a.dbg && tid == 0) {
+        a.dbg[(size_t)blockIdx.x * 16 + 7] = ((unsigned long long)n_cand << 32) | n_keep;
+        a.dbg[(size_t)blockIdx.x * 16 + 9] = __builtin_amdgcn_s_memrealtime();
+    }
 
     if (tid == 0) {
 #pragma unroll

@@ -1,5 +1,5 @@
-"""The first-generation kernels (k1_demod for chip <= 72, k2_search_fast/dense for the stream kernel's geometries) stay in
-the library as fallbacks (AMR_K1_IMPL=old, AMR_K2_IMPL=old) and as the A side of A/B measurements: keep them exact.
+"""The first-generation kernels (k1_demod for chip <= 72, k2_search_fast/dense for the stream kernel's geometries, the per-hit k3_slice) stay in
+the library as fallbacks (AMR_K1_IMPL=old, AMR_K2_IMPL=old, AMR_K3_IMPL=old) and as the A side of A/B measurements: keep them exact.
 The switch is read once per process, hence the child processes."""
 import os
 import subprocess
@@ -27,8 +27,9 @@ print("fallbacks exact")
 """
 
 
-@pytest.mark.parametrize("env", [{"AMR_K1_IMPL": "old"}, {"AMR_K2_IMPL": "old"}, {"AMR_K1_IMPL": "old", "AMR_K2_IMPL": "old"}],
-                         ids=["k1-old", "k2-old", "both-old"])
+@pytest.mark.parametrize("env", [{"AMR_K1_IMPL": "old"}, {"AMR_K2_IMPL": "old"}, {"AMR_K3_IMPL": "old"},
+                                 {"AMR_K1_IMPL": "old", "AMR_K2_IMPL": "old", "AMR_K3_IMPL": "old"}],
+                         ids=["k1-old", "k2-old", "k3-old", "all-old"])
 def test_first_generation_kernels_stay_exact(env):
     r = subprocess.run([sys.executable, "-c", CHILD], cwd=ROOT, env={**os.environ, **env}, capture_output=True, text=True,
                        timeout=600)
