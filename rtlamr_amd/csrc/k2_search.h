@@ -576,16 +576,17 @@ __device__ __forceinline__ uint32_t k3_transpose32(uint32_t x, uint32_t lane)
     return x;
 }
 
+constexpr int kK3Batch = 4;    // words (entries) a wave works on together: their bitstream loads are in flight at once
+
 __global__ __launch_bounds__(256) void k3_slice_words(const K3Args a)
 {
     const SearchGeom &g = a.g;
     const uint32_t T = blockIdx.x, q = blockIdx.y;
     __shared__ uint64_t red[2][4];
-    __shared__ uint32_t tab[4][32];          // per wave: staging index of the hit at bit b of the current word, or ~0
-    const uint32_t cnt = a.counts[q * a.n_tiles + T];
-    if (cnt == 0 && T != 0) return;
-    // slot of this (tile, preamble) list and the grand total: as in k3_slice
+    __shared__ uint32_t tab[4][kK3Batch][32];   // per wave and entry: staging index of the hit at bit b of the word, or ~0
+    // slot of this (tile, preamble) list and the grand total, as in k3_slice; all loads go out before the first use
     const uint32_t n_groups = k2_groups(a.n_tiles), my_g = q * n_groups + (T >> 6);
+    const uint32_t cnt = a.counts[q * a.n_tiles + T];
     uint64_t before = 0, all = 0;
     for (uint32_t i = threadIdx.x; i < g.n_pre * n_groups; i += 256) {
         const uint32_t c = a.gcnt[i];
@@ -593,6 +594,8 @@ __global__ __launch_bounds__(256) void k3_slice_words(const K3Args a)
         before += i < my_g ? c : 0u;
     }
     if (threadIdx.x < (T & 63)) before += a.counts[q * a.n_tiles + (T & ~63u) + threadIdx.x];
+    const uint32_t ovf = *a.overflow;
+    if (cnt == 0 && T != 0) return;
     for (int d = 32; d; d >>= 1) {
         before += __shfl_down((unsigned long long)before, d);
         all += __shfl_down((unsigned long long)all, d);
@@ -604,9 +607,9 @@ __global__ __launch_bounds__(256) void k3_slice_words(const K3Args a)
     if (T == 0 && threadIdx.x == 0) {
         a.offs_pre[q] = off;
         a.h_offs_pre[q] = off;
-        if (q == 0) { a.offs_pre[g.n_pre] = total; a.h_offs_pre[g.n_pre] = total; *a.h_overflow = *a.overflow; }
+        if (q == 0) { a.offs_pre[g.n_pre] = total; a.h_offs_pre[g.n_pre] = total; *a.h_overflow = ovf; }
     }
-    if (*a.overflow || cnt == 0) return;
+    if (ovf || cnt == 0) return;
     if (total > a.out_cap) return;   // the host grows the buffer and searches again
     uint64_t *hit_block = reinterpret_cast<uint64_t *>(a.out);
     uint32_t *hit_idx = reinterpret_cast<uint32_t *>(a.out + total * 8);
@@ -616,6 +619,7 @@ __global__ __launch_bounds__(256) void k3_slice_words(const K3Args a)
     const uint32_t lg_bs = g.lg_block_size, bs_mask = g.block_size - 1, lg_tw = 6 + g.lg_wpb;
     const uint32_t lane = threadIdx.x & 63, wv = threadIdx.x >> 6, l32 = lane & 31, half = lane >> 5;
     const uint32_t PS = g.packet_symbols, SL = g.symbol_length, PB = g.pkt_bytes;
+    const bool dword_ok = (PB & 3) == 0 && (PS & 7) == 0;
     // symbol offset of this lane inside a 64-symbol step: the 32 lanes of a block take the symbols bit-reversed
     // within every byte, so that bit i of the transposed dword is the symbol Decoder.Slice puts into bit i
     const uint32_t sym_lane = half * 32 + ((l32 & ~7u) | (7u - (l32 & 7u)));
@@ -639,51 +643,63 @@ __global__ __launch_bounds__(256) void k3_slice_words(const K3Args a)
         const uint32_t prev = __shfl_up(key, 1);
         uint64_t leaders = __ballot(ok && (lane == 0 || key != prev));
         while (leaders) {
-            const uint32_t L = (uint32_t)__ffsll((unsigned long long)leaders) - 1;
-            leaders &= leaders - 1;
-            const uint32_t key_s = __builtin_amdgcn_readlane(key, L);
-            if (lane < 32) tab[wv][lane] = 0xffffffffu;
-            if (ok && key == key_s) tab[wv][local & 31] = i;          // same wave: LDS operations execute in order
-            const uint32_t slot = tab[wv][31 - l32];                  // lane c of a block ends up with position 31-c
-            uint8_t *out = pkt + (off + slot) * (uint64_t)PB;
-            const uint32_t v0 = key_s << 5;
-            for (uint32_t p0 = 0; p0 < PS; p0 += 256) {               // four 64-symbol steps per round: 8 loads in flight
-                uint32_t A[4], B[4];
+            uint32_t v0[kK3Batch], slot[kK3Batch];
+            int nb = 0;
 #pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    A[k] = 0; B[k] = 0;
-                    if (p0 + 64 * k < PS) {
-                        const uint32_t sy = p0 + 64 * k + sym_lane;
-                        const uint32_t v = v0 + (sy < PS ? sy : PS - 1) * SL;
-                        A[k] = word_at(v);
-                        B[k] = word_at(v + 32);
-                    }
+            for (int e = 0; e < kK3Batch; ++e) {
+                v0[e] = 0; slot[e] = 0xffffffffu;
+                if (leaders) {                                         // wave-uniform
+                    const uint32_t L = (uint32_t)__ffsll((unsigned long long)leaders) - 1;
+                    leaders &= leaders - 1;
+                    const uint32_t key_s = __builtin_amdgcn_readlane(key, L);
+                    if (lane < 32) tab[wv][e][lane] = 0xffffffffu;
+                    if (ok && key == key_s) tab[wv][e][local & 31] = i;   // same wave: LDS operations execute in order
+                    slot[e] = tab[wv][e][31 - l32];                    // lane c of a block ends up with position 31-c
+                    v0[e] = key_s << 5;
+                    nb = e + 1;
                 }
+            }
+            for (uint32_t p0 = 0; p0 < PS; p0 += 128) {               // two 64-symbol steps of up to four words per round
+                uint32_t A[kK3Batch][2], B[kK3Batch][2];
 #pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    if (p0 + 64 * k >= PS) break;
-                    const uint32_t sy = p0 + 64 * k + sym_lane;
-                    const uint32_t v = v0 + (sy < PS ? sy : PS - 1) * SL;
-                    const uint32_t W = (v & 16) ? __builtin_amdgcn_alignbit(A[k], B[k], 16) : A[k];
-                    const uint32_t Y = k3_transpose32(W, lane);
-                    const uint32_t b0 = (p0 + 64 * k) / 8 + half * 4;   // first packet byte of this lane's dword
-                    if (slot != 0xffffffffu && b0 < PB) {
-                        if (b0 + 4 <= PB && (PB & 3) == 0 && (PS & 7) == 0) {
-                            *reinterpret_cast<uint32_t *>(out + b0) = Y;
-                        } else {
+                for (int e = 0; e < kK3Batch; ++e)
 #pragma unroll
-                            for (uint32_t j = 0; j < 4; ++j) {
-                                const uint32_t bj = b0 + j;
-                                if (bj < PB) {
-                                    uint32_t byte = (Y >> (8 * j)) & 0xffu;
-                                    const uint32_t valid = PS - bj * 8;
-                                    if (valid < 8) byte >>= (8 - valid);   // PacketSymbols % 8 != 0: right-aligned like Go's shift-in
-                                    out[bj] = (uint8_t)byte;
+                    for (int k = 0; k < 2; ++k) {
+                        A[e][k] = 0; B[e][k] = 0;
+                        if (e < nb && p0 + 64 * k < PS) {
+                            const uint32_t sy = p0 + 64 * k + sym_lane;
+                            const uint32_t v = v0[e] + (sy < PS ? sy : PS - 1) * SL;
+                            A[e][k] = word_at(v);
+                            B[e][k] = word_at(v + 32);
+                        }
+                    }
+#pragma unroll
+                for (int e = 0; e < kK3Batch; ++e)
+#pragma unroll
+                    for (int k = 0; k < 2; ++k) {
+                        if (e >= nb || p0 + 64 * k >= PS) continue;
+                        const uint32_t sy = p0 + 64 * k + sym_lane;
+                        const uint32_t W = ((sy < PS ? sy : PS - 1) * SL & 16) ? __builtin_amdgcn_alignbit(A[e][k], B[e][k], 16) : A[e][k];
+                        const uint32_t Y = k3_transpose32(W, lane);
+                        const uint32_t b0 = (p0 + 64 * k) / 8 + half * 4;   // first packet byte of this lane's dword
+                        if (slot[e] != 0xffffffffu && b0 < PB) {
+                            uint8_t *out = pkt + (off + slot[e]) * (uint64_t)PB;
+                            if (b0 + 4 <= PB && dword_ok) {
+                                *reinterpret_cast<uint32_t *>(out + b0) = Y;
+                            } else {
+#pragma unroll
+                                for (uint32_t j = 0; j < 4; ++j) {
+                                    const uint32_t bj = b0 + j;
+                                    if (bj < PB) {
+                                        uint32_t byte = (Y >> (8 * j)) & 0xffu;
+                                        const uint32_t valid = PS - bj * 8;
+                                        if (valid < 8) byte >>= (8 - valid);   // PacketSymbols % 8 != 0: right-aligned like Go's shift-in
+                                        out[bj] = (uint8_t)byte;
+                                    }
                                 }
                             }
                         }
                     }
-                }
             }
         }
     }
