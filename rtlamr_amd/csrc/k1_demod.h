@@ -152,6 +152,7 @@ struct K1Uni {       // wave-uniform state (SGPRs)
     int32_t og;      // output groups produced so far (negative during warm-up)
     uint32_t ngroups;// total groups per lane
     uint32_t ntiles; // total staging tiles per lane
+    uint32_t odd;    // 1 = this wave sits in an odd hardware wave slot of its SIMD (priority swap, see k1_tile.h PRIO)
     uint32_t wi;     // output words buffered in L.ow
     uint32_t wdone;  // output words already written
     uint32_t st;     // store instructions issued since the last tile DMA
@@ -235,6 +236,9 @@ __device__ __forceinline__ uint4 k1_fetch_next(K1Uni &U, const K1Args &a, uint32
         U.st = 0;
         if (t + 1 < U.ntiles && AMR_K1_DIAG != 1)
             k1_prefetch<CL, TAIL>(a, tiles_lds, wg, t + 1, ((t + 1) & 1) * kTileBuf, lane, voff_e, voff_o, rows_valid);
+        // the two waves of a SIMD swap priority every 8 tiles: left alone the arbiter favours the older one, which
+        // finishes ~9 % early and leaves the other without a partner to hide its stalls (measured in k1_tile.h)
+        if (((t >> 3) ^ U.odd) & 1) __builtin_amdgcn_s_setprio(0); else __builtin_amdgcn_s_setprio(1);
     }
     const uint4 r = *reinterpret_cast<const uint4 *>(tiles + (rdv ^ U.roff));
     U.roff += 16;                                 // 8 groups per tile; bit 7 set = wrapped, fixed up on the rare path
@@ -501,6 +505,8 @@ __global__ __launch_bounds__(64, 2) void k1_demod(const K1Args a)
     U.wi = 0;
     U.wdone = 0;
     U.st = 0;
+    U.odd = __builtin_amdgcn_s_getreg(4 | (3 << 11)) & 1u;   // HW_REG_HW_ID.wave_id: slot of this wave in its SIMD
+    if (U.odd) __builtin_amdgcn_s_setprio(1);
 
     // pipeline prologue: tile 0, the LUT values of group 0, the row of group 1
     U.tcur = 0;

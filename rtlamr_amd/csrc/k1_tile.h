@@ -26,6 +26,10 @@
 
 namespace amr {
 
+#if AMR_K1T_CLK
+__device__ unsigned long long k1t_timeline[2 * 8192];   // harness only: 100 MHz start / end tick of every workgroup
+#endif
+
 // SCHED  instruction order inside a tile: 0 = per group: 16 gathers, then the 8 samples' arithmetic; 1 = per half
 //        group, gathers one half ahead of their use (same 16 value registers).
 // DEPTH  staging tiles in flight per wave: 2 = two LDS buffers, every DMA has two tile-times to land; 1 = one LDS
@@ -39,16 +43,22 @@ namespace amr {
 //        NW words kept in registers and the 4-word staging chunk: a burst is 4 * (NLC + 1) + NW words per lane.
 //        Output stores mixed into the read stream cost far more than their bytes, and the cost goes with the number
 //        of bursts (tools/sst_bench.hip: 64 MiB in 8 / 4 / 2 / 1 chip-wide bursts: +30 / +23 / +15 / +8 %).
-template <int SCHED_, int DEPTH_, int XCD_, int NW_, int DIAG_ = 0, int STPOL_ = 0, int STORE_AFTER_ = 0, int NLC_ = 0>
+// PRIO   the two waves of a SIMD do not share it fairly: the arbiter prefers the older wave, which then finishes ~9 %
+//        earlier and leaves the younger one alone (no latency hiding, half the memory parallelism) for the rest of the
+//        launch.  1: the wave in the odd hardware slot runs at priority 1 throughout; 2 / 3 / 4: the two waves swap
+//        priority 0 / 1 every tile / 4 tiles / 16 tiles (the wave in the odd slot starts high).  5: priority 2 from the
+//        wait for the next tile to the issue of the following DMA (the memory-critical stretch), 0 otherwise; 6 = 5 on
+//        top of the per-tile swap of 2 (levels 0 / 1, boundary 3).  10 + k: swap every 2^k tiles.
+template <int SCHED_, int DEPTH_, int XCD_, int NW_, int DIAG_ = 0, int STPOL_ = 0, int STORE_AFTER_ = 0, int NLC_ = 0, int PRIO_ = 0>
 struct K1TCfg {
-    static constexpr int SCHED = SCHED_, DEPTH = DEPTH_, XCD = XCD_, NW = NW_, DIAG = DIAG_, STPOL = STPOL_, STORE_AFTER = STORE_AFTER_, NLC = NLC_;
+    static constexpr int SCHED = SCHED_, DEPTH = DEPTH_, XCD = XCD_, NW = NW_, DIAG = DIAG_, STPOL = STPOL_, STORE_AFTER = STORE_AFTER_, NLC = NLC_, PRIO = PRIO_;
     static constexpr int CAP = NLC_ + NW_ / 4 + 1;               // chunks per full burst (LDS, registers, staging)
     static constexpr uint32_t kLut = DEPTH_ * kTileBuf;          // LDS byte offset of the LUT behind the tile buffer(s)
     static constexpr uint32_t kPark = DEPTH_ * kTileBuf + 1024;  // parked output chunks: chunk c of lane l at kPark + c * 1024 + l * 16
     static constexpr uint32_t kLds = DEPTH_ * kTileBuf + 1024 + NLC_ * 1024;   // dynamic LDS bytes per workgroup
     static constexpr uint32_t kFlip = DEPTH_ == 2 ? kTileBuf : 0; // toggles U.par between the buffers
 };
-typedef K1TCfg<0, 1, 1, 16, 0, 1, 1, 11> K1TDefault;
+typedef K1TCfg<0, 1, 1, 16, 0, 1, 1, 11, 13> K1TDefault;
 
 constexpr int k1t_gcd(int a, int b) { return b == 0 ? a : k1t_gcd(b, a % b); }
 
@@ -95,6 +105,7 @@ struct K1TUni {
     uint32_t nch;      // finished chunks buffered (LDS first, then registers, the last one stays in staging)
     uint32_t wdone;    // words stored
     uint32_t st;       // depth 1: 1 = a store burst was issued after the DMA in flight
+    uint32_t odd;      // PRIO: 1 = this wave sits in an odd hardware wave slot of its SIMD
 };
 
 // LUT gathers of `n` samples starting at sample s0 (0..63) of the register tile: lv[2j], lv[2j+1] = lut[I], lut[Q]
@@ -301,6 +312,8 @@ __device__ __forceinline__ bool k1t_tile(K1TLane<CL, C> &L, K1TUni &U, const K1A
         if (g == 7 && more) {
             // every tile register is dead now.  Outstanding VMEM in issue order: DMA(t+1), the store burst of the
             // previous boundary, DMA(t+2): vmcnt(8) leaves at most DMA(t+2)'s eight pieces in flight.
+            if constexpr (C::PRIO == 5) __builtin_amdgcn_s_setprio(2);
+            if constexpr (C::PRIO == 6) __builtin_amdgcn_s_setprio(3);
             k1t_wait_tile<C>(U);
             k1t_drain<CL, C>(L, rdv, U.par);
         }
@@ -342,6 +355,11 @@ __device__ __forceinline__ bool k1t_tile(K1TLane<CL, C> &L, K1TUni &U, const K1A
     if (kStoreAfter) {
         U.st = 0;
         if (!WARMUP && U.nch == (uint32_t)C::CAP && C::DIAG != 3) { k1t_flush<CL, C>(L, U, qrow); U.st = 1; }
+    }
+    if constexpr (C::PRIO == 5) __builtin_amdgcn_s_setprio(0);
+    if constexpr ((C::PRIO >= 2 && C::PRIO <= 4) || C::PRIO == 6 || C::PRIO >= 10) {
+        constexpr int SH = C::PRIO >= 10 ? C::PRIO - 10 : (C::PRIO == 2 || C::PRIO == 6) ? 0 : C::PRIO == 3 ? 2 : 4;
+        if ((((U.t + 1) >> SH) ^ U.odd) & 1) __builtin_amdgcn_s_setprio(0); else __builtin_amdgcn_s_setprio(1);
     }
     vt_e += kTileBytes;   // lane offsets of the tile the next boundary fetches
     vt_o += kTileBytes;
@@ -426,6 +444,8 @@ __global__ __launch_bounds__(64, 2) void k1t_demod(const K1Args a)
     K1TUni U;
     U.ntiles = (G::HBA / 2 + a.block_size) / 64;
     U.t = 0; U.wi = 0; U.nch = 0; U.wdone = 0; U.st = 0;
+    U.odd = C::PRIO ? (__builtin_amdgcn_s_getreg(4 | (3 << 11)) & 1u) : 0u;   // HW_REG_HW_ID, wave_id: slot of this wave in its SIMD
+    if (C::PRIO && U.odd) __builtin_amdgcn_s_setprio(1);
 
     // prologue: tiles 0 and 1 go out, tile 0 is drained, tile 2 follows it into buffer 0
     k1_prefetch<CL, TAIL>(a, 0, wg, 0, 0, lane, voff_e, voff_o, rows_valid);
@@ -455,6 +475,7 @@ __global__ __launch_bounds__(64, 2) void k1t_demod(const K1Args a)
         const uint64_t c = __builtin_readcyclecounter() - clk0, r = __builtin_amdgcn_s_memrealtime() - rt0;
         a.qt[0] = (uint32_t)c; a.qt[1] = (uint32_t)(c >> 32); a.qt[2] = (uint32_t)r; a.qt[3] = (uint32_t)(r >> 32);
     }
+    if (lane == 0 && blockIdx.x < 8192) { k1t_timeline[2 * blockIdx.x] = rt0; k1t_timeline[2 * blockIdx.x + 1] = __builtin_amdgcn_s_memrealtime(); }
 #endif
 }
 
