@@ -120,6 +120,7 @@ struct Comm;
 
 struct amr_handle {
     int device = 0;
+    int n_cus = 256;            // compute units of the device (K1 launches one chip-filling round at a time)
     amr_geometry geom{};
     amr::SearchGeom sg{};
     std::vector<int> proto_pid;
@@ -511,7 +512,20 @@ amr_status submit(amr_handle *h, const uint8_t *d_iq, size_t n_blocks, bool sear
 
     s.timed = h->timing_level;
     hipEvent_t e0 = s.timed ? s.ev0 : nullptr, e1 = s.timed ? s.ev1 : nullptr;
-    if (full) { k1.wg_first = 0; launch_k1<false>(h->geom.chip_length, dim3(full), st, k1, e0, rem ? nullptr : e1); }
+    // One launch per "round" for long blocks: K1 holds 8 waves per CU, and a launch that exactly fills the chip keeps its
+    // waves in step -- all of them read together and write their output bursts together.  A larger grid runs the later
+    // rounds out of step (output stores trickle into the read stream all the time): BlockSize 4096, 4 GiB: 0.895 ms in
+    // one launch, 4 x 0.179 ms in four; IDM (BlockSize 8192, 4 GiB) 0.860 -> 0.804 ms.  Short blocks (a round lasts
+    // under 0.1 ms) lose more at the extra launch boundaries than they gain: BlockSize 2048 0.182 -> 0.256 ms, so they
+    // keep the single launch.  AMR_K1_ROUND=0 / =N: never split / rounds of N wave-tiles.
+    static const int round_env = [] { const char *e = getenv("AMR_K1_ROUND"); return e ? atoi(e) : -1; }();
+    const uint32_t round = round_env == 0 ? full : round_env > 0 ? (uint32_t)round_env
+                         : bs >= 4096 ? (uint32_t)h->n_cus * 8u : full;
+    for (uint32_t w0 = 0; w0 < full; w0 += round) {
+        const uint32_t n = std::min(round, full - w0);
+        k1.wg_first = w0;
+        launch_k1<false>(h->geom.chip_length, dim3(n), st, k1, w0 == 0 ? e0 : nullptr, (w0 + n == full && !rem) ? e1 : nullptr);
+    }
     if (rem) { k1.wg_first = full; launch_k1<true>(h->geom.chip_length, dim3(1), st, k1, full ? nullptr : e0, e1); }
     HIP_TRY(hipGetLastError());
     AMR_DBG(st, "k1_demod");
@@ -814,6 +828,7 @@ amr_status amr_create(const amr_protocol *protos, int32_t n_protos, int32_t devi
     amr_handle *h = new (std::nothrow) amr_handle();
     if (!h) return fail(AMR_ENOMEM, "new amr_handle");
     h->device = device_id;
+    h->n_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     h->dense_search = getenv("AMR_DENSE_SEARCH") != nullptr;   // test hook: force the fallback search kernel
     if (const char *hc = getenv("AMR_HIT_CAP")) h->init_hit_cap = std::max<uint64_t>(256, strtoull(hc, nullptr, 10));
 
