@@ -212,6 +212,7 @@ def main():
     ap.add_argument("--workload", default="cfg2", help="cfg2 (default), cfg3, cfg4:<chip>, cfg5")
     ap.add_argument("--blocks", type=int, default=0, help="blocks per GPU per step (default: the workload's size)")
     ap.add_argument("--spinup-ms", type=float, default=250.0, help="untimed passes before the warm-up (shader clock ramp)")
+    ap.add_argument("--depth", type=int, default=3, help="batches in flight (1..3)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-verify", action="store_true", help="skip the golden hit count / planted message check")
     ap.add_argument("--write-golden", action="store_true", help="record this run's hit count as the workload's golden count")
@@ -300,7 +301,8 @@ def main():
         return br
 
     def run(n, level, every=1):
-        """n steps through the two-deep pipeline: the GPU runs batch i+1 while the host reads back batch i.
+        """n steps through the pipeline, --depth batches in flight (3: the GPU runs batches i+1 and i+2 while the host
+        reads back batch i, and K3 of batch i runs next to the search of batch i+1).
         Steps 0, every, 2*every, ... carry timing events of the given level (every=0: none)."""
         out, timed = [], []
 
@@ -310,11 +312,17 @@ def main():
             dec.submit_device(d_iq.value, n_blocks)
             timed.append(t)
 
-        submit(0)
-        for i in range(1, n):
+        depth = max(1, min(args.depth, 3))
+        for i in range(min(depth - 1, n)):
             submit(i)
-            out.append((finish(), dec.timing() if timed[i - 1] else None))
-        out.append((finish(), dec.timing() if timed[n - 1] else None))
+        done = 0
+        for i in range(depth - 1, n):
+            submit(i)
+            out.append((finish(), dec.timing() if timed[done] else None))
+            done += 1
+        while done < n:
+            out.append((finish(), dec.timing() if timed[done] else None))
+            done += 1
         return out
 
     # Timing events cost a ~5 us stream bubble each: the warm-up steps carry the full set

@@ -190,8 +190,9 @@ amr_status amr_decode_batch_device(amr_handle *h, const void *d_iq, size_t n_blo
 /*
  * Pipelined form for throughput-oriented callers (file replay, many-SDR aggregation): submit
  * enqueues a batch and returns immediately, collect waits for the OLDEST submitted batch and returns
- * its result.  At most two batches may be in flight; the GPU then runs batch i+1 while the host reads
- * back and parses batch i.  amr_decode_batch_device == submit + collect.  A result stays valid until
+ * its result.  At most three batches may be in flight; the GPU then runs batches i+1 and i+2 while the host
+ * reads back and parses batch i, and with two or more in flight the slicing of batch i (K3) shares the GPU with the
+ * search of batch i+1 instead of waiting in front of its demodulation.  amr_decode_batch_device == submit + collect.  A result stays valid until
  * the second submit after the collect that returned it.  d_iq must stay untouched until collected.
  */
 amr_status amr_submit_device(amr_handle *h, const void *d_iq, size_t n_blocks);

@@ -105,6 +105,9 @@ struct Slot {
     uint64_t *h_done = nullptr;   // pinned, coherent: the batch's last kernel stores the batch ticket here
     uint64_t ticket = 0;          // value that marks the batch in flight as complete
     int timed = 0;                // timing level the batch in flight was submitted with
+    bool tail_enqueued = true;    // K3.. of the batch in flight have been launched (false: collect launches them)
+    bool tail_split = false;      // ... on the second stream
+    hipEvent_t ev_k2 = nullptr, ev_t = nullptr;   // K2 stop, K3 start (timing level 2 with the tail on the second stream)
     // the batch in flight
     bool pending = false, search = false;
     const uint8_t *d_iq = nullptr;
@@ -118,6 +121,12 @@ struct Slot {
 
 struct Comm;
 
+// Up to three batches in flight over four slots: the state update of batch i writes the history rows into the slot
+// batch i+1 will use, which must not belong to a batch that is still in flight.
+constexpr int kSlots = 4;
+constexpr int kMaxPending = 3;
+constexpr int kIqHist = 5;   // r900 IQ history buffers, rotating: a batch in flight keeps its own until it is collected
+
 struct amr_handle {
     int device = 0;
     int n_cus = 256;            // compute units of the device (K1 launches one chip-filling round at a time)
@@ -129,6 +138,12 @@ struct amr_handle {
     uint32_t hist_rows = 0;    // ceil(PL/BS)
 
     hipStream_t own_stream = nullptr, stream = nullptr, copy_stream = nullptr, h2d_stream = nullptr;
+    // K3 / K4 / K5 of batch i run here, next to the search of batch i+1, once the caller pipelines (lazy_tail)
+    hipStream_t tail_stream = nullptr;
+    bool lazy_tail = false;
+    bool allow_lazy = true;      // AMR_TAIL_OVERLAP=0: everything on one stream, as before
+    uint64_t *d_tail_done = nullptr;   // device word: ticket of the last batch whose second-stream part has finished
+    uint64_t *h_flags = nullptr;  // pinned: [0] ticket of the last batch whose search has started, [1] whose stream-A part is done
     bool timing_valid = false;
     amr_timing timing{};
     int timing_level = 0;
@@ -146,7 +161,7 @@ struct amr_handle {
 
     struct Comm *comm = nullptr;   // multi-GPU hit gather (amr_comm_init), see the section at the end of this file
 
-    Slot slot[2];
+    Slot slot[kSlots];
     int next_slot = 0;           // slot the next submit uses
     int n_pending = 0;           // submitted, not yet collected (oldest = next_slot - n_pending)
     int last_slot = -1;          // slot of the last collected batch (amr_copy_quantized, result storage)
@@ -160,7 +175,7 @@ struct amr_handle {
     bool validate = false;
     amr::ValRule rules[AMR_MAX_PREAMBLES] = {};
     uint64_t last_searched = 0;   // hits the search of the last collected batch found (before validation)
-    uint8_t *d_iqhist[3] = {nullptr, nullptr, nullptr};   // three, rotating: a batch in flight keeps its own for a re-run
+    uint8_t *d_iqhist[kIqHist] = {};   // rotating: a batch in flight keeps its own for K4 and for a re-run
     int iqhist_cur = 0;
     uint32_t iqhist_valid = 0;
 };
@@ -282,9 +297,12 @@ amr_status ensure_capacity(amr_handle *h, Slot &s, Slot &other, size_t n_blocks)
         AMR_TRY(dev_realloc(s.d_counts, st * h->sg.n_pre));
         s.cnt_tiles = st;
     }
-    // group sums: BOTH slots (the hist kernel of the batch in one slot zeroes those of the other), kept zero between uses
+    // group sums: this slot and the next one (the hist kernel of this batch zeroes those of the next), kept zero between
+    // uses.  Neither holds a batch in flight; the slots that do keep what their own batch was sized for.
     const uint32_t gw = (uint32_t)(amr::k2_groups((uint32_t)st) * h->sg.n_pre);
-    for (Slot &sl : h->slot) {
+    Slot *both[2] = {&s, &other};
+    for (Slot *slp : both) {
+        Slot &sl = *slp;
         if (gw <= sl.gcnt_words) continue;
         HIP_TRY(hipStreamSynchronize(h->stream));
         AMR_TRY(dev_realloc(sl.d_gcnt, gw));
@@ -307,10 +325,12 @@ bool k2_use_stream()
     return on;
 }
 
-// K2 + K3 (+ K4, K5) for the batch held by slot s (may be re-run after a capacity overflow).
-amr_status enqueue_search(amr_handle *h, Slot &s, bool rerun = false, bool dense = false)
+// The search of the batch held by slot s in two parts: K2 on stream `st`, then K3 (+ K4, K5) -- the "tail" -- on the
+// same stream at once (enqueue_search; also every re-run after a capacity overflow) or later on the second stream
+// (pipelined callers: collect() launches it when the next batch's K1 has finished, so that it runs next to that
+// batch's K2 instead of in front of its K1).  `split`: K2 gets a stop event of its own for timing level 2.
+amr_status enqueue_k2(amr_handle *h, Slot &s, hipStream_t st, bool rerun, bool dense, bool split)
 {
-    hipStream_t st = h->stream;
     const uint32_t n_pre = h->sg.n_pre;
     const uint32_t bs = (uint32_t)h->geom.block_size;
     amr::K2Args k2{};
@@ -333,6 +353,9 @@ amr_status enqueue_search(amr_handle *h, Slot &s, bool rerun = false, bool dense
         HIP_TRY(hipMemsetAsync(k2dbg, 0, (size_t)s.n_tiles * 128, st));
     }
     const bool t2 = s.timed >= 2;
+    hipEvent_t k2stop = (t2 && split) ? s.ev_k2 : nullptr;
+    k2.started = rerun ? nullptr : &h->h_flags[0];
+    k2.started_value = s.ticket;
     // the overflow word is zeroed by the previous batch's k_hist_update; only a re-run has to do it here
     if (rerun) {
         HIP_TRY(hipMemsetAsync(s.d_overflow, 0, 4, st));
@@ -354,7 +377,7 @@ amr_status enqueue_search(amr_handle *h, Slot &s, bool rerun = false, bool dense
 #define AMR_K2S_LAUNCH(S, DD, W)                                                                                       \
     do {                                                                                                             \
         HIP_TRY(hipFuncSetAttribute((const void *)amr::k2_search_stream<S, DD, W>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2)); \
-        hipExtLaunchKernelGGL((amr::k2_search_stream<S, DD, W>), dim3(grid), dim3(64 * W), lds2, st, t2 ? s.ev_s : nullptr, nullptr, 0, k2); \
+        hipExtLaunchKernelGGL((amr::k2_search_stream<S, DD, W>), dim3(grid), dim3(64 * W), lds2, st, t2 ? s.ev_s : nullptr, k2stop, 0, k2); \
     } while (0)
 #define AMR_K2S_W(S, DD)                                                                                             \
     do {                                                                                                             \
@@ -385,7 +408,7 @@ amr_status enqueue_search(amr_handle *h, Slot &s, bool rerun = false, bool dense
         HIP_TRY(hipFuncSetAttribute((const void *)amr::k2_search_fast<N, W, J>, hipFuncAttributeMaxDynamicSharedMemorySize, \
                                     (int)lds2));                                                                     \
         hipExtLaunchKernelGGL((amr::k2_search_fast<N, W, J>), dim3(s.n_tiles), dim3(64 * W), lds2, st, t2 ? s.ev_s : nullptr, \
-                              nullptr, 0, k2);                                                                       \
+                              k2stop, 0, k2);                                                                       \
     } while (0)
 #define AMR_K2_CASE(N)                                                                                              \
     case N:                                                                                                          \
@@ -399,7 +422,7 @@ amr_status enqueue_search(amr_handle *h, Slot &s, bool rerun = false, bool dense
         const size_t lds2 = ((size_t)h->sg.wpb * 65 + 8) * 4;
         HIP_TRY(hipFuncSetAttribute((const void *)amr::k2_search_dense, hipFuncAttributeMaxDynamicSharedMemorySize,
                                     (int)lds2));
-        hipExtLaunchKernelGGL(amr::k2_search_dense, dim3(s.n_tiles), dim3(256), lds2, st, t2 ? s.ev_s : nullptr, nullptr, 0, k2);
+        hipExtLaunchKernelGGL(amr::k2_search_dense, dim3(s.n_tiles), dim3(256), lds2, st, t2 ? s.ev_s : nullptr, k2stop, 0, k2);
     }
     if (k2.dbg && (++k2dbg_calls == 6 || k2dbg_calls == 400)) {   // phase timestamps of the 6th search: mean duration of each phase over the workgroups
         HIP_TRY(hipStreamSynchronize(st));
@@ -441,14 +464,22 @@ amr_status enqueue_search(amr_handle *h, Slot &s, bool rerun = false, bool dense
                 pc(durs, .1), pc(durs, .5), pc(durs, .9), pc(durs, 1.0));
     }
     AMR_DBG(st, "k2_search");
+    return AMR_OK;
+}
+
+amr_status enqueue_tail(amr_handle *h, Slot &s, hipStream_t st, bool split)
+{
+    const uint32_t n_pre = h->sg.n_pre;
+    const uint32_t bs = (uint32_t)h->geom.block_size;
+    const bool t2 = s.timed >= 2;
     amr::K3Args k3{};
     k3.qt = s.d_qt; k3.counts = s.d_counts; k3.gcnt = s.d_gcnt; k3.staging = s.d_staging;
     k3.out = s.d_out; k3.offs_pre = s.d_offs_pre; k3.h_offs_pre = s.h_off; k3.h_overflow = s.h_ovf;
     k3.out_cap = s.out_cap; k3.overflow = s.d_overflow;
     k3.block_base = s.calls_base; k3.n_tiles = s.n_tiles; k3.cap = s.stage_cap; k3.g = h->sg;
     static const bool k3_old = [] { const char *e = getenv("AMR_K3_IMPL"); return e && strcmp(e, "old") == 0; }();
-    if (k3_old) hipExtLaunchKernelGGL(amr::k3_slice, dim3(s.n_tiles, n_pre), dim3(256), 0, st, nullptr, t2 ? s.ev2 : nullptr, 0, k3);
-    else hipExtLaunchKernelGGL(amr::k3_slice_words, dim3(s.n_tiles, n_pre), dim3(256), 0, st, nullptr, t2 ? s.ev2 : nullptr, 0, k3);
+    if (k3_old) hipExtLaunchKernelGGL(amr::k3_slice, dim3(s.n_tiles, n_pre), dim3(256), 0, st, (t2 && split) ? s.ev_t : nullptr, t2 ? s.ev2 : nullptr, 0, k3);
+    else hipExtLaunchKernelGGL(amr::k3_slice_words, dim3(s.n_tiles, n_pre), dim3(256), 0, st, (t2 && split) ? s.ev_t : nullptr, t2 ? s.ev2 : nullptr, 0, k3);
     HIP_TRY(hipGetLastError());
     AMR_DBG(st, "k3_slice");
     if (h->r900_pid >= 0) {
@@ -479,20 +510,28 @@ amr_status enqueue_search(amr_handle *h, Slot &s, bool rerun = false, bool dense
     return AMR_OK;
 }
 
+amr_status enqueue_search(amr_handle *h, Slot &s, bool rerun = false, bool dense = false)
+{
+    AMR_TRY(enqueue_k2(h, s, h->stream, rerun, dense, false));
+    return enqueue_tail(h, s, h->stream, false);
+}
+
 // Enqueue one batch on the compute stream: K1, (search), history + carry update.  Returns at once.
 amr_status submit(amr_handle *h, const uint8_t *d_iq, size_t n_blocks, bool search)
 {
     HIP_TRY(hipSetDevice(h->device));
     if (n_blocks == 0 || n_blocks > 0x7fffffffull) return fail(AMR_EINVAL, "n_blocks out of range");
-    if (h->n_pending >= 2) return fail(AMR_EINVAL, "two batches already in flight: call amr_collect first");
+    if (h->n_pending >= kMaxPending) return fail(AMR_EINVAL, "three batches already in flight: call amr_collect first");
     Slot &s = h->slot[h->next_slot];
-    Slot &other = h->slot[h->next_slot ^ 1];
+    Slot &other = h->slot[(h->next_slot + 1) % kSlots];   // the slot the next batch will use: never one in flight
+    const Slot &prev = h->slot[(h->next_slot + kSlots - 1) % kSlots];   // the batch submitted before this one
     AMR_TRY(ensure_capacity(h, s, other, n_blocks));
     hipStream_t st = h->stream;
     const uint32_t bs = (uint32_t)h->geom.block_size;
     const uint32_t full = (uint32_t)(n_blocks / 64), rem = (uint32_t)(n_blocks % 64);
 
     s.tile0_saved = false;
+    s.ticket = h->next_ticket++;
     s.d_iq = d_iq;
     s.n_blocks = n_blocks;
     s.n_tiles = (uint32_t)((n_blocks + 63) / 64) + 1;
@@ -531,11 +570,21 @@ amr_status submit(amr_handle *h, const uint8_t *d_iq, size_t n_blocks, bool sear
     AMR_DBG(st, "k1_demod");
     s.dense = h->dense_hold > 0;
     if (s.dense) h->dense_hold--;
-    if (search) AMR_TRY(enqueue_search(h, s, false, s.dense));
+    // A caller that keeps batches in flight gets K3 (K4, K5) of this batch on the second stream, launched by collect()
+    // when the NEXT batch's K1 has finished: they then share the machine with that batch's search (which leaves room)
+    // instead of standing between two K1 launches (which do not).
+    const bool lazy = search && h->allow_lazy && (h->lazy_tail || h->n_pending >= 1);
+    if (lazy) h->lazy_tail = true;
+    if (search) {
+        if (lazy) AMR_TRY(enqueue_k2(h, s, st, false, s.dense, true));
+        else AMR_TRY(enqueue_search(h, s, false, s.dense));
+    }
+    s.tail_enqueued = !lazy;
+    s.tail_split = lazy;
 
     if (h->r900_pid >= 0) {   // the PL samples that precede the next batch (r900.go:168-170 keeps them as magnitudes)
         const uint64_t n_batch = (uint64_t)n_blocks * bs;
-        const int nxt = (h->iqhist_cur + 1) % 3;
+        const int nxt = (h->iqhist_cur + 1) % kIqHist;
         amr::IqHistArgs ih{d_iq, h->d_iqhist[h->iqhist_cur], h->d_iqhist[nxt], n_batch, (uint32_t)h->geom.packet_length};
         hipLaunchKernelGGL(amr::k_iqhist_update, dim3(32), dim3(256), 0, st, ih);
         HIP_TRY(hipGetLastError());
@@ -548,7 +597,8 @@ amr_status submit(amr_handle *h, const uint8_t *d_iq, size_t n_blocks, bool sear
     amr::HistArgs ha{s.d_qt, other.d_qt, (uint32_t)n_blocks, h->hist_rows, h->sg.wpb, h->sg.lg_wpb,
                      d_iq + n_blocks * (size_t)h->geom.block_size2 - h->halo_bytes, h->d_carry, h->halo_bytes, other.d_overflow,
                      other.d_gcnt, other.gcnt_words, other.pending ? other.d_hist_save : nullptr,
-                     s.h_done, s.ticket = h->next_ticket++};
+                     lazy ? nullptr : s.h_done, s.ticket, &h->h_flags[1],
+                     (prev.pending && prev.search && prev.tail_split) ? h->d_tail_done : nullptr, prev.ticket};
     other.tile0_saved = other.pending;
     hipLaunchKernelGGL(amr::k_hist_update, dim3(1), dim3(1024), (size_t)h->hist_rows * h->sg.wpb * 4, st, ha);
     HIP_TRY(hipGetLastError());
@@ -557,7 +607,7 @@ amr_status submit(amr_handle *h, const uint8_t *d_iq, size_t n_blocks, bool sear
     if (search) h->calls_done += n_blocks;
     s.pending = true;
     h->n_pending++;
-    h->next_slot ^= 1;
+    h->next_slot = (h->next_slot + 1) % kSlots;
     return AMR_OK;
 }
 
@@ -572,29 +622,35 @@ static inline void cpu_relax()
 #endif
 }
 
-amr_status wait_done(amr_handle *h, Slot &s)
+// Spin until the pinned word `flag` reaches `value`; `st` is the stream whose completion guarantees it.
+amr_status wait_flag(const uint64_t *flag, uint64_t value, hipStream_t st)
 {
     // three stages: a short busy spin (a batch in steady state completes within tens of microseconds of the call),
     // then spinning with sched_yield so that parser threads and the other ranks' hosts get the core, and after ~2 ms a
     // blocking hipStreamSynchronize (which also surfaces a device fault)
     for (uint64_t spin = 0;; ++spin) {
-        if (__atomic_load_n(s.h_done, __ATOMIC_ACQUIRE) >= s.ticket) return AMR_OK;
+        if (__atomic_load_n(flag, __ATOMIC_ACQUIRE) >= value) return AMR_OK;
         if (spin < 4096) { cpu_relax(); continue; }
         if ((spin & 0xff) == 0) {
-            hipError_t e = hipStreamQuery(h->stream);
+            hipError_t e = hipStreamQuery(st);
             if (e == hipSuccess) {   // everything submitted has run: the ticket must be there now
-                if (__atomic_load_n(s.h_done, __ATOMIC_ACQUIRE) >= s.ticket) return AMR_OK;
+                if (__atomic_load_n(flag, __ATOMIC_ACQUIRE) >= value) return AMR_OK;
                 return fail(AMR_EHIP, "batch finished without publishing its ticket");
             }
             if (e != hipErrorNotReady) return fail(AMR_EHIP, "hipStreamQuery", e);
         }
         if (spin > 4096 + 20000) {
-            HIP_TRY(hipStreamSynchronize(h->stream));
-            if (__atomic_load_n(s.h_done, __ATOMIC_ACQUIRE) >= s.ticket) return AMR_OK;
+            HIP_TRY(hipStreamSynchronize(st));
+            if (__atomic_load_n(flag, __ATOMIC_ACQUIRE) >= value) return AMR_OK;
             return fail(AMR_EHIP, "batch finished without publishing its ticket");
         }
         sched_yield();
     }
+}
+
+amr_status wait_done(amr_handle *h, Slot &s)
+{
+    return wait_flag(s.h_done, s.ticket, s.tail_split ? h->tail_stream : h->stream);
 }
 
 // Wait for the oldest batch in flight, grow capacities / re-run the search if it overflowed, read back hits.
@@ -602,10 +658,23 @@ amr_status collect(amr_handle *h, amr_result *res)
 {
     HIP_TRY(hipSetDevice(h->device));
     if (h->n_pending == 0) return fail(AMR_EINVAL, "amr_collect: nothing in flight");
-    const int si = (h->n_pending == 2) ? h->next_slot : (h->next_slot ^ 1);
+    const int si = (h->next_slot - h->n_pending + kSlots) % kSlots;
     Slot &s = h->slot[si];
     const uint32_t n_pre = h->sg.n_pre;
+    if (s.search && !s.tail_enqueued) {
+        // K3 (K4, K5) of this batch, on the second stream.  They need the batch's K2 to have finished; they are held
+        // back until the NEXT batch's K1 has finished as well (its search announces itself in h_flags[0]): next to a
+        // K1 launch, which fills every wave slot of the chip, they would only delay some of its waves.
+        const Slot *nx = h->n_pending >= 2 ? &h->slot[(si + 1) % kSlots] : nullptr;
+        if (nx && nx->search) AMR_TRY(wait_flag(&h->h_flags[0], nx->ticket, h->stream));
+        else AMR_TRY(wait_flag(&h->h_flags[1], s.ticket, h->stream));
+        AMR_TRY(enqueue_tail(h, s, h->tail_stream, true));
+        hipLaunchKernelGGL(amr::k_done, dim3(1), dim3(1), 0, h->tail_stream, s.h_done, s.ticket, h->d_tail_done);
+        HIP_TRY(hipGetLastError());
+        s.tail_enqueued = true;
+    }
     AMR_TRY(wait_done(h, s));
+    if (h->n_pending == 1) h->lazy_tail = false;   // nothing else in flight: the caller is not pipelining (any more)
     uint64_t total = 0, searched = 0;
     bool use_dense = s.dense, swapped = false;
     if (s.search) {
@@ -687,7 +756,11 @@ amr_status collect(amr_handle *h, amr_result *res)
     float a = 0, b = 0, c = 0;
     h->timing_valid = false;
     if (s.timed && hipEventSynchronize(s.ev1) == hipSuccess && hipEventElapsedTime(&a, s.ev0, s.ev1) == hipSuccess) {
-        if (s.timed >= 2 && s.search && hipEventSynchronize(s.ev2) == hipSuccess &&
+        float b2 = 0;
+        if (s.timed >= 2 && s.search && s.tail_split && hipEventSynchronize(s.ev2) == hipSuccess &&
+            hipEventElapsedTime(&b, s.ev_s, s.ev_k2) == hipSuccess && hipEventElapsedTime(&b2, s.ev_t, s.ev2) == hipSuccess)
+            h->timing = amr_timing{a, b + b2, a + b + b2};   // K2 and the tail ran apart: their durations, added up
+        else if (s.timed >= 2 && s.search && !s.tail_split && hipEventSynchronize(s.ev2) == hipSuccess &&
             hipEventElapsedTime(&b, s.ev_s, s.ev2) == hipSuccess && hipEventElapsedTime(&c, s.ev0, s.ev2) == hipSuccess)
             h->timing = amr_timing{a, b, c};
         else
@@ -850,12 +923,20 @@ amr_status amr_create(const amr_protocol *protos, int32_t n_protos, int32_t devi
     if (e == hipSuccess) e = hipStreamCreateWithFlags(&h->own_stream, hipStreamNonBlocking);
     if (e == hipSuccess) e = hipStreamCreateWithFlags(&h->copy_stream, hipStreamNonBlocking);
     if (e == hipSuccess) e = hipStreamCreateWithFlags(&h->h2d_stream, hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipStreamCreateWithFlags(&h->tail_stream, hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipHostMalloc((void **)&h->h_flags, 16, hipHostMallocCoherent);
+    if (e == hipSuccess) { h->h_flags[0] = 0; h->h_flags[1] = 0; }
+    if (e == hipSuccess) e = hipMalloc((void **)&h->d_tail_done, 8);
+    if (e == hipSuccess) e = hipMemset(h->d_tail_done, 0, 8);
+    if (const char *ov = getenv("AMR_TAIL_OVERLAP")) h->allow_lazy = ov[0] != '0';
     h->stream = h->own_stream;
     for (Slot &sl : h->slot) {
         if (e == hipSuccess) e = hipEventCreate(&sl.ev0);
         if (e == hipSuccess) e = hipEventCreate(&sl.ev1);
         if (e == hipSuccess) e = hipEventCreate(&sl.ev2);
         if (e == hipSuccess) e = hipEventCreate(&sl.ev_s);
+        if (e == hipSuccess) e = hipEventCreate(&sl.ev_k2);
+        if (e == hipSuccess) e = hipEventCreate(&sl.ev_t);
         if (e == hipSuccess) e = hipEventCreateWithFlags(&sl.ev_h2d, hipEventDisableTiming);
         if (e == hipSuccess) e = hipHostMalloc((void **)&sl.h_done, 8, hipHostMallocCoherent);
         if (e == hipSuccess) *sl.h_done = 0;
@@ -895,9 +976,12 @@ amr_status amr_destroy(amr_handle *h)
     if (!h) return AMR_OK;
     (void)hipSetDevice(h->device);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
+    if (h->tail_stream) (void)hipStreamSynchronize(h->tail_stream);
     if (h->copy_stream) (void)hipStreamSynchronize(h->copy_stream);
-    void *ptrs[] = {h->d_lut, h->d_carry, h->d_iq, h->d_untile, h->d_iqhist[0], h->d_iqhist[1], h->d_iqhist[2]};
+    void *ptrs[] = {h->d_lut, h->d_carry, h->d_iq, h->d_untile, h->d_tail_done};
     for (void *p : ptrs) if (p) (void)hipFree(p);
+    for (uint8_t *p : h->d_iqhist) if (p) (void)hipFree(p);
+    if (h->h_flags) (void)hipHostFree(h->h_flags);
     for (Slot &sl : h->slot) {
         void *dp[] = {sl.d_qt, sl.d_counts, sl.d_gcnt, sl.d_offs_pre, sl.d_overflow, sl.d_staging, sl.d_out, sl.d_iq_stage, sl.d_r900,
                       sl.d_val, sl.d_keep, sl.d_chunk, sl.d_offs_val, sl.d_hist_save};
@@ -906,7 +990,7 @@ amr_status amr_destroy(amr_handle *h)
         for (void *p : dp) if (p) (void)hipFree(p);
         void *hp[] = {sl.h_off, sl.h_ovf, sl.h_out, sl.h_offv};
         for (void *p : hp) if (p) (void)hipHostFree(p);
-        hipEvent_t evs[] = {sl.ev0, sl.ev1, sl.ev_s, sl.ev2};
+        hipEvent_t evs[] = {sl.ev0, sl.ev1, sl.ev_s, sl.ev2, sl.ev_k2, sl.ev_t};
         if (sl.h_done) (void)hipHostFree(sl.h_done);
         for (hipEvent_t ev : evs) if (ev) (void)hipEventDestroy(ev);
     }
@@ -914,6 +998,7 @@ amr_status amr_destroy(amr_handle *h)
     if (h->own_stream) (void)hipStreamDestroy(h->own_stream);
     if (h->copy_stream) (void)hipStreamDestroy(h->copy_stream);
     if (h->h2d_stream) (void)hipStreamDestroy(h->h2d_stream);
+    if (h->tail_stream) (void)hipStreamDestroy(h->tail_stream);
     delete h;
     return AMR_OK;
 }
@@ -923,6 +1008,7 @@ amr_status amr_reset(amr_handle *h)
     if (!h) return fail(AMR_EINVAL, "null handle");
     HIP_TRY(hipSetDevice(h->device));
     AMR_TRY(drain(h));
+    HIP_TRY(hipStreamSynchronize(h->tail_stream));
     for (Slot &sl : h->slot)
         if (sl.d_qt) HIP_TRY(hipMemsetAsync(sl.d_qt, 0, (size_t)64 * h->sg.wpb * 4, h->stream));
     HIP_TRY(hipStreamSynchronize(h->stream));
@@ -1050,7 +1136,7 @@ amr_status amr_submit_host(amr_handle *h, const uint8_t *iq, size_t iq_bytes, si
     const size_t need = n_blocks * (size_t)h->geom.block_size2;
     if (iq_bytes < need) return fail(AMR_EINVAL, "short input (the Go decoder panics here, decode.go:222)");
     if (n_blocks == 0) return fail(AMR_EINVAL, "n_blocks out of range");
-    if (h->n_pending >= 2) return fail(AMR_EINVAL, "two batches already in flight: call amr_collect first");
+    if (h->n_pending >= kMaxPending) return fail(AMR_EINVAL, "three batches already in flight: call amr_collect first");
     HIP_TRY(hipSetDevice(h->device));
     Slot &s = h->slot[h->next_slot];   // the slot submit() is about to use; its previous batch has been collected
     if (need > s.iq_stage_cap) {

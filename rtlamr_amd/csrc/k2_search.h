@@ -56,8 +56,18 @@ struct K2Args {
     int64_t n_lo, n_hi;    // valid positions: n_lo <= n < n_hi, n relative to batch sample 0
     unsigned long long *dbg;   // developer diagnostics (AMR_K2_DBG): 16 words of timestamps per workgroup, or null
     uint32_t xcd;              // stream kernel: XCD-contiguous tile order (the grid is then 8 * ceil(n_tiles / 8))
+    // pinned host word that receives `started_value` when the search starts, i.e. when everything before it on the
+    // stream (this batch's K1) has finished: the host then launches the previous batch's K3 on the second stream
+    uint64_t *started;
+    uint64_t started_value;
     SearchGeom g;
 };
+
+__device__ __forceinline__ void k2_announce(const K2Args &a)
+{
+    if (a.started && blockIdx.x == 0 && threadIdx.x == 0)
+        __hip_atomic_store(a.started, a.started_value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
 
 // Index of word w (32 decisions) of tiled row R (row 64 + b = batch block b; rows 0..63 = history tile) in the
 // "tiled4" bitstream K1 writes: per 64-row tile, 4-word chunks, a row's chunk = 16 contiguous bytes.
@@ -80,6 +90,7 @@ __host__ __device__ __forceinline__ uint32_t k2_groups(uint32_t n_tiles) { retur
 
 __global__ __launch_bounds__(256) void k2_search_dense(const K2Args a)
 {
+    k2_announce(a);
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];  // wpb*65 words + 8 counters
     const SearchGeom &g = a.g;
     const uint32_t T = blockIdx.x;
@@ -200,6 +211,7 @@ __device__ __forceinline__ uint32_t k2_depth(uint32_t npre) { return (uint32_t)A
 template <int NPRE, int NWV, int JW>
 __global__ __launch_bounds__(64 * NWV) void k2_search_fast(const K2Args a)
 {
+    k2_announce(a);
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
     const uint32_t T = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
     // the wave index is wave-uniform, but hipcc cannot know that of tid >> 6: without readfirstlane the whole
@@ -727,6 +739,15 @@ struct HistArgs {
     // completion ticket of the batch, stored to pinned host memory by the last thread of this last kernel
     uint64_t *done_flag;
     uint64_t done_value;
+    // ticket of the stream-A part of the batch (K1, search, this kernel), always published; done_flag may be null
+    // when K3 and what follows it run later on the second stream and publish the batch ticket themselves
+    uint64_t *adone_flag;
+    // Pipelined callers: K3.. of the PREVIOUS batch run on the second stream next to this batch's search.  When they
+    // take longer than the search, the next K1 launch (which needs every wave slot of the chip) has to wait for them:
+    // this kernel, the last one in front of it, spins until the device word `wait_flag` reaches `wait_value`
+    // (k_done of that batch) -- for at most ~2 ms, in case the host never launches them.
+    const uint64_t *wait_flag;
+    uint64_t wait_value;
 };
 
 __global__ __launch_bounds__(1024) void k_hist_update(const HistArgs a)
@@ -752,7 +773,23 @@ __global__ __launch_bounds__(1024) void k_hist_update(const HistArgs a)
     }
     __syncthreads();
     // every earlier kernel of the batch has completed (same stream); the host polls this word
-    if (threadIdx.x == 0) __hip_atomic_store(a.done_flag, a.done_value, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    if (threadIdx.x == 0) {
+        if (a.adone_flag) __hip_atomic_store(a.adone_flag, a.done_value, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        if (a.done_flag) __hip_atomic_store(a.done_flag, a.done_value, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        if (a.wait_flag) {
+            const uint64_t t0 = __builtin_amdgcn_s_memrealtime();   // 100 MHz
+            while (__hip_atomic_load(a.wait_flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < a.wait_value &&
+                   __builtin_amdgcn_s_memrealtime() - t0 < 200000ull)
+                __builtin_amdgcn_s_sleep(32);
+        }
+    }
+}
+
+// last kernel of a batch whose K3 (K4, K5) ran on the second stream: publishes the batch ticket
+__global__ void k_done(uint64_t *flag, uint64_t value, uint64_t *dev_flag)
+{
+    __hip_atomic_store(dev_flag, value, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);   // k_hist_update of the next batch waits here
+    __hip_atomic_store(flag, value, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
 // Exchange the history rows of tile 0 with their saved copy (before and after a re-run of a search whose slot has

@@ -184,6 +184,7 @@ __global__ __launch_bounds__(64 * NWV, AMR_K2S_OCC) void k2_search_stream(const 
 #define K2S_STAMP(i) do { if (a.dbg && threadIdx.x == 0) a.dbg[(size_t)blockIdx.x * 16 + (i)] = __builtin_readcyclecounter(); } while (0)
     // a.xcd: workgroup b runs on XCD b % 8; give every XCD one contiguous run of tiles (the grid is rounded up to 8 runs)
     const uint32_t T = a.xcd ? (blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3) : blockIdx.x;
+    k2_announce(a);
     if (T >= a.n_tiles) return;
     K2S_STAMP(0);
     if (a.dbg && threadIdx.x == 0) a.dbg[(size_t)blockIdx.x * 16 + 8] = __builtin_amdgcn_s_memrealtime();

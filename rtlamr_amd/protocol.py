@@ -319,7 +319,7 @@ class Decoder:
         return self._collect(res, n_blocks, first)
 
     def submit_device(self, d_ptr: int, n_blocks: int) -> None:
-        """Pipelined form: enqueue a device-resident batch and return (at most two in flight)."""
+        """Pipelined form: enqueue a device-resident batch and return (at most three in flight)."""
         _lib.check(_lib.lib().amr_submit_device(self._require(), C.c_void_p(d_ptr), n_blocks), "amr_submit_device")
         self._inflight.append((n_blocks, self._calls + self._block_base))
         self._calls += n_blocks

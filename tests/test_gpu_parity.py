@@ -301,9 +301,10 @@ def test_error_paths_return_status_not_crash():
         buf.array[:] = 127
         dec.submit_host(buf.array)
         dec.submit_host(buf.array)
-        with pytest.raises(_lib.AmrError):
+        dec.submit_host(buf.array)
+        with pytest.raises(_lib.AmrError):   # a fourth batch in flight
             dec.submit_host(buf.array)
-        dec.collect(); dec.collect()
+        dec.collect(); dec.collect(); dec.collect()
         buf.free()
     finally:
         dec.close()
@@ -340,3 +341,47 @@ def test_ragged_and_empty_inputs():
             fresh.close()
     finally:
         dec.close()
+
+
+def test_three_batches_in_flight_and_the_fourth_is_refused():
+    """amr_submit_device: up to three batches in flight; with two or more in flight K3 of a batch runs on the second
+    stream next to the search of the batch behind it.  Results in submission order, equal to the oracle's."""
+    import ctypes as C
+    from rtlamr_amd import _lib
+    L = _lib.lib()
+    dec = util.make_decoder(["scm"], 72)
+    bufs = []
+    try:
+        bs2 = dec.Cfg.BlockSize2
+        sizes = [70, 64, 1, 130, 65, 3, 128]
+        iq, _ = util.synth_stream(["scm"], 72, sum(sizes), dec.Cfg.BlockSize, seed=41, n_packets=14)
+        want = util.oracle_run(["scm"], 72, iq)
+        got, pos, inflight = [], 0, 0
+        for k, nb in enumerate(sizes):
+            part = np.ascontiguousarray(iq[pos * bs2:(pos + nb) * bs2])
+            d = C.c_void_p()
+            _lib.check(L.amr_dev_alloc(0, part.size, C.byref(d)), "alloc")
+            _lib.check(L.amr_dev_upload(0, d, part.ctypes.data, part.size), "upload")
+            bufs.append(d)
+            dec.submit_device(d.value, nb)
+            inflight += 1
+            pos += nb
+            if inflight == 3:
+                if k == 2:   # a fourth submit is an argument error and leaves the three in flight alone
+                    assert L.amr_submit_device(dec._require(), d, nb) == _lib.AMR_EINVAL
+                got.append(dec.collect()); inflight -= 1
+        while inflight:
+            got.append(dec.collect()); inflight -= 1
+        hs, ps = [], []
+        for br in got:
+            blk, idx, pk = br.for_preamble(0)
+            hs.append(np.stack([np.zeros(len(blk), np.int64), blk.astype(np.int64), idx.astype(np.int64)], axis=1))
+            ps.append(pk)
+        h, p = np.concatenate(hs), np.concatenate(ps)
+        assert np.array_equal(h, want[2]), "hits of the pipelined run differ from the oracle's"
+        nfull = dec.Cfg.PacketSymbols // 8
+        assert np.array_equal(p[:, :nfull], want[3][:, :nfull])
+    finally:
+        dec.close()
+        for d in bufs:
+            L.amr_dev_free(0, d)

@@ -70,7 +70,7 @@ def _stream_for(rng, protos, chip, bs):
 
 @pytest.mark.parametrize("seed", range(int(os.environ.get("AMR_RANDOM_SEEDS", "24"))))
 def test_random_pipeline_and_validation(seed):
-    """The pipelined entry points (two batches in flight, host or device input) with and without the on-device
+    """The pipelined entry points (two or three batches in flight, host or device input) with and without the on-device
     validation, against the oracle (filtered by oracle/validate_oracle.py when validation is on)."""
     import ctypes as C
     from oracle import validate_oracle as vo
@@ -112,8 +112,11 @@ def test_random_pipeline_and_validation(seed):
                 got_p.append(pk)
 
         pos, inflight = 0, 0
+        depth = int(rng.integers(2, 4))               # two or three batches in flight
+        parts = []
         for nb in split:
             part = np.ascontiguousarray(iq[pos * bs2:(pos + nb) * bs2])
+            parts.append(part)                        # host input must stay untouched until collected
             if host_input:
                 dec.submit_host(part)
             else:
@@ -124,7 +127,7 @@ def test_random_pipeline_and_validation(seed):
                 dec.submit_device(d.value, nb)
             inflight += 1
             pos += nb
-            if inflight == 2:
+            if inflight == depth:
                 take(dec.collect()); inflight -= 1
         while inflight:
             take(dec.collect()); inflight -= 1
