@@ -108,6 +108,7 @@ struct Slot {
     bool tail_enqueued = true;    // K3.. of the batch in flight have been launched (false: collect launches them)
     bool tail_split = false;      // ... on the second stream
     hipEvent_t ev_k2 = nullptr, ev_t = nullptr;   // K2 stop, K3 start (timing level 2 with the tail on the second stream)
+    hipEvent_t ev_k1done = nullptr, ev_tail = nullptr;   // dependencies between the two streams (no timing)
     // the batch in flight
     bool pending = false, search = false;
     const uint8_t *d_iq = nullptr;
@@ -142,6 +143,10 @@ struct amr_handle {
     hipStream_t tail_stream = nullptr;
     bool lazy_tail = false;
     bool allow_lazy = true;      // AMR_TAIL_OVERLAP=0: everything on one stream, as before
+    // false (default): the host launches the tail when it sees the next batch's search start (a pinned flag; no event on
+    // the compute stream).  AMR_TAIL_MODE=event: stream dependencies instead -- robust against a slow host, but the two
+    // events per batch cost ~10 us of stream bubbles (cfg2: 0.237 ms per step against 0.227)
+    bool tail_events = false;
     uint64_t *d_tail_done = nullptr;   // device word: ticket of the last batch whose second-stream part has finished
     uint64_t *h_flags = nullptr;  // pinned: [0] ticket of the last batch whose search has started, [1] whose stream-A part is done
     bool timing_valid = false;
@@ -516,12 +521,15 @@ amr_status enqueue_search(amr_handle *h, Slot &s, bool rerun = false, bool dense
     return enqueue_tail(h, s, h->stream, false);
 }
 
+amr_status launch_ready_tails(amr_handle *h);
+
 // Enqueue one batch on the compute stream: K1, (search), history + carry update.  Returns at once.
 amr_status submit(amr_handle *h, const uint8_t *d_iq, size_t n_blocks, bool search)
 {
     HIP_TRY(hipSetDevice(h->device));
     if (n_blocks == 0 || n_blocks > 0x7fffffffull) return fail(AMR_EINVAL, "n_blocks out of range");
     if (h->n_pending >= kMaxPending) return fail(AMR_EINVAL, "three batches already in flight: call amr_collect first");
+    if (!h->tail_events) AMR_TRY(launch_ready_tails(h));
     Slot &s = h->slot[h->next_slot];
     Slot &other = h->slot[(h->next_slot + 1) % kSlots];   // the slot the next batch will use: never one in flight
     const Slot &prev = h->slot[(h->next_slot + kSlots - 1) % kSlots];   // the batch submitted before this one
@@ -551,6 +559,11 @@ amr_status submit(amr_handle *h, const uint8_t *d_iq, size_t n_blocks, bool sear
 
     s.timed = h->timing_level;
     hipEvent_t e0 = s.timed ? s.ev0 : nullptr, e1 = s.timed ? s.ev1 : nullptr;
+    // The batch submitted before this one left its K3.. for the second stream: they go there now, behind the end of
+    // THIS batch's K1 (its last launch carries the event), i.e. next to this batch's search.
+    Slot &prevm = h->slot[(h->next_slot + kSlots - 1) % kSlots];
+    const bool prev_tail_now = h->tail_events && prevm.pending && prevm.search && prevm.tail_split && !prevm.tail_enqueued;
+    if (prev_tail_now && !e1) e1 = s.ev_k1done;
     // One launch per "round" for long blocks: K1 holds 8 waves per CU, and a launch that exactly fills the chip keeps its
     // waves in step -- all of them read together and write their output bursts together.  A larger grid runs the later
     // rounds out of step (output stores trickle into the read stream all the time): BlockSize 4096, 4 GiB: 0.895 ms in
@@ -568,6 +581,14 @@ amr_status submit(amr_handle *h, const uint8_t *d_iq, size_t n_blocks, bool sear
     if (rem) { k1.wg_first = full; launch_k1<true>(h->geom.chip_length, dim3(1), st, k1, full ? nullptr : e0, e1); }
     HIP_TRY(hipGetLastError());
     AMR_DBG(st, "k1_demod");
+    if (prev_tail_now) {
+        HIP_TRY(hipStreamWaitEvent(h->tail_stream, e1, 0));
+        AMR_TRY(enqueue_tail(h, prevm, h->tail_stream, true));
+        hipLaunchKernelGGL(amr::k_done, dim3(1), dim3(1), 0, h->tail_stream, prevm.h_done, prevm.ticket, h->d_tail_done);
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipEventRecord(prevm.ev_tail, h->tail_stream));
+        prevm.tail_enqueued = true;
+    }
     s.dense = h->dense_hold > 0;
     if (s.dense) h->dense_hold--;
     // A caller that keeps batches in flight gets K3 (K4, K5) of this batch on the second stream, launched by collect()
@@ -594,11 +615,13 @@ amr_status submit(amr_handle *h, const uint8_t *d_iq, size_t n_blocks, bool sear
     }
     // state carried to the next batch (decode.go:165-166): last rows of this slot's bitstream become the
     // history tile of the OTHER slot (where the next batch runs); last HBA bytes of IQ become the carry
+    // the next K1 launch must not meet the previous batch's K3.. (it needs every wave slot): wait for them here
+    if (prev_tail_now) HIP_TRY(hipStreamWaitEvent(st, prevm.ev_tail, 0));
     amr::HistArgs ha{s.d_qt, other.d_qt, (uint32_t)n_blocks, h->hist_rows, h->sg.wpb, h->sg.lg_wpb,
                      d_iq + n_blocks * (size_t)h->geom.block_size2 - h->halo_bytes, h->d_carry, h->halo_bytes, other.d_overflow,
                      other.d_gcnt, other.gcnt_words, other.pending ? other.d_hist_save : nullptr,
                      lazy ? nullptr : s.h_done, s.ticket, &h->h_flags[1],
-                     (prev.pending && prev.search && prev.tail_split) ? h->d_tail_done : nullptr, prev.ticket};
+                     (!prev_tail_now && prev.pending && prev.search && prev.tail_split) ? h->d_tail_done : nullptr, prev.ticket};
     other.tile0_saved = other.pending;
     hipLaunchKernelGGL(amr::k_hist_update, dim3(1), dim3(1024), (size_t)h->hist_rows * h->sg.wpb * 4, st, ha);
     HIP_TRY(hipGetLastError());
@@ -653,6 +676,25 @@ amr_status wait_done(amr_handle *h, Slot &s)
     return wait_flag(s.h_done, s.ticket, s.tail_split ? h->tail_stream : h->stream);
 }
 
+// Launch, without waiting for anything, the second-stream part (K3..) of every batch in flight whose successor's search
+// has started (= the successor's K1 has finished), oldest first.  Called wherever the host passes by: submit, collect
+// and the wait for the read-back, so that a host that is busy copying results does not hold the GPU up.
+amr_status launch_ready_tails(amr_handle *h)
+{
+    for (int k = 0; k + 1 < h->n_pending; ++k) {
+        Slot &t = h->slot[(h->next_slot - h->n_pending + k + 2 * kSlots) % kSlots];
+        if (!t.search || t.tail_enqueued) continue;
+        const Slot &nx = h->slot[(h->next_slot - h->n_pending + k + 1 + 2 * kSlots) % kSlots];
+        const uint64_t *flag = nx.search ? &h->h_flags[0] : &h->h_flags[1];
+        if (__atomic_load_n(flag, __ATOMIC_ACQUIRE) < nx.ticket) break;   // in order: the tickets on the second stream rise
+        AMR_TRY(enqueue_tail(h, t, h->tail_stream, true));
+        hipLaunchKernelGGL(amr::k_done, dim3(1), dim3(1), 0, h->tail_stream, t.h_done, t.ticket, h->d_tail_done);
+        HIP_TRY(hipGetLastError());
+        t.tail_enqueued = true;
+    }
+    return AMR_OK;
+}
+
 // Wait for the oldest batch in flight, grow capacities / re-run the search if it overflowed, read back hits.
 amr_status collect(amr_handle *h, amr_result *res)
 {
@@ -661,6 +703,7 @@ amr_status collect(amr_handle *h, amr_result *res)
     const int si = (h->next_slot - h->n_pending + kSlots) % kSlots;
     Slot &s = h->slot[si];
     const uint32_t n_pre = h->sg.n_pre;
+    AMR_TRY(launch_ready_tails(h));
     if (s.search && !s.tail_enqueued) {
         // K3 (K4, K5) of this batch, on the second stream.  They need the batch's K2 to have finished; they are held
         // back until the NEXT batch's K1 has finished as well (its search announces itself in h_flags[0]): next to a
@@ -750,7 +793,14 @@ amr_status collect(amr_handle *h, amr_result *res)
                 }
                 if (nr) HIP_TRY(hipMemcpyAsync(s.h_r900, s.d_r900, nr * amr::kR900Digits, hipMemcpyDeviceToHost, h->copy_stream));
             }
-            HIP_TRY(hipStreamSynchronize(h->copy_stream));
+            // the read-back takes as long as a K1 launch: keep an eye on the batches behind this one meanwhile
+            for (;;) {
+                const hipError_t qe = hipStreamQuery(h->copy_stream);
+                if (qe == hipSuccess) break;
+                if (qe != hipErrorNotReady) return fail(AMR_EHIP, "hipStreamQuery(copy stream)", qe);
+                AMR_TRY(launch_ready_tails(h));
+                cpu_relax();
+            }
         }
     }
     float a = 0, b = 0, c = 0;
@@ -929,6 +979,7 @@ amr_status amr_create(const amr_protocol *protos, int32_t n_protos, int32_t devi
     if (e == hipSuccess) e = hipMalloc((void **)&h->d_tail_done, 8);
     if (e == hipSuccess) e = hipMemset(h->d_tail_done, 0, 8);
     if (const char *ov = getenv("AMR_TAIL_OVERLAP")) h->allow_lazy = ov[0] != '0';
+    if (const char *tm = getenv("AMR_TAIL_MODE")) h->tail_events = strcmp(tm, "event") == 0;
     h->stream = h->own_stream;
     for (Slot &sl : h->slot) {
         if (e == hipSuccess) e = hipEventCreate(&sl.ev0);
@@ -937,6 +988,8 @@ amr_status amr_create(const amr_protocol *protos, int32_t n_protos, int32_t devi
         if (e == hipSuccess) e = hipEventCreate(&sl.ev_s);
         if (e == hipSuccess) e = hipEventCreate(&sl.ev_k2);
         if (e == hipSuccess) e = hipEventCreate(&sl.ev_t);
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&sl.ev_k1done, hipEventDisableTiming);
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&sl.ev_tail, hipEventDisableTiming);
         if (e == hipSuccess) e = hipEventCreateWithFlags(&sl.ev_h2d, hipEventDisableTiming);
         if (e == hipSuccess) e = hipHostMalloc((void **)&sl.h_done, 8, hipHostMallocCoherent);
         if (e == hipSuccess) *sl.h_done = 0;
@@ -990,7 +1043,7 @@ amr_status amr_destroy(amr_handle *h)
         for (void *p : dp) if (p) (void)hipFree(p);
         void *hp[] = {sl.h_off, sl.h_ovf, sl.h_out, sl.h_offv};
         for (void *p : hp) if (p) (void)hipHostFree(p);
-        hipEvent_t evs[] = {sl.ev0, sl.ev1, sl.ev_s, sl.ev2, sl.ev_k2, sl.ev_t};
+        hipEvent_t evs[] = {sl.ev0, sl.ev1, sl.ev_s, sl.ev2, sl.ev_k2, sl.ev_t, sl.ev_k1done, sl.ev_tail};
         if (sl.h_done) (void)hipHostFree(sl.h_done);
         for (hipEvent_t ev : evs) if (ev) (void)hipEventDestroy(ev);
     }
