@@ -76,15 +76,12 @@ bool legal_chip_length(int cl)
 
 }  // namespace
 
-// One in-flight batch.  Two slots let the host read back batch i (copy stream) while the GPU
-// already runs batch i+1 (compute stream); the quantized history flows slot -> slot.
+// One in-flight batch.  Four slots, up to three batches in flight: the host reads back batch i (copy stream) while the
+// GPU runs batches i+1 and i+2; the quantized history flows slot -> next slot (see "4b" in DESIGN.md).
 struct Slot {
     uint32_t *d_qt = nullptr;     size_t qt_tiles = 0;     // tiled bitstream, tile 0 = history tile
     uint32_t *d_counts = nullptr; size_t cnt_tiles = 0;
     uint32_t *d_gcnt = nullptr; uint32_t gcnt_words = 0;     // hit counts summed over groups of 64 tiles (K2 -> K3)
-    // copy of this slot's history rows (tile 0) taken when the NEXT batch's state update overwrote them while this
-    // slot's batch was still uncollected: a re-run of its search swaps them back in
-    uint32_t *d_hist_save = nullptr; bool tile0_saved = false;
     uint64_t *d_offs_pre = nullptr;                        // [n_pre+1] + overflow word behind it
     uint32_t *d_overflow = nullptr;
     uint32_t *d_staging = nullptr; size_t staging_tiles = 0; uint32_t stage_cap = 1024;
@@ -249,9 +246,9 @@ void launch_k1(int cl, dim3 grid, hipStream_t st, const amr::K1Args &a, hipEvent
 }
 
 // Make room for `tiles` tiles in the bitstream of slot `s` (the slot being submitted: nothing of it is in flight),
-// keeping its tile 0 = the history the previous batch left there.  The other slot may hold an uncollected batch whose
-// rows a re-run of its search still needs, so it is never reallocated here; it only has to EXIST, because this
-// batch's state update writes the next history tile into it.
+// keeping its tile 0 = the history the previous batch left there.  The next slot in the ring (`other`, never one with a
+// batch in flight) only has to EXIST here, because this batch's state update writes the next history tile into it; it
+// is grown when its own batch is submitted.
 amr_status ensure_qt(amr_handle *h, Slot &s, Slot &other, size_t tiles)
 {
     const size_t tile_words = (size_t)64 * h->sg.wpb;
@@ -482,9 +479,11 @@ amr_status enqueue_tail(amr_handle *h, Slot &s, hipStream_t st, bool split)
     k3.out = s.d_out; k3.offs_pre = s.d_offs_pre; k3.h_offs_pre = s.h_off; k3.h_overflow = s.h_ovf;
     k3.out_cap = s.out_cap; k3.overflow = s.d_overflow;
     k3.block_base = s.calls_base; k3.n_tiles = s.n_tiles; k3.cap = s.stage_cap; k3.g = h->sg;
+    // AMR_K3_IMPL=old: the per-hit slicing of round 1 (A/B measurements, tests)
     static const bool k3_old = [] { const char *e = getenv("AMR_K3_IMPL"); return e && strcmp(e, "old") == 0; }();
-    if (k3_old) hipExtLaunchKernelGGL(amr::k3_slice, dim3(s.n_tiles, n_pre), dim3(256), 0, st, (t2 && split) ? s.ev_t : nullptr, t2 ? s.ev2 : nullptr, 0, k3);
-    else hipExtLaunchKernelGGL(amr::k3_slice_words, dim3(s.n_tiles, n_pre), dim3(256), 0, st, (t2 && split) ? s.ev_t : nullptr, t2 ? s.ev2 : nullptr, 0, k3);
+    hipEvent_t k3e0 = (t2 && split) ? s.ev_t : nullptr, k3e1 = t2 ? s.ev2 : nullptr;
+    if (k3_old) hipExtLaunchKernelGGL(amr::k3_slice, dim3(s.n_tiles, n_pre), dim3(256), 0, st, k3e0, k3e1, 0, k3);
+    else hipExtLaunchKernelGGL(amr::k3_slice_words, dim3(s.n_tiles, n_pre), dim3(256), 0, st, k3e0, k3e1, 0, k3);
     HIP_TRY(hipGetLastError());
     AMR_DBG(st, "k3_slice");
     if (h->r900_pid >= 0) {
@@ -538,7 +537,6 @@ amr_status submit(amr_handle *h, const uint8_t *d_iq, size_t n_blocks, bool sear
     const uint32_t bs = (uint32_t)h->geom.block_size;
     const uint32_t full = (uint32_t)(n_blocks / 64), rem = (uint32_t)(n_blocks % 64);
 
-    s.tile0_saved = false;
     s.ticket = h->next_ticket++;
     s.d_iq = d_iq;
     s.n_blocks = n_blocks;
@@ -619,10 +617,9 @@ amr_status submit(amr_handle *h, const uint8_t *d_iq, size_t n_blocks, bool sear
     if (prev_tail_now) HIP_TRY(hipStreamWaitEvent(st, prevm.ev_tail, 0));
     amr::HistArgs ha{s.d_qt, other.d_qt, (uint32_t)n_blocks, h->hist_rows, h->sg.wpb, h->sg.lg_wpb,
                      d_iq + n_blocks * (size_t)h->geom.block_size2 - h->halo_bytes, h->d_carry, h->halo_bytes, other.d_overflow,
-                     other.d_gcnt, other.gcnt_words, other.pending ? other.d_hist_save : nullptr,
+                     other.d_gcnt, other.gcnt_words,
                      lazy ? nullptr : s.h_done, s.ticket, &h->h_flags[1],
                      (!prev_tail_now && prev.pending && prev.search && prev.tail_split) ? h->d_tail_done : nullptr, prev.ticket};
-    other.tile0_saved = other.pending;
     hipLaunchKernelGGL(amr::k_hist_update, dim3(1), dim3(1024), (size_t)h->hist_rows * h->sg.wpb * 4, st, ha);
     HIP_TRY(hipGetLastError());
     AMR_DBG(st, "k_hist_update");
@@ -719,7 +716,7 @@ amr_status collect(amr_handle *h, amr_result *res)
     AMR_TRY(wait_done(h, s));
     if (h->n_pending == 1) h->lazy_tail = false;   // nothing else in flight: the caller is not pipelining (any more)
     uint64_t total = 0, searched = 0;
-    bool use_dense = s.dense, swapped = false;
+    bool use_dense = s.dense;
     if (s.search) {
         for (int attempt = 0;; ++attempt) {
             const uint32_t ovf = *s.h_ovf;
@@ -751,21 +748,11 @@ amr_status collect(amr_handle *h, amr_result *res)
                 if (attempt) HIP_TRY(hipMemsetAsync(s.d_gcnt, 0, (size_t)s.gcnt_words * 4, h->stream));
                 break;
             }
-            // The slot's bitstream rows are intact until the slot is reused, so the search can simply run again --
-            // except the history rows of tile 0 when the following batch has already put ITS tail there: swap the
-            // saved rows in for the re-runs (and back afterwards, below)
-            if (s.tile0_saved && !swapped) {
-                hipLaunchKernelGGL(amr::k_hist_swap, dim3(1), dim3(1024), 0, h->stream, s.d_qt, s.d_hist_save, h->hist_rows,
-                                   h->sg.wpb, h->sg.lg_wpb);
-                swapped = true;
-            }
+            // The slot's bitstream, its history rows included, is intact until the slot is reused (four slots, three batches
+            // in flight: the state update that overwrites this slot's history tile belongs to a batch that cannot be
+            // submitted before this one has been collected), so the search can simply run again.
             AMR_TRY(enqueue_search(h, s, true, use_dense));
             HIP_TRY(hipStreamSynchronize(h->stream));
-        }
-        if (swapped) {
-            hipLaunchKernelGGL(amr::k_hist_swap, dim3(1), dim3(1024), 0, h->stream, s.d_qt, s.d_hist_save, h->hist_rows,
-                               h->sg.wpb, h->sg.lg_wpb);
-            HIP_TRY(hipGetLastError());
         }
         if (use_dense && !s.dense) {
             if (++h->dense_streak >= 4) { h->dense_hold = 32; h->dense_streak = 0; }
@@ -995,7 +982,6 @@ amr_status amr_create(const amr_protocol *protos, int32_t n_protos, int32_t devi
         if (e == hipSuccess) *sl.h_done = 0;
         if (e == hipSuccess) e = hipMalloc((void **)&sl.d_offs_pre, (AMR_MAX_PREAMBLES + 1) * 8);
         if (e == hipSuccess) e = hipMalloc((void **)&sl.d_overflow, 4);
-        if (e == hipSuccess) e = hipMalloc((void **)&sl.d_hist_save, (size_t)h->hist_rows * sg.wpb * 4);
         if (e == hipSuccess) e = hipMalloc((void **)&sl.d_offs_val, (AMR_MAX_PREAMBLES + 1) * 8);
         if (e == hipSuccess) e = hipHostMalloc((void **)&sl.h_offv, (AMR_MAX_PREAMBLES + 1) * 8, hipHostMallocDefault);
         if (e == hipSuccess) e = hipMemset(sl.d_overflow, 0, 4);
@@ -1037,7 +1023,7 @@ amr_status amr_destroy(amr_handle *h)
     if (h->h_flags) (void)hipHostFree(h->h_flags);
     for (Slot &sl : h->slot) {
         void *dp[] = {sl.d_qt, sl.d_counts, sl.d_gcnt, sl.d_offs_pre, sl.d_overflow, sl.d_staging, sl.d_out, sl.d_iq_stage, sl.d_r900,
-                      sl.d_val, sl.d_keep, sl.d_chunk, sl.d_offs_val, sl.d_hist_save};
+                      sl.d_val, sl.d_keep, sl.d_chunk, sl.d_offs_val};
         if (sl.h_r900) (void)hipHostFree(sl.h_r900);
         if (sl.ev_h2d) (void)hipEventDestroy(sl.ev_h2d);
         for (void *p : dp) if (p) (void)hipFree(p);

@@ -576,6 +576,10 @@ __global__ __launch_bounds__(256) void k3_slice(const K3Args a)
 // already in the byte order of Decoder.Slice (decode.go:363-366) because the symbols were dealt to the lanes
 // bit-reversed inside every byte.  Positions that are hits store their dword, the others are dropped.
 // Input and output are those of k3_slice (positions in the staging slots, ascending; packed result).
+// (Tried and dropped: one workgroup per tile that first stages the tile's 64 rows in LDS -- LDS-DMA, rows XOR-swizzled
+// against bank conflicts -- and takes the windows from there: 64 vs 54 us of search per 1 GiB with scm, 1.05 vs 0.67 ms
+// per 4 GiB with four preambles.  The preambles of a tile run one after the other, half as many workgroups fit a CU,
+// and the staging is one more latency in front of a kernel that is made of latencies.)
 __device__ __forceinline__ uint32_t k3_transpose32(uint32_t x, uint32_t lane)
 {
 #define K3_TSTEP(S, M)                                                                                                \
@@ -733,9 +737,6 @@ struct HistArgs {
     uint32_t *ovf_next;
     uint32_t *gcnt_next;    // the group sums the next batch's K2 adds into
     uint32_t gcnt_words;
-    // When the batch that ran in the other slot has not been collected yet, its history rows (tile 0 of qt_next) are
-    // saved here before they are overwritten: a re-run of its search (capacity overflow) needs them back.
-    uint32_t *save_next;    // [hr*wpb] or null
     // completion ticket of the batch, stored to pinned host memory by the last thread of this last kernel
     uint64_t *done_flag;
     uint64_t done_value;
@@ -768,7 +769,6 @@ __global__ __launch_bounds__(1024) void k_hist_update(const HistArgs a)
     for (uint32_t i = threadIdx.x; i < n; i += 1024) {
         const uint32_t j = i >> a.lg_wpb, w = i & (a.wpb - 1);
         const size_t di = qt_index(64 - a.hr + j, w, a.lg_wpb);
-        if (a.save_next) a.save_next[i] = a.qt_next[di];
         a.qt_next[di] = tmp[i];
     }
     __syncthreads();
@@ -790,20 +790,6 @@ __global__ void k_done(uint64_t *flag, uint64_t value, uint64_t *dev_flag)
 {
     __hip_atomic_store(dev_flag, value, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);   // k_hist_update of the next batch waits here
     __hip_atomic_store(flag, value, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-}
-
-// Exchange the history rows of tile 0 with their saved copy (before and after a re-run of a search whose slot has
-// already received the next-but-one batch's history).
-__global__ __launch_bounds__(1024) void k_hist_swap(uint32_t *qt, uint32_t *save, uint32_t hr, uint32_t wpb, uint32_t lg_wpb)
-{
-    const uint32_t n = hr << lg_wpb;
-    for (uint32_t i = threadIdx.x; i < n; i += 1024) {
-        const uint32_t j = i >> lg_wpb, w = i & (wpb - 1);
-        const size_t di = qt_index(64 - hr + j, w, lg_wpb);
-        const uint32_t t = qt[di];
-        qt[di] = save[i];
-        save[i] = t;
-    }
 }
 
 // Tests: tiled rows 64.. -> linear MSB-first byte stream (decode.go:259-265 packing).
