@@ -245,6 +245,11 @@ void launch_k1(int cl, dim3 grid, hipStream_t st, const amr::K1Args &a, hipEvent
     }
 }
 
+// Wait for the compute stream.  With K3.. of some batches still unlaunched (pipelined callers), a k_hist_update on the
+// stream may be waiting for one of them: launch them first (each as soon as its own search has finished), or the wait
+// would only end at that kernel's 2 ms time-out.
+amr_status sync_compute(amr_handle *h);
+
 // Make room for `tiles` tiles in the bitstream of slot `s` (the slot being submitted: nothing of it is in flight),
 // keeping its tile 0 = the history the previous batch left there.  The next slot in the ring (`other`, never one with a
 // batch in flight) only has to EXIST here, because this batch's state update writes the next history tile into it; it
@@ -260,7 +265,7 @@ amr_status ensure_qt(amr_handle *h, Slot &s, Slot &other, size_t tiles)
         if (e != hipSuccess) return fail(AMR_ENOMEM, "hipMalloc(qt)", e);
         if (s.d_qt) {
             HIP_TRY(hipMemcpyAsync(nq, s.d_qt, tile_words * 4, hipMemcpyDeviceToDevice, h->stream));
-            HIP_TRY(hipStreamSynchronize(h->stream));
+            AMR_TRY(sync_compute(h));
             HIP_TRY(hipFree(s.d_qt));
         } else {
             HIP_TRY(hipMemsetAsync(nq, 0, tile_words * 4, h->stream));
@@ -306,7 +311,7 @@ amr_status ensure_capacity(amr_handle *h, Slot &s, Slot &other, size_t n_blocks)
     for (Slot *slp : both) {
         Slot &sl = *slp;
         if (gw <= sl.gcnt_words) continue;
-        HIP_TRY(hipStreamSynchronize(h->stream));
+        AMR_TRY(sync_compute(h));
         AMR_TRY(dev_realloc(sl.d_gcnt, gw));
         HIP_TRY(hipMemsetAsync(sl.d_gcnt, 0, (size_t)gw * 4, h->stream));   // ordered before the K2 that adds into it
         sl.gcnt_words = gw;
@@ -520,7 +525,7 @@ amr_status enqueue_search(amr_handle *h, Slot &s, bool rerun = false, bool dense
     return enqueue_tail(h, s, h->stream, false);
 }
 
-amr_status launch_ready_tails(amr_handle *h);
+amr_status launch_ready_tails(amr_handle *h, bool last_too = false);
 
 // Enqueue one batch on the compute stream: K1, (search), history + carry update.  Returns at once.
 amr_status submit(amr_handle *h, const uint8_t *d_iq, size_t n_blocks, bool search)
@@ -676,19 +681,39 @@ amr_status wait_done(amr_handle *h, Slot &s)
 // Launch, without waiting for anything, the second-stream part (K3..) of every batch in flight whose successor's search
 // has started (= the successor's K1 has finished), oldest first.  Called wherever the host passes by: submit, collect
 // and the wait for the read-back, so that a host that is busy copying results does not hold the GPU up.
-amr_status launch_ready_tails(amr_handle *h)
+amr_status launch_ready_tails(amr_handle *h, bool last_too)
 {
-    for (int k = 0; k + 1 < h->n_pending; ++k) {
+    for (int k = 0; k < h->n_pending; ++k) {
         Slot &t = h->slot[(h->next_slot - h->n_pending + k + 2 * kSlots) % kSlots];
         if (!t.search || t.tail_enqueued) continue;
-        const Slot &nx = h->slot[(h->next_slot - h->n_pending + k + 1 + 2 * kSlots) % kSlots];
-        const uint64_t *flag = nx.search ? &h->h_flags[0] : &h->h_flags[1];
+        const bool last = k + 1 == h->n_pending;
+        if (last && !last_too) break;
+        // the youngest batch has no successor to wait for: its own search must have finished (last_too: the caller is
+        // waiting for a read-back anyway and submits nothing meanwhile)
+        const Slot &nx = last ? t : h->slot[(h->next_slot - h->n_pending + k + 1 + 2 * kSlots) % kSlots];
+        const uint64_t *flag = (!last && nx.search) ? &h->h_flags[0] : &h->h_flags[1];
         if (__atomic_load_n(flag, __ATOMIC_ACQUIRE) < nx.ticket) break;   // in order: the tickets on the second stream rise
         AMR_TRY(enqueue_tail(h, t, h->tail_stream, true));
         hipLaunchKernelGGL(amr::k_done, dim3(1), dim3(1), 0, h->tail_stream, t.h_done, t.ticket, h->d_tail_done);
         HIP_TRY(hipGetLastError());
         t.tail_enqueued = true;
     }
+    return AMR_OK;
+}
+
+amr_status sync_compute(amr_handle *h)
+{
+    for (int k = 0; k < h->n_pending; ++k) {
+        Slot &t = h->slot[(h->next_slot - h->n_pending + k + 2 * kSlots) % kSlots];
+        if (!t.search || t.tail_enqueued) continue;
+        AMR_TRY(wait_flag(&h->h_flags[1], t.ticket, h->stream));   // its K2 (and state update) have finished
+        AMR_TRY(enqueue_tail(h, t, h->tail_stream, true));
+        hipLaunchKernelGGL(amr::k_done, dim3(1), dim3(1), 0, h->tail_stream, t.h_done, t.ticket, h->d_tail_done);
+        HIP_TRY(hipGetLastError());
+        t.tail_enqueued = true;
+    }
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    HIP_TRY(hipStreamSynchronize(h->tail_stream));
     return AMR_OK;
 }
 
@@ -731,14 +756,14 @@ amr_status collect(amr_handle *h, amr_result *res)
                 s.stage_cap *= 8;
                 const uint64_t lim = (uint64_t)64 * h->geom.block_size;
                 if (s.stage_cap > lim) s.stage_cap = (uint32_t)lim;
-                HIP_TRY(hipStreamSynchronize(h->stream));
+                AMR_TRY(sync_compute(h));
                 AMR_TRY(dev_realloc(s.d_staging, s.staging_tiles * n_pre * (size_t)s.stage_cap));
                 rerun = true;
             } else if (!rerun && total > s.out_cap) {
                 uint64_t nc = s.out_cap;
                 while (nc < total) nc *= 2;
                 s.out_cap = nc;
-                HIP_TRY(hipStreamSynchronize(h->stream));
+                AMR_TRY(sync_compute(h));
                 AMR_TRY(alloc_hit_buffers(h, s));
                 rerun = true;
             }
@@ -752,7 +777,7 @@ amr_status collect(amr_handle *h, amr_result *res)
             // in flight: the state update that overwrites this slot's history tile belongs to a batch that cannot be
             // submitted before this one has been collected), so the search can simply run again.
             AMR_TRY(enqueue_search(h, s, true, use_dense));
-            HIP_TRY(hipStreamSynchronize(h->stream));
+            AMR_TRY(sync_compute(h));
         }
         if (use_dense && !s.dense) {
             if (++h->dense_streak >= 4) { h->dense_hold = 32; h->dense_streak = 0; }
@@ -785,7 +810,7 @@ amr_status collect(amr_handle *h, amr_result *res)
                 const hipError_t qe = hipStreamQuery(h->copy_stream);
                 if (qe == hipSuccess) break;
                 if (qe != hipErrorNotReady) return fail(AMR_EHIP, "hipStreamQuery(copy stream)", qe);
-                AMR_TRY(launch_ready_tails(h));
+                AMR_TRY(launch_ready_tails(h, true));
                 cpu_relax();
             }
         }
@@ -832,7 +857,7 @@ amr_status collect(amr_handle *h, amr_result *res)
 amr_status stage_host_input(amr_handle *h, const uint8_t *iq, size_t bytes)
 {
     if (bytes > h->iq_cap) {
-        HIP_TRY(hipStreamSynchronize(h->stream));
+        AMR_TRY(sync_compute(h));
         AMR_TRY(dev_realloc(h->d_iq, bytes));
         h->iq_cap = bytes;
     }
@@ -1050,7 +1075,7 @@ amr_status amr_reset(amr_handle *h)
     HIP_TRY(hipStreamSynchronize(h->tail_stream));
     for (Slot &sl : h->slot)
         if (sl.d_qt) HIP_TRY(hipMemsetAsync(sl.d_qt, 0, (size_t)64 * h->sg.wpb * 4, h->stream));
-    HIP_TRY(hipStreamSynchronize(h->stream));
+    AMR_TRY(sync_compute(h));
     h->zero_halo = true;
     h->calls_done = 0;
     h->last_n_blocks = 0;
@@ -1255,7 +1280,7 @@ amr_status amr_copy_quantized(amr_handle *h, uint8_t *out, size_t out_bytes)
                        (uint32_t)h->last_n_blocks, h->sg.lg_wpb);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipMemcpyAsync(out, h->d_untile, words * 4, hipMemcpyDeviceToHost, h->stream));
-    HIP_TRY(hipStreamSynchronize(h->stream));
+    AMR_TRY(sync_compute(h));
     return AMR_OK;
 }
 
