@@ -298,8 +298,15 @@ amr_status alloc_hit_buffers(amr_handle *h, Slot &s)
 amr_status ensure_capacity(amr_handle *h, Slot &s, Slot &other, size_t n_blocks)
 {
     const size_t bt = (n_blocks + 63) / 64;   // batch tiles
-    AMR_TRY(ensure_qt(h, s, other, bt + 2));
     const size_t st = bt + 1;                 // tiles searched
+    {   // hipMalloc / hipFree wait for the whole device: with batches in flight, launch their pending K3.. first (see
+        // sync_compute) -- this happens on the first use of each slot and when a batch is larger than any before
+        const uint32_t gw0 = (uint32_t)(amr::k2_groups((uint32_t)st) * h->sg.n_pre);
+        const bool grows = bt + 2 > s.qt_tiles || !other.d_qt || st > s.cnt_tiles || gw0 > s.gcnt_words || gw0 > other.gcnt_words ||
+                           st > s.staging_tiles || !s.d_out || (h->validate && !s.d_val);
+        if (grows && h->n_pending) AMR_TRY(sync_compute(h));
+    }
+    AMR_TRY(ensure_qt(h, s, other, bt + 2));
     if (st > s.cnt_tiles) {
         AMR_TRY(dev_realloc(s.d_counts, st * h->sg.n_pre));
         s.cnt_tiles = st;
