@@ -543,7 +543,7 @@ amr_status submit(amr_handle *h, const uint8_t *d_iq, size_t n_blocks, bool sear
     if (!h->tail_events) AMR_TRY(launch_ready_tails(h));
     Slot &s = h->slot[h->next_slot];
     Slot &other = h->slot[(h->next_slot + 1) % kSlots];   // the slot the next batch will use: never one in flight
-    const Slot &prev = h->slot[(h->next_slot + kSlots - 1) % kSlots];   // the batch submitted before this one
+    Slot &prev = h->slot[(h->next_slot + kSlots - 1) % kSlots];   // the batch submitted before this one (if still in flight)
     AMR_TRY(ensure_capacity(h, s, other, n_blocks));
     hipStream_t st = h->stream;
     const uint32_t bs = (uint32_t)h->geom.block_size;
@@ -571,8 +571,7 @@ amr_status submit(amr_handle *h, const uint8_t *d_iq, size_t n_blocks, bool sear
     hipEvent_t e0 = s.timed ? s.ev0 : nullptr, e1 = s.timed ? s.ev1 : nullptr;
     // The batch submitted before this one left its K3.. for the second stream: they go there now, behind the end of
     // THIS batch's K1 (its last launch carries the event), i.e. next to this batch's search.
-    Slot &prevm = h->slot[(h->next_slot + kSlots - 1) % kSlots];
-    const bool prev_tail_now = h->tail_events && prevm.pending && prevm.search && prevm.tail_split && !prevm.tail_enqueued;
+    const bool prev_tail_now = h->tail_events && prev.pending && prev.search && prev.tail_split && !prev.tail_enqueued;
     if (prev_tail_now && !e1) e1 = s.ev_k1done;
     // One launch per "round" for long blocks: K1 holds 8 waves per CU, and a launch that exactly fills the chip keeps its
     // waves in step -- all of them read together and write their output bursts together.  A larger grid runs the later
@@ -593,11 +592,11 @@ amr_status submit(amr_handle *h, const uint8_t *d_iq, size_t n_blocks, bool sear
     AMR_DBG(st, "k1_demod");
     if (prev_tail_now) {
         HIP_TRY(hipStreamWaitEvent(h->tail_stream, e1, 0));
-        AMR_TRY(enqueue_tail(h, prevm, h->tail_stream, true));
-        hipLaunchKernelGGL(amr::k_done, dim3(1), dim3(1), 0, h->tail_stream, prevm.h_done, prevm.ticket, h->d_tail_done);
+        AMR_TRY(enqueue_tail(h, prev, h->tail_stream, true));
+        hipLaunchKernelGGL(amr::k_done, dim3(1), dim3(1), 0, h->tail_stream, prev.h_done, prev.ticket, h->d_tail_done);
         HIP_TRY(hipGetLastError());
-        HIP_TRY(hipEventRecord(prevm.ev_tail, h->tail_stream));
-        prevm.tail_enqueued = true;
+        HIP_TRY(hipEventRecord(prev.ev_tail, h->tail_stream));
+        prev.tail_enqueued = true;
     }
     s.dense = h->dense_hold > 0;
     if (s.dense) h->dense_hold--;
@@ -626,7 +625,7 @@ amr_status submit(amr_handle *h, const uint8_t *d_iq, size_t n_blocks, bool sear
     // state carried to the next batch (decode.go:165-166): last rows of this slot's bitstream become the
     // history tile of the OTHER slot (where the next batch runs); last HBA bytes of IQ become the carry
     // the next K1 launch must not meet the previous batch's K3.. (it needs every wave slot): wait for them here
-    if (prev_tail_now) HIP_TRY(hipStreamWaitEvent(st, prevm.ev_tail, 0));
+    if (prev_tail_now) HIP_TRY(hipStreamWaitEvent(st, prev.ev_tail, 0));
     amr::HistArgs ha{s.d_qt, other.d_qt, (uint32_t)n_blocks, h->hist_rows, h->sg.wpb, h->sg.lg_wpb,
                      d_iq + n_blocks * (size_t)h->geom.block_size2 - h->halo_bytes, h->d_carry, h->halo_bytes, other.d_overflow,
                      other.d_gcnt, other.gcnt_words,
