@@ -1,14 +1,18 @@
 // K1 (second generation) -- the same computation as k1_demod.h (MagLUT.Execute + Decoder.Filter + pack,
 // protocol/decode.go:219-245, one lane = one reference block, same operation order and roundings), reorganised
 // around what bounded the first kernel on MI355X: with two waves per SIMD nothing hides a stall, so the kernel
-//   1. keeps TWO staging tiles in flight per wave instead of one.  A tile (64 rows x 128 B) that has landed in LDS
-//      is drained into 32 VGPRs in one burst at the tile boundary (the same eight ds_read_b128 the old kernel
-//      spread over the tile), which frees its LDS buffer a whole tile-time early: the next DMA goes out at once
-//      and every DMA has two tile-times to land.  No extra LDS, so the occupancy stays at 8 waves per CU.
+//   1. keeps the staging tile in REGISTERS.  A tile (64 rows x 128 B) that has landed in LDS is drained into 32 VGPRs in
+//      one burst at the tile boundary (the same eight ds_read_b128 the old kernel spread over the tile), which frees its
+//      LDS buffer a whole tile-time early: the DMA of the tile after next goes out at once and is in flight during the
+//      whole computation of the next tile, with ONE 8 KiB buffer per wave instead of two (two buffers with two tiles
+//      in flight, DEPTH 2, turned out slower: the memory side alone runs at 0.205 ms with 32 MiB in flight chip-wide
+//      against 0.164 ms with 16 MiB).  The LDS saved parks finished output chunks (NLC) for larger store bursts.
 //   2. runs a fully static instruction stream in steady state.  One "super-body" = lcm(RING, 64) samples covers a
 //      whole number of csum-ring turns AND of staging tiles (5 tiles / 4 turns at chip length 72), so ring slots,
 //      tile registers and word boundaries are all compile-time constants: no per-group scalar bookkeeping, no
 //      per-group branches, three instructions per DMA piece.
+//   3. lets the two waves of a SIMD swap s_setprio every 8 tiles (PRIO below): the arbiter's preference for the older
+//      wave made it finish 9 % earlier and leave the other one alone for the rest of the launch.
 // Output layout, arguments and the halo/carry conventions are those of k1_demod.h (K1Args, "tiled4" bitstream).
 #pragma once
 #include "k1_demod.h"

@@ -9,13 +9,14 @@
 //   * a wave sweeps 32 words (8 groups of 4) of all 64 rows, lane = row = one reference block as before, and keeps the
 //     words its first D taps can reach in a REGISTER ring filled with ds_read_b128 (consecutive lanes read consecutive
 //     16 bytes: conflict-free).  SymbolLength and D are template parameters, so every window word of every tap is a
-//     fixed register: per word and tap one v_perm (odd multiples of 16 bits only), one v_xor with the preamble bit (a
-//     scalar 0 / ~0) and half a v_bitop3 -- no address arithmetic, no LDS access in the tap loop;
+//     fixed register: per word and tap one v_perm (odd multiples of 16 bits only) and ONE v_bitop3 (M & (W ^ inv), the
+//     preamble bit as a scalar 0 / ~0) -- no address arithmetic, no LDS access in the tap loop;
 //   * survivors of the D taps (2^-D of the positions in noise) go to the per-wave list of k2_search.h; everything behind
 //     that (remaining taps on the list entries, per-tile ranks, ordered emission into the staging slots, counts, overflow
 //     protocol) is the first kernel's code reading the new tile layout -- K3 and the host see no difference.
-// Used when every preamble has at least D symbols (all of rtlamr's have 16 or more: scm+ 16, scm 21, idm / netidm /
-// r900 32) and a row has 64..256 words; otherwise k2_search_fast / k2_search_dense run.
+// D = 10 for one preamble, 12 for several (AMR_K2S_D1 / AMR_K2S_DN; 16 in the first version: 47 / 39 / 37 us at 16 / 12 /
+// 10).  Used when every preamble has at least D symbols (all of rtlamr's have 16 or more: scm+ 16, scm 21, idm / netidm
+// / r900 32) and a row has 64..256 words; otherwise k2_search_fast / k2_search_dense run.
 // (A first version without the LDS tile -- every wave streaming its words and the look-ahead straight from global memory --
 // read 141 MB instead of 64 MiB, the look-ahead of D = 16 taps being longer than a wave's own segment, and was no faster
 // than the first kernel.)
