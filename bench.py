@@ -150,9 +150,10 @@ def verify_batch(ra, wl, local_rank, d_iq, n_blocks, pk, bs, n_samples):
         dec.close()
 
 
-def sharded_gather_check(ra, shard, wl, local_rank, rank, world, n_blocks=256):
+def sharded_gather_check(ra, shard, wl, local_rank, rank, world, n_blocks=256, cabi=True, device=None):
     """Every rank decodes its block range of one small stream (primed with the blocks before it), the hits are gathered
-    through the C ABI, and rank 0 compares them with its own single-decoder result for the whole stream."""
+    through the C ABI (cabi=False: with torch.distributed), and rank 0 compares them with its own single-decoder result
+    for the whole stream."""
     import numpy as np
     import torch.distributed as dist
     from rtlamr_amd import synth
@@ -176,16 +177,20 @@ def sharded_gather_check(ra, shard, wl, local_rank, rank, world, n_blocks=256):
             fn, nbits = B[kinds[i % len(kinds)]]
             pk.append(synth.Packet(int(s), fn(900 + i), nbits, 27 if i % 2 else -27, -25 if i % 2 else 25))
         synth.plant(iq, pk, wl["chip"])
-        g = shard.CommGatherer(dec, cap_hits=1 << 16)
+        g = shard.CommGatherer(dec, cap_hits=1 << 16) if cabi else None
         k0, k1 = shard.shard_range(n_blocks, world, rank)
         p0, _ = shard.prime_range(k0, dec.prime_blocks())
         if k0 > p0:
             dec.prime(iq[p0 * bs2: k0 * bs2], iq[p0 * bs2 - dec.halo_bytes(): p0 * bs2] if p0 > 0 else None)
         dec.set_block_base(k0)
-        dec.decode_batch(iq[k0 * bs2: k1 * bs2])
-        g.post()
-        got = g.result()
-        ok, detail = True, f"{n_blocks}-block stream over {world} rank(s): gathered hits == single decoder"
+        br_mine = dec.decode_batch(iq[k0 * bs2: k1 * bs2])
+        if cabi:
+            g.post()
+            got = g.result()
+        else:
+            got = shard.gather_hits(shard.batch_hits_array(br_mine, dec.n_preambles), device=device)
+        how = "C ABI gather" if cabi else "torch.distributed gather"
+        ok, detail = True, f"{n_blocks}-block stream over {world} rank(s), {how}: gathered hits == single decoder"
         if rank == 0:
             one = mk()
             try:
@@ -196,7 +201,7 @@ def sharded_gather_check(ra, shard, wl, local_rank, rank, world, n_blocks=256):
             order = np.lexsort((got[:, 2], got[:, 1], got[:, 0]))
             ok = len(want) > 0 and np.array_equal(got[order], want)
             if not ok:
-                detail = f"MISMATCH: gathered {len(got)} hit records, single decoder {len(want)}"
+                detail = f"MISMATCH ({how}): gathered {len(got)} hit records, single decoder {len(want)}"
         flag = [ok]
         dist.broadcast_object_list(flag, src=0)
         return bool(flag[0]), detail
@@ -338,18 +343,38 @@ def main():
         t = torch.tensor([n_first], dtype=torch.int64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         cap = max(1024, int(int(t.item()) * 1.5))
-        if os.environ.get("AMR_BENCH_GATHER", "cabi") == "cabi":
+        # Before anything is timed: a 256-block stream sharded over the ranks (HIP engine + amr_prime + the gather) must
+        # give exactly what rank 0's single decoder gives for the whole stream.  Every decision below is taken by all
+        # ranks together (all_reduce MIN), so that no rank waits in a collective the others never enter.
+        def all_agree(flag: bool) -> bool:
+            t = torch.tensor([1 if flag else 0], dtype=torch.int64, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MIN)
+            return bool(int(t.item()))
+
+        use_cabi = os.environ.get("AMR_BENCH_GATHER", "cabi") == "cabi"
+        if use_cabi:
             try:
-                # before anything is timed: a 256-block stream sharded over the ranks (HIP engine + amr_prime +
-                # the C-ABI gather) must give exactly what rank 0's single decoder gives for the whole stream
+                shard.comm_unique_id()            # loads librccl through the library: fails here, not inside a collective
+                loadable = True
+            except Exception as e:
+                loadable = False
+                check["sharded_gather"] = f"C-ABI gather unavailable ({e})"
+            use_cabi = all_agree(loadable)
+        if use_cabi:
+            try:
                 ok, detail = sharded_gather_check(ra, shard, wl, local_rank, rank, world)
-                check["sharded_gather"] = detail
-                rc = rc or (0 if ok else 5)
-                gatherer = shard.CommGatherer(dec, cap_hits=cap)
-                gather_kind = ("C ABI amr_gather_hits: RCCL send/recv of (block, idx) records to rank 0 on the library's own "
-                               "stream, one per step, no host synchronisation")
-            except Exception as e:       # e.g. librccl not loadable: keep the job alive on the torch.distributed path
-                check["sharded_gather"] = f"C-ABI gather unavailable ({e}); torch.distributed gather used instead"
+            except Exception as e:
+                ok, detail = False, f"C-ABI gather failed ({e})"
+            check["sharded_gather"] = detail
+            use_cabi = all_agree(ok)
+        if use_cabi:
+            gatherer = shard.CommGatherer(dec, cap_hits=cap)
+            gather_kind = ("C ABI amr_gather_hits: RCCL send/recv of (block, idx) records to rank 0 on the library's own "
+                           "stream, one per step, no host synchronisation")
+        else:   # the torch.distributed path, checked the same way; a mismatch here fails the run
+            ok, detail = sharded_gather_check(ra, shard, wl, local_rank, rank, world, cabi=False, device=dev)
+            check["sharded_gather"] = (check.get("sharded_gather", "") + "; " if "sharded_gather" in check else "") + detail
+            rc = rc or (0 if all_agree(ok) else 5)
         if gatherer is None:
             gatherer = shard.HitGatherer(dec.n_preambles, device=dev)
             gatherer.negotiate(n_first)
