@@ -148,6 +148,14 @@ class Decoder:
         self._last_blocks = 0
         self._block_base = 0
         self._inflight: List[tuple] = []   # (n_blocks, first_block) of submitted, uncollected batches
+        # The exported buffers of the Go Decoder (decode.go:46-50).  No parser reads Quantized; r900 reads Signal
+        # (r900/r900.go:162-170).  Both stay on the GPU unless asked for: with KeepSignal / KeepQuantized set before a
+        # decode_batch() call, the buffers hold afterwards what the Go fields hold after the batch's last Decode call
+        # (integration level (A) of INTEGRATION.md; go/protocol/decode_amd.go does the same).
+        self.KeepSignal = False
+        self.KeepQuantized = False
+        self.Signal: Optional[np.ndarray] = None      # float32[BlockSize + SymbolLength]
+        self.Quantized: Optional[np.ndarray] = None   # uint8[BufferLength], one decision per byte
 
     # -- decode.go:100-128 ------------------------------------------------
     def RegisterProtocol(self, p: Parser) -> None:
@@ -307,7 +315,28 @@ class Decoder:
         _lib.check(_lib.lib().amr_decode_batch(h, iq.ctypes.data, iq.size, n_blocks, C.byref(res)), "amr_decode_batch")
         first = self._calls + self._block_base
         self._calls += n_blocks
-        return self._collect(res, n_blocks, first)
+        out = self._collect(res, n_blocks, first)
+        if self.KeepSignal or self.KeepQuantized:
+            self._refill_exports(iq, n_blocks)
+        return out
+
+    def _refill_exports(self, iq: np.ndarray, n_blocks: int) -> None:
+        """Signal / Quantized as the reference leaves them after the last of the batch's Decode calls: each call slides
+        the buffer by BlockSize (decode.go:165-166) and appends the block's magnitudes (MagLUT.Execute, decode.go:169,
+        219-225: lut[I] + lut[Q] in float32) resp. its BlockSize decisions (decode.go:172)."""
+        cfg = self.Cfg
+        bs, bs2 = cfg.BlockSize, cfg.BlockSize2
+        if self.Signal is None:
+            self.Signal = np.zeros(bs + cfg.SymbolLength, np.float32)
+            self.Quantized = np.zeros(cfg.BufferLength, np.uint8)
+        if self.KeepSignal:
+            lut = self.mag_lut()
+            tail = iq[max(0, n_blocks - 2) * bs2: n_blocks * bs2]          # SymbolLength < BlockSize: two blocks suffice
+            mags = lut[tail[0::2]] + lut[tail[1::2]]                       # float32 + float32, one rounding
+            self.Signal = np.concatenate([self.Signal, mags.astype(np.float32)])[-(bs + cfg.SymbolLength):].copy()
+        if self.KeepQuantized:
+            bits = np.unpackbits(self.quantized_packed())[: n_blocks * bs]  # MSB first = stream order
+            self.Quantized = np.concatenate([self.Quantized, bits])[-cfg.BufferLength:].copy()
 
     def decode_batch_device(self, d_ptr: int, n_blocks: int) -> BatchResult:
         h = self._require()
@@ -423,6 +452,7 @@ class Decoder:
     def reset(self) -> None:
         _lib.check(_lib.lib().amr_reset(self._require()), "amr_reset")
         self._calls = 0
+        self.Signal = self.Quantized = None     # a fresh Decoder's buffers are zero (decode.go:144-145)
 
     # -- test / bench helpers ----------------------------------------------
     def quantized_packed(self) -> np.ndarray:

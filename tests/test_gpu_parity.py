@@ -385,3 +385,31 @@ def test_three_batches_in_flight_and_the_fourth_is_refused():
         dec.close()
         for d in bufs:
             L.amr_dev_free(0, d)
+
+
+@pytest.mark.parametrize("protos,chip", [(["scm"], 72), (["scm", "r900"], 72), (["scm+"], 32)])
+def test_exported_signal_and_quantized_buffers(protos, chip):
+    """Decoder.Signal / Decoder.Quantized (decode.go:46-50; r900 reads Signal, r900/r900.go:162-170): with KeepSignal /
+    KeepQuantized the mirror holds after every batch exactly what the reference's buffers hold after the batch's last
+    Decode call -- integration level (A) of INTEGRATION.md, the unchanged r900 parser on top of the GPU decoder."""
+    from oracle.oracle import OracleDecoder
+    dec = util.make_decoder(protos, chip)
+    try:
+        dec.KeepSignal = dec.KeepQuantized = True
+        bs2 = dec.Cfg.BlockSize2
+        sizes = [1, 1, 3, 5, 27]
+        iq, _ = util.synth_stream(protos, chip, sum(sizes), dec.Cfg.BlockSize, seed=61, n_packets=3)
+        o = OracleDecoder(list(protos), chip)
+        pos = 0
+        for nb in sizes:
+            dec.decode_batch(iq[pos * bs2:(pos + nb) * bs2])
+            for k in range(pos, pos + nb):
+                o.decode(iq[k * bs2:(k + 1) * bs2])
+            pos += nb
+            assert dec.Signal.dtype == np.float32 and dec.Signal.shape == o.signal.shape
+            assert np.array_equal(dec.Signal.view(np.uint32), o.signal.view(np.uint32)), f"Signal differs after call {pos}"
+            assert np.array_equal(dec.Quantized, o.quantized), f"Quantized differs after call {pos}"
+        dec.reset()
+        assert dec.Signal is None and dec.Quantized is None
+    finally:
+        dec.close()
