@@ -104,6 +104,7 @@ struct Slot {
     int timed = 0;                // timing level the batch in flight was submitted with
     bool tail_enqueued = true;    // K3.. of the batch in flight have been launched (false: collect launches them)
     bool tail_split = false;      // ... on the second stream
+    bool folded = false;          // the state update ran inside the search kernel: no stream-A ticket for this batch
     hipEvent_t ev_k2 = nullptr, ev_t = nullptr;   // K2 stop, K3 start (timing level 2 with the tail on the second stream)
     hipEvent_t ev_k1done = nullptr, ev_tail = nullptr;   // dependencies between the two streams (no timing)
     // the batch in flight
@@ -343,8 +344,10 @@ bool k2_use_stream()
 // same stream at once (enqueue_search; also every re-run after a capacity overflow) or later on the second stream
 // (pipelined callers: collect() launches it when the next batch's K1 has finished, so that it runs next to that
 // batch's K2 instead of in front of its K1).  `split`: K2 gets a stop event of its own for timing level 2.
-amr_status enqueue_k2(amr_handle *h, Slot &s, hipStream_t st, bool rerun, bool dense, bool split)
+amr_status enqueue_k2(amr_handle *h, Slot &s, hipStream_t st, bool rerun, bool dense, bool split,
+                      const amr::HistArgs *fold = nullptr, bool *folded = nullptr)
 {
+    if (folded) *folded = false;
     const uint32_t n_pre = h->sg.n_pre;
     const uint32_t bs = (uint32_t)h->geom.block_size;
     amr::K2Args k2{};
@@ -386,7 +389,16 @@ amr_status enqueue_k2(amr_handle *h, Slot &s, hipStream_t st, bool rerun, bool d
         const size_t lds2 = amr::k2_stream_lds_bytes(h->sg.wpb, n_pre);
         static const bool xcd = [] { const char *e = getenv("AMR_K2_XCD"); return !(e && e[0] == '0'); }();
         k2.xcd = xcd ? 1u : 0u;
-        const uint32_t grid = xcd ? 8u * ((s.n_tiles + 7u) / 8u) : s.n_tiles;
+        // the batch's state update as workgroup number n_tiles of this launch (see K2Args::do_hist)
+        if (fold) {
+            k2.do_hist = 1;
+            k2.hist = *fold;
+            k2.hist.adone_flag = nullptr;     // no ticket from inside the search (see K2Args::do_hist)
+            k2.hist.done_flag = nullptr;
+            if (folded) *folded = true;
+        }
+        const uint32_t wgs = s.n_tiles + (fold ? 1u : 0u);
+        const uint32_t grid = xcd ? 8u * ((wgs + 7u) / 8u) : wgs;
         bool launched = true;
 #define AMR_K2S_LAUNCH(S, DD, W)                                                                                       \
     do {                                                                                                             \
@@ -410,6 +422,7 @@ amr_status enqueue_k2(amr_handle *h, Slot &s, hipStream_t st, bool rerun, bool d
 #undef AMR_K2S_W
 #undef AMR_K2S_LAUNCH
         stream_ok = launched;
+        if (!launched && folded) *folded = false;
     }
     // the list-based kernel splits a row's words over 4 or 8 waves, 4 or 8 words per step: rows of fewer than 16 words
     // (BlockSize 256: scm+ alone at chip length 8) go through the dense kernel
@@ -605,12 +618,26 @@ amr_status submit(amr_handle *h, const uint8_t *d_iq, size_t n_blocks, bool sear
     // instead of standing between two K1 launches (which do not).
     const bool lazy = search && h->allow_lazy && (h->lazy_tail || h->n_pending >= 1);
     if (lazy) h->lazy_tail = true;
+    // state carried to the next batch (decode.go:165-166): the last rows of this slot's bitstream become the history
+    // tile of the NEXT slot, the last HBA bytes of IQ the carry, the next slot's search words are reset.  The kernel
+    // that does it is also the last one in front of the next K1 launch, which must not meet the previous batch's K3..
+    // (it needs every wave slot): it waits for them on a device word.
+    amr::HistArgs ha{s.d_qt, other.d_qt, (uint32_t)n_blocks, h->hist_rows, h->sg.wpb, h->sg.lg_wpb,
+                     d_iq + n_blocks * (size_t)h->geom.block_size2 - h->halo_bytes, h->d_carry, h->halo_bytes, other.d_overflow,
+                     other.d_gcnt, other.gcnt_words,
+                     lazy ? nullptr : s.h_done, s.ticket, &h->h_flags[1],
+                     (!prev_tail_now && prev.pending && prev.search && prev.tail_split) ? h->d_tail_done : nullptr, prev.ticket};
+    // pipelined callers: the update rides along with the search as one more workgroup (stream kernel only) instead of
+    // following it as a 5 us kernel; AMR_HIST_FOLD=0 keeps the kernel
+    static const bool fold_ok = [] { const char *e = getenv("AMR_HIST_FOLD"); return !(e && e[0] == '0'); }();
+    bool folded = false;
     if (search) {
-        if (lazy) AMR_TRY(enqueue_k2(h, s, st, false, s.dense, true));
+        if (lazy) AMR_TRY(enqueue_k2(h, s, st, false, s.dense, true, (fold_ok && !prev_tail_now) ? &ha : nullptr, &folded));
         else AMR_TRY(enqueue_search(h, s, false, s.dense));
     }
     s.tail_enqueued = !lazy;
     s.tail_split = lazy;
+    s.folded = folded;
 
     if (h->r900_pid >= 0) {   // the PL samples that precede the next batch (r900.go:168-170 keeps them as magnitudes)
         const uint64_t n_batch = (uint64_t)n_blocks * bs;
@@ -622,18 +649,12 @@ amr_status submit(amr_handle *h, const uint8_t *d_iq, size_t n_blocks, bool sear
         const uint64_t v = (uint64_t)h->iqhist_valid + n_batch;
         h->iqhist_valid = (uint32_t)std::min<uint64_t>(v, (uint64_t)h->geom.packet_length);
     }
-    // state carried to the next batch (decode.go:165-166): last rows of this slot's bitstream become the
-    // history tile of the OTHER slot (where the next batch runs); last HBA bytes of IQ become the carry
-    // the next K1 launch must not meet the previous batch's K3.. (it needs every wave slot): wait for them here
-    if (prev_tail_now) HIP_TRY(hipStreamWaitEvent(st, prev.ev_tail, 0));
-    amr::HistArgs ha{s.d_qt, other.d_qt, (uint32_t)n_blocks, h->hist_rows, h->sg.wpb, h->sg.lg_wpb,
-                     d_iq + n_blocks * (size_t)h->geom.block_size2 - h->halo_bytes, h->d_carry, h->halo_bytes, other.d_overflow,
-                     other.d_gcnt, other.gcnt_words,
-                     lazy ? nullptr : s.h_done, s.ticket, &h->h_flags[1],
-                     (!prev_tail_now && prev.pending && prev.search && prev.tail_split) ? h->d_tail_done : nullptr, prev.ticket};
-    hipLaunchKernelGGL(amr::k_hist_update, dim3(1), dim3(1024), (size_t)h->hist_rows * h->sg.wpb * 4, st, ha);
-    HIP_TRY(hipGetLastError());
-    AMR_DBG(st, "k_hist_update");
+    if (!folded) {
+        if (prev_tail_now) HIP_TRY(hipStreamWaitEvent(st, prev.ev_tail, 0));
+        hipLaunchKernelGGL(amr::k_hist_update, dim3(1), dim3(1024), (size_t)h->hist_rows * h->sg.wpb * 4, st, ha);
+        HIP_TRY(hipGetLastError());
+        AMR_DBG(st, "k_hist_update");
+    }
     h->zero_halo = false;
     if (search) h->calls_done += n_blocks;
     s.pending = true;
@@ -684,25 +705,60 @@ amr_status wait_done(amr_handle *h, Slot &s)
     return wait_flag(s.h_done, s.ticket, s.tail_split ? h->tail_stream : h->stream);
 }
 
+// Has the compute-stream part (K1, search, state update) of the k-th batch in flight finished -- in particular its search,
+// whose output K3 reads?  The signals, all without an event on the stream: the NEXT batch's search has announced its
+// start (pinned word 0; the stream is in order), or the batch's own state-update kernel has published its ticket (pinned
+// word 1), or -- when that update rode along inside the search kernel and the batch is the youngest -- the stream is idle.
+amr_status search_finished(amr_handle *h, int k, bool wait, bool *yes)
+{
+    auto pending = [&](int i) -> Slot & { return h->slot[(h->next_slot - h->n_pending + i + 2 * kSlots) % kSlots]; };
+    const Slot &t = pending(k);
+    const uint64_t *flag = nullptr;
+    uint64_t value = 0;
+    if (k + 1 < h->n_pending) {
+        const Slot &nx = pending(k + 1);
+        flag = nx.search ? &h->h_flags[0] : &h->h_flags[1];    // a batch without a search always has the kernel
+        value = nx.ticket;
+    } else if (!t.folded) {
+        flag = &h->h_flags[1];
+        value = t.ticket;
+    }
+    if (flag) {
+        if (wait) AMR_TRY(wait_flag(flag, value, h->stream));
+        *yes = __atomic_load_n(flag, __ATOMIC_ACQUIRE) >= value;
+        return AMR_OK;
+    }
+    if (wait) { HIP_TRY(hipStreamSynchronize(h->stream)); *yes = true; return AMR_OK; }
+    const hipError_t e = hipStreamQuery(h->stream);
+    if (e != hipSuccess && e != hipErrorNotReady) return fail(AMR_EHIP, "hipStreamQuery", e);
+    *yes = e == hipSuccess;
+    return AMR_OK;
+}
+
+amr_status launch_tail(amr_handle *h, Slot &t)
+{
+    AMR_TRY(enqueue_tail(h, t, h->tail_stream, true));
+    hipLaunchKernelGGL(amr::k_done, dim3(1), dim3(1), 0, h->tail_stream, t.h_done, t.ticket, h->d_tail_done);
+    HIP_TRY(hipGetLastError());
+    t.tail_enqueued = true;
+    return AMR_OK;
+}
+
 // Launch, without waiting for anything, the second-stream part (K3..) of every batch in flight whose successor's search
 // has started (= the successor's K1 has finished), oldest first.  Called wherever the host passes by: submit, collect
 // and the wait for the read-back, so that a host that is busy copying results does not hold the GPU up.
+// last_too: also the youngest batch's, once its own search has finished (the caller is waiting for a read-back and
+// submits nothing meanwhile; otherwise it waits for the K1 of a successor that may be on its way).
 amr_status launch_ready_tails(amr_handle *h, bool last_too)
 {
     for (int k = 0; k < h->n_pending; ++k) {
         Slot &t = h->slot[(h->next_slot - h->n_pending + k + 2 * kSlots) % kSlots];
         if (!t.search || t.tail_enqueued) continue;
-        const bool last = k + 1 == h->n_pending;
-        if (last && !last_too) break;
-        // the youngest batch has no successor to wait for: its own search must have finished (last_too: the caller is
-        // waiting for a read-back anyway and submits nothing meanwhile)
-        const Slot &nx = last ? t : h->slot[(h->next_slot - h->n_pending + k + 1 + 2 * kSlots) % kSlots];
-        const uint64_t *flag = (!last && nx.search) ? &h->h_flags[0] : &h->h_flags[1];
-        if (__atomic_load_n(flag, __ATOMIC_ACQUIRE) < nx.ticket) break;   // in order: the tickets on the second stream rise
-        AMR_TRY(enqueue_tail(h, t, h->tail_stream, true));
-        hipLaunchKernelGGL(amr::k_done, dim3(1), dim3(1), 0, h->tail_stream, t.h_done, t.ticket, h->d_tail_done);
-        HIP_TRY(hipGetLastError());
-        t.tail_enqueued = true;
+        if (k + 1 == h->n_pending && !last_too) break;
+        bool ready = false;
+        AMR_TRY(search_finished(h, k, false, &ready));
+        if (!ready) break;                       // in order: the tickets on the second stream rise
+        AMR_TRY(launch_tail(h, t));
     }
     return AMR_OK;
 }
@@ -712,11 +768,9 @@ amr_status sync_compute(amr_handle *h)
     for (int k = 0; k < h->n_pending; ++k) {
         Slot &t = h->slot[(h->next_slot - h->n_pending + k + 2 * kSlots) % kSlots];
         if (!t.search || t.tail_enqueued) continue;
-        AMR_TRY(wait_flag(&h->h_flags[1], t.ticket, h->stream));   // its K2 (and state update) have finished
-        AMR_TRY(enqueue_tail(h, t, h->tail_stream, true));
-        hipLaunchKernelGGL(amr::k_done, dim3(1), dim3(1), 0, h->tail_stream, t.h_done, t.ticket, h->d_tail_done);
-        HIP_TRY(hipGetLastError());
-        t.tail_enqueued = true;
+        bool ready = false;
+        AMR_TRY(search_finished(h, k, true, &ready));
+        AMR_TRY(launch_tail(h, t));
     }
     HIP_TRY(hipStreamSynchronize(h->stream));
     HIP_TRY(hipStreamSynchronize(h->tail_stream));
@@ -734,15 +788,11 @@ amr_status collect(amr_handle *h, amr_result *res)
     AMR_TRY(launch_ready_tails(h));
     if (s.search && !s.tail_enqueued) {
         // K3 (K4, K5) of this batch, on the second stream.  They need the batch's K2 to have finished; they are held
-        // back until the NEXT batch's K1 has finished as well (its search announces itself in h_flags[0]): next to a
-        // K1 launch, which fills every wave slot of the chip, they would only delay some of its waves.
-        const Slot *nx = h->n_pending >= 2 ? &h->slot[(si + 1) % kSlots] : nullptr;
-        if (nx && nx->search) AMR_TRY(wait_flag(&h->h_flags[0], nx->ticket, h->stream));
-        else AMR_TRY(wait_flag(&h->h_flags[1], s.ticket, h->stream));
-        AMR_TRY(enqueue_tail(h, s, h->tail_stream, true));
-        hipLaunchKernelGGL(amr::k_done, dim3(1), dim3(1), 0, h->tail_stream, s.h_done, s.ticket, h->d_tail_done);
-        HIP_TRY(hipGetLastError());
-        s.tail_enqueued = true;
+        // back until the NEXT batch's K1 has finished as well (its search announces itself): next to a K1 launch,
+        // which fills every wave slot of the chip, they would only delay some of its waves.
+        bool ready = false;
+        AMR_TRY(search_finished(h, 0, true, &ready));
+        AMR_TRY(launch_tail(h, s));
     }
     AMR_TRY(wait_done(h, s));
     if (h->n_pending == 1) h->lazy_tail = false;   // nothing else in flight: the caller is not pipelining (any more)

@@ -45,6 +45,86 @@ struct SearchGeom {
     uint64_t pre_bits[kMaxPre];  // bit p = preamble[p]
 };
 
+// After a batch: the last `hr` rows (reference blocks) become the history rows 64-hr..63 of tile 0 of the next slot, the
+// last HBA IQ bytes the carry, and the next slot's search words are reset -- the state the Go Decoder carries from call
+// to call (decode.go:165-166).  One workgroup; reads everything before writing anything.
+struct HistArgs {
+    const uint32_t *qt;     // bitstream of the batch just processed (its tile 0 = the old history)
+    uint32_t *qt_next;      // bitstream buffer the next batch will use: receives the new history tile
+    uint32_t n_blocks;  // rows in the batch just processed
+    uint32_t hr;        // history rows kept = ceil(PL/BS) (<= 63)
+    uint32_t wpb, lg_wpb;
+    // the other per-batch state, folded into this launch: the IQ halo of the next batch's block 0 (last HBA stream
+    // bytes, decode.go:165) and the reset of the overflow word the next batch's search will use
+    const uint8_t *carry_src;
+    uint8_t *carry_dst;
+    uint32_t carry_bytes;   // multiple of 16
+    uint32_t *ovf_next;
+    uint32_t *gcnt_next;    // the group sums the next batch's K2 adds into
+    uint32_t gcnt_words;
+    // completion ticket of the batch, stored to pinned host memory by the last thread of this last kernel
+    uint64_t *done_flag;
+    uint64_t done_value;
+    // ticket of the stream-A part of the batch (K1, search, this kernel), always published; done_flag may be null
+    // when K3 and what follows it run later on the second stream and publish the batch ticket themselves
+    uint64_t *adone_flag;
+    // Pipelined callers: K3.. of the PREVIOUS batch run on the second stream next to this batch's search.  When they
+    // take longer than the search, the next K1 launch (which needs every wave slot of the chip) has to wait for them:
+    // this kernel, the last one in front of it, spins until the device word `wait_flag` reaches `wait_value`
+    // (k_done of that batch) -- for at most ~2 ms, in case the host never launches them.
+    const uint64_t *wait_flag;
+    uint64_t wait_value;
+};
+
+__device__ __forceinline__ size_t qt_index_fwd(uint64_t R, uint32_t w, uint32_t lg_wpb)   // = qt_index, defined below
+{
+    return ((R >> 6) << (6 + lg_wpb)) + ((size_t)(w >> 2) << 8) + ((R & 63) << 2) + (w & 3);
+}
+
+// the work, by a workgroup of `nt` threads with hr * wpb words of LDS at tmp
+__device__ __forceinline__ void hist_body(const HistArgs &a, uint32_t *tmp, uint32_t nt)
+{
+    const uint32_t tid = threadIdx.x;
+    for (uint32_t i = tid; i < a.carry_bytes / 16; i += nt)
+        reinterpret_cast<uint4 *>(a.carry_dst)[i] = reinterpret_cast<const uint4 *>(a.carry_src)[i];
+    if (tid == nt - 1) *a.ovf_next = 0;
+    for (uint32_t i = tid; i < a.gcnt_words; i += nt) a.gcnt_next[i] = 0;
+    const uint32_t n = a.hr << a.lg_wpb;
+    for (uint32_t i = tid; i < n; i += nt) {
+        const uint32_t j = i >> a.lg_wpb, w = i & (a.wpb - 1);
+        // new history row j = stream row (n_blocks - hr + j) of the batch; negative -> old history
+        const int64_t srow = (int64_t)64 + a.n_blocks - a.hr + j;  // tiled row index (tile 0 rows 0..63 = old history)
+        tmp[i] = a.qt[qt_index_fwd((uint64_t)srow, w, a.lg_wpb)];
+    }
+    __syncthreads();
+    for (uint32_t i = tid; i < n; i += nt) {
+        const uint32_t j = i >> a.lg_wpb, w = i & (a.wpb - 1);
+        a.qt_next[qt_index_fwd(64 - a.hr + j, w, a.lg_wpb)] = tmp[i];
+    }
+    __syncthreads();
+}
+
+// the tickets, by one thread, once everything of the batch on this stream has completed
+__device__ __forceinline__ void hist_publish(const HistArgs &a)
+{
+    if (a.adone_flag) __hip_atomic_store(a.adone_flag, a.done_value, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    if (a.done_flag) __hip_atomic_store(a.done_flag, a.done_value, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    if (a.wait_flag) {
+        const uint64_t t0 = __builtin_amdgcn_s_memrealtime();   // 100 MHz
+        while (__hip_atomic_load(a.wait_flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < a.wait_value &&
+               __builtin_amdgcn_s_memrealtime() - t0 < 200000ull)
+            __builtin_amdgcn_s_sleep(32);
+    }
+}
+
+__global__ __launch_bounds__(1024) void k_hist_update(const HistArgs a)
+{
+    extern __shared__ uint32_t hist_tmp[];  // hr*wpb words
+    hist_body(a, hist_tmp, 1024);
+    // every earlier kernel of the batch has completed (same stream); the host polls these words
+    if (threadIdx.x == 0) hist_publish(a);
+}
+
 struct K2Args {
     const uint32_t *qt;    // tiled bitstream, tile 0 = history tile
     uint32_t *counts;      // [n_pre][n_tiles]
@@ -60,6 +140,12 @@ struct K2Args {
     // stream (this batch's K1) has finished: the host then launches the previous batch's K3 on the second stream
     uint64_t *started;
     uint64_t started_value;
+    // stream kernel, pipelined callers: the state update rides along as one more workgroup (tile index n_tiles) instead
+    // of a 5 us kernel of its own behind the search.  It carries no completion ticket (the search is still running
+    // when it is done; a ticket from inside the kernel would also need every workgroup to release its writes, an L2
+    // write-back each): the host takes "the next search has started" or "the stream is idle" as the signal instead.
+    uint32_t do_hist;
+    HistArgs hist;
     SearchGeom g;
 };
 
@@ -717,70 +803,6 @@ __global__ __launch_bounds__(256) void k3_slice_words(const K3Args a)
                         }
                     }
             }
-        }
-    }
-}
-
-// After a batch: the last `hr` rows (reference blocks) become the history rows 64-hr..63 of tile 0.
-// Single workgroup, reads everything before writing anything (rows may move inside tile 0).
-struct HistArgs {
-    const uint32_t *qt;     // bitstream of the batch just processed (its tile 0 = the old history)
-    uint32_t *qt_next;      // bitstream buffer the next batch will use: receives the new history tile
-    uint32_t n_blocks;  // rows in the batch just processed
-    uint32_t hr;        // history rows kept = ceil(PL/BS) (<= 63)
-    uint32_t wpb, lg_wpb;
-    // the other per-batch state, folded into this launch: the IQ halo of the next batch's block 0 (last HBA stream
-    // bytes, decode.go:165) and the reset of the overflow word the next batch's search will use
-    const uint8_t *carry_src;
-    uint8_t *carry_dst;
-    uint32_t carry_bytes;   // multiple of 16
-    uint32_t *ovf_next;
-    uint32_t *gcnt_next;    // the group sums the next batch's K2 adds into
-    uint32_t gcnt_words;
-    // completion ticket of the batch, stored to pinned host memory by the last thread of this last kernel
-    uint64_t *done_flag;
-    uint64_t done_value;
-    // ticket of the stream-A part of the batch (K1, search, this kernel), always published; done_flag may be null
-    // when K3 and what follows it run later on the second stream and publish the batch ticket themselves
-    uint64_t *adone_flag;
-    // Pipelined callers: K3.. of the PREVIOUS batch run on the second stream next to this batch's search.  When they
-    // take longer than the search, the next K1 launch (which needs every wave slot of the chip) has to wait for them:
-    // this kernel, the last one in front of it, spins until the device word `wait_flag` reaches `wait_value`
-    // (k_done of that batch) -- for at most ~2 ms, in case the host never launches them.
-    const uint64_t *wait_flag;
-    uint64_t wait_value;
-};
-
-__global__ __launch_bounds__(1024) void k_hist_update(const HistArgs a)
-{
-    extern __shared__ uint32_t tmp[];  // hr*wpb words
-    if (threadIdx.x < a.carry_bytes / 16)
-        reinterpret_cast<uint4 *>(a.carry_dst)[threadIdx.x] = reinterpret_cast<const uint4 *>(a.carry_src)[threadIdx.x];
-    if (threadIdx.x == 1023) *a.ovf_next = 0;
-    for (uint32_t i = threadIdx.x; i < a.gcnt_words; i += 1024) a.gcnt_next[i] = 0;
-    const uint32_t n = a.hr << a.lg_wpb;
-    for (uint32_t i = threadIdx.x; i < n; i += 1024) {
-        const uint32_t j = i >> a.lg_wpb, w = i & (a.wpb - 1);
-        // new history row j = stream row (n_blocks - hr + j) of the batch; negative -> old history
-        const int64_t srow = (int64_t)64 + a.n_blocks - a.hr + j;  // tiled row index (tile 0 rows 0..63 = old history)
-        tmp[i] = a.qt[qt_index((uint64_t)srow, w, a.lg_wpb)];
-    }
-    __syncthreads();
-    for (uint32_t i = threadIdx.x; i < n; i += 1024) {
-        const uint32_t j = i >> a.lg_wpb, w = i & (a.wpb - 1);
-        const size_t di = qt_index(64 - a.hr + j, w, a.lg_wpb);
-        a.qt_next[di] = tmp[i];
-    }
-    __syncthreads();
-    // every earlier kernel of the batch has completed (same stream); the host polls this word
-    if (threadIdx.x == 0) {
-        if (a.adone_flag) __hip_atomic_store(a.adone_flag, a.done_value, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-        if (a.done_flag) __hip_atomic_store(a.done_flag, a.done_value, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-        if (a.wait_flag) {
-            const uint64_t t0 = __builtin_amdgcn_s_memrealtime();   // 100 MHz
-            while (__hip_atomic_load(a.wait_flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < a.wait_value &&
-                   __builtin_amdgcn_s_memrealtime() - t0 < 200000ull)
-                __builtin_amdgcn_s_sleep(32);
         }
     }
 }

@@ -186,7 +186,13 @@ __global__ __launch_bounds__(64 * NWV, AMR_K2S_OCC) void k2_search_stream(const 
     // a.xcd: workgroup b runs on XCD b % 8; give every XCD one contiguous run of tiles (the grid is rounded up to 8 runs)
     const uint32_t T = a.xcd ? (blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3) : blockIdx.x;
     k2_announce(a);
-    if (T >= a.n_tiles) return;
+    if (T >= a.n_tiles) {
+        if (a.do_hist && T == a.n_tiles) {     // the state update of the batch, next to the search instead of behind it
+            hist_body(a.hist, lds, 64 * NWV);
+            if (threadIdx.x == 0) hist_publish(a.hist);   // no tickets here (the search is still running): only the wait
+        }
+        return;
+    }
     K2S_STAMP(0);
     if (a.dbg && threadIdx.x == 0) a.dbg[(size_t)blockIdx.x * 16 + 8] = __builtin_amdgcn_s_memrealtime();
     const uint32_t tid = threadIdx.x, lane = tid & 63;
