@@ -139,6 +139,10 @@ struct amr_handle {
     hipStream_t own_stream = nullptr, stream = nullptr, copy_stream = nullptr, h2d_stream = nullptr;
     // K3 / K4 / K5 of batch i run here, next to the search of batch i+1, once the caller pipelines (lazy_tail)
     hipStream_t tail_stream = nullptr;
+    // the K1 launch of a batch's last, partial wave-tile (n_blocks % 64 blocks: ONE wave, which takes as long as a whole
+    // chip-filling launch) runs on the host-input stream, next to the main launch instead of behind it.  (A stream of
+    // its own ended up on the hardware queue of tail_stream and held the K3 launches up.)
+    hipEvent_t ev_k1rem = nullptr;
     bool lazy_tail = false;
     bool allow_lazy = true;      // AMR_TAIL_OVERLAP=0: everything on one stream, as before
     // false (default): the host launches the tail when it sees the next batch's search start (a pinned flag; no event on
@@ -600,7 +604,17 @@ amr_status submit(amr_handle *h, const uint8_t *d_iq, size_t n_blocks, bool sear
         k1.wg_first = w0;
         launch_k1<false>(h->geom.chip_length, dim3(n), st, k1, w0 == 0 ? e0 : nullptr, (w0 + n == full && !rem) ? e1 : nullptr);
     }
-    if (rem) { k1.wg_first = full; launch_k1<true>(h->geom.chip_length, dim3(1), st, k1, full ? nullptr : e0, e1); }
+    if (rem && full && !e1) {
+        // the partial wave-tile needs nothing from the compute stream (its halo lies inside this batch's IQ, its rows in
+        // a slot that holds no batch): it runs on a stream of its own, and the search waits for it
+        k1.wg_first = full;
+        launch_k1<true>(h->geom.chip_length, dim3(1), h->h2d_stream, k1, nullptr, nullptr);
+        HIP_TRY(hipEventRecord(h->ev_k1rem, h->h2d_stream));
+        HIP_TRY(hipStreamWaitEvent(st, h->ev_k1rem, 0));
+    } else if (rem) {
+        k1.wg_first = full;
+        launch_k1<true>(h->geom.chip_length, dim3(1), st, k1, full ? nullptr : e0, e1);
+    }
     HIP_TRY(hipGetLastError());
     AMR_DBG(st, "k1_demod");
     if (prev_tail_now) {
@@ -1042,6 +1056,7 @@ amr_status amr_create(const amr_protocol *protos, int32_t n_protos, int32_t devi
     if (e == hipSuccess) e = hipStreamCreateWithFlags(&h->copy_stream, hipStreamNonBlocking);
     if (e == hipSuccess) e = hipStreamCreateWithFlags(&h->h2d_stream, hipStreamNonBlocking);
     if (e == hipSuccess) e = hipStreamCreateWithFlags(&h->tail_stream, hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&h->ev_k1rem, hipEventDisableTiming);
     if (e == hipSuccess) e = hipHostMalloc((void **)&h->h_flags, 16, hipHostMallocCoherent);
     if (e == hipSuccess) { h->h_flags[0] = 0; h->h_flags[1] = 0; }
     if (e == hipSuccess) e = hipMalloc((void **)&h->d_tail_done, 8);
@@ -1097,6 +1112,7 @@ amr_status amr_destroy(amr_handle *h)
     (void)hipSetDevice(h->device);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
     if (h->tail_stream) (void)hipStreamSynchronize(h->tail_stream);
+    if (h->h2d_stream) (void)hipStreamSynchronize(h->h2d_stream);
     if (h->copy_stream) (void)hipStreamSynchronize(h->copy_stream);
     void *ptrs[] = {h->d_lut, h->d_carry, h->d_iq, h->d_untile, h->d_tail_done};
     for (void *p : ptrs) if (p) (void)hipFree(p);
@@ -1119,6 +1135,7 @@ amr_status amr_destroy(amr_handle *h)
     if (h->copy_stream) (void)hipStreamDestroy(h->copy_stream);
     if (h->h2d_stream) (void)hipStreamDestroy(h->h2d_stream);
     if (h->tail_stream) (void)hipStreamDestroy(h->tail_stream);
+    if (h->ev_k1rem) (void)hipEventDestroy(h->ev_k1rem);
     delete h;
     return AMR_OK;
 }
