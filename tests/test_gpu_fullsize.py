@@ -61,7 +61,7 @@ CASES = [
     # (name, protocols, chip, bytes, planted kind, packets)
     ("cfg2_scm72_1GiB", ["scm"], 72, 1 * GIB, "scm", 4096),
     ("cfg3_idm72_4GiB", ["idm"], 72, 4 * GIB, "idm", 4096),
-    ("cfg5_all72_2GiB", ["scm", "scm+", "idm", "r900"], 72, 2 * GIB, "scm+", 2048),
+    ("cfg5_all72_4GiB", ["scm", "scm+", "idm", "r900"], 72, 4 * GIB, "scm+", 4096),
 ] + [(f"cfg4_scm{c}_1GiB", ["scm"], c, 1 * GIB, "scm", 4096) for c in (8, 32, 40, 48, 56, 64)]
 
 
