@@ -489,7 +489,7 @@ def main():
                          "traffic_source": traffic_src,
                          "k1_ms": round(k1_ms, 4), "k1_timing": ("HIP events on the K1 dispatch of every timed step" if args.k1_events == 1 else
                                        f"HIP events on the K1 dispatch of every {args.k1_events}th timed step ({len(demod_ms)} launches)"),
-                         "search_ms": round(float(np.mean(search_ms)), 4), "search_timing": "warm-up steps",
+                         "search_ms": round(float(np.mean(search_ms)), 4), "search_timing": "warm-up steps; K2 duration + K3.. duration (they run on two streams once batches are in flight, K3 next to the following K2)",
                          "algorithmic_bytes_per_launch": ALG_BYTES_PER_SAMPLE * n_samples},
         }
         if world == 1 and not args.no_cpu_baseline:
