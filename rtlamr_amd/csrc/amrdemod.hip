@@ -139,10 +139,6 @@ struct amr_handle {
     hipStream_t own_stream = nullptr, stream = nullptr, copy_stream = nullptr, h2d_stream = nullptr;
     // K3 / K4 / K5 of batch i run here, next to the search of batch i+1, once the caller pipelines (lazy_tail)
     hipStream_t tail_stream = nullptr;
-    // the K1 launch of a batch's last, partial wave-tile (n_blocks % 64 blocks: ONE wave, which takes as long as a whole
-    // chip-filling launch) runs on the host-input stream, next to the main launch instead of behind it.  (A stream of
-    // its own ended up on the hardware queue of tail_stream and held the K3 launches up.)
-    hipEvent_t ev_k1rem = nullptr, ev_k1rem_in = nullptr;
     bool lazy_tail = false;
     bool allow_lazy = true;      // AMR_TAIL_OVERLAP=0: everything on one stream, as before
     // false (default): the host launches the tail when it sees the next batch's search start (a pinned flag; no event on
@@ -599,27 +595,12 @@ amr_status submit(amr_handle *h, const uint8_t *d_iq, size_t n_blocks, bool sear
     static const int round_env = [] { const char *e = getenv("AMR_K1_ROUND"); return e ? atoi(e) : -1; }();
     const uint32_t round = round_env == 0 ? full : round_env > 0 ? (uint32_t)round_env
                          : bs >= 4096 ? (uint32_t)h->n_cus * 8u : full;
-    const bool rem_aside = rem && full && !e1;
-    if (rem_aside) {
-        // The partial wave-tile of a batch that is not a multiple of 64 blocks is ONE wave, and a wave takes as long as
-        // a whole chip-filling launch: it runs on the host-input stream next to the main launch instead of behind it.
-        // It needs the batch's input, which may still be on its way on the compute stream (a staged host batch, the
-        // caller's own producer kernels): that stream's state is taken first.  Its rows lie in a slot that holds no
-        // batch; the search waits for it.
-        HIP_TRY(hipEventRecord(h->ev_k1rem_in, st));
-        HIP_TRY(hipStreamWaitEvent(h->h2d_stream, h->ev_k1rem_in, 0));
-        k1.wg_first = full;
-        launch_k1<true>(h->geom.chip_length, dim3(1), h->h2d_stream, k1, nullptr, nullptr);
-        HIP_TRY(hipEventRecord(h->ev_k1rem, h->h2d_stream));
-    }
     for (uint32_t w0 = 0; w0 < full; w0 += round) {
         const uint32_t n = std::min(round, full - w0);
         k1.wg_first = w0;
         launch_k1<false>(h->geom.chip_length, dim3(n), st, k1, w0 == 0 ? e0 : nullptr, (w0 + n == full && !rem) ? e1 : nullptr);
     }
-    if (rem_aside) {
-        HIP_TRY(hipStreamWaitEvent(st, h->ev_k1rem, 0));
-    } else if (rem) {
+    if (rem) {   // the partial wave-tile: one wave (wave quantisation)
         k1.wg_first = full;
         launch_k1<true>(h->geom.chip_length, dim3(1), st, k1, full ? nullptr : e0, e1);
     }
@@ -1064,8 +1045,6 @@ amr_status amr_create(const amr_protocol *protos, int32_t n_protos, int32_t devi
     if (e == hipSuccess) e = hipStreamCreateWithFlags(&h->copy_stream, hipStreamNonBlocking);
     if (e == hipSuccess) e = hipStreamCreateWithFlags(&h->h2d_stream, hipStreamNonBlocking);
     if (e == hipSuccess) e = hipStreamCreateWithFlags(&h->tail_stream, hipStreamNonBlocking);
-    if (e == hipSuccess) e = hipEventCreateWithFlags(&h->ev_k1rem, hipEventDisableTiming);
-    if (e == hipSuccess) e = hipEventCreateWithFlags(&h->ev_k1rem_in, hipEventDisableTiming);
     if (e == hipSuccess) e = hipHostMalloc((void **)&h->h_flags, 16, hipHostMallocCoherent);
     if (e == hipSuccess) { h->h_flags[0] = 0; h->h_flags[1] = 0; }
     if (e == hipSuccess) e = hipMalloc((void **)&h->d_tail_done, 8);
@@ -1121,7 +1100,6 @@ amr_status amr_destroy(amr_handle *h)
     (void)hipSetDevice(h->device);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
     if (h->tail_stream) (void)hipStreamSynchronize(h->tail_stream);
-    if (h->h2d_stream) (void)hipStreamSynchronize(h->h2d_stream);
     if (h->copy_stream) (void)hipStreamSynchronize(h->copy_stream);
     void *ptrs[] = {h->d_lut, h->d_carry, h->d_iq, h->d_untile, h->d_tail_done};
     for (void *p : ptrs) if (p) (void)hipFree(p);
@@ -1144,8 +1122,6 @@ amr_status amr_destroy(amr_handle *h)
     if (h->copy_stream) (void)hipStreamDestroy(h->copy_stream);
     if (h->h2d_stream) (void)hipStreamDestroy(h->h2d_stream);
     if (h->tail_stream) (void)hipStreamDestroy(h->tail_stream);
-    if (h->ev_k1rem) (void)hipEventDestroy(h->ev_k1rem);
-    if (h->ev_k1rem_in) (void)hipEventDestroy(h->ev_k1rem_in);
     delete h;
     return AMR_OK;
 }
