@@ -15,9 +15,13 @@ Workloads (--workload, BASELINE.json configs 2-5; cfg1 is the CPU-only plumbing 
 
 Before the warm-up the GPU is spun up with untimed passes for --spinup-ms: the shader clock of an idle MI355X needs
 tens of milliseconds of load to reach its steady value (K1 measured at 1.6 GHz in the first 5 ms of a fresh process,
-2.4 GHz after 60 ms), and a 20-step timed region is only 6 ms long.  After the timed region the step's hit count is
-compared with the committed golden count of the workload (tests/golden/bench_counts.json) and, on rank 0, a validating
+2.4 GHz after 60 ms), and a 20-step timed region is only 6 ms long.  After the timed region the last step's complete
+result (hit list, packet bytes, quantized bitstream) is compared by sha256 with what the CPU oracle computed for the
+workload (tests/golden/bench_golden.json, made by tests/golden/make_bench_golden.py) and, on rank 0, a validating
 decoder must turn the batch into exactly the planted messages; a mismatch makes the exit code non-zero.
+
+N > 1: every rank's hits that pass the parsers' checksum tests on the GPU (K5; --gather raw: every hit) travel to rank 0
+each step through the library's RCCL gather, and rank 0 reads every step's records inside the timed loop.
 
 Launch:  python bench.py [--gpus 1] [--steps K] [--warmup W] [--workload cfg2]
          python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
@@ -39,7 +43,7 @@ sys.path.insert(0, ROOT)
 GIB = 1 << 30
 HBM_PEAK_GBS = 8000.0        # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
 ALG_BYTES_PER_SAMPLE = 2.0   # K1 reads one (I,Q) uint8 pair per sample
-GOLDEN = os.path.join(ROOT, "tests", "golden", "bench_counts.json")
+GOLDEN = os.path.join(ROOT, "tests", "golden", "bench_golden.json")
 LEGAL_CHIPS = (8, 32, 40, 48, 56, 64, 72, 80, 88, 96)
 
 
@@ -76,13 +80,55 @@ def build_packets(wl: dict, shard: int, bs: int, n_samples: int):
     kinds = wl["kinds"]
     longest = max(B[k][1] for k in kinds) * 2 * wl["chip"]
     base = shard * n_samples
-    starts = synth.packet_schedule(wl["n_packets"], n_samples, longest, seed=1 + shard, edge_every=64, block_size=bs)
+    n_packets = max(1, min(wl["n_packets"], n_samples // (4 * longest)))      # --blocks N: fewer packets in a short stream
+    starts = synth.packet_schedule(n_packets, n_samples, longest, seed=1 + shard, edge_every=64, block_size=bs)
     pk = []
     for i, s in enumerate(starts):
         fn, nbits = B[kinds[i % len(kinds)]]
         sign = 1 if i % 2 else -1
         pk.append(synth.Packet(int(base + s), fn(shard * wl["n_packets"] + i), nbits, sign * (22 + i % 17), -sign * (21 + i % 13)))
     return pk
+
+
+def device_workload(dec, wl: dict, shard_idx: int, n_blocks: int, local_rank: int = 0):
+    """Shard `shard_idx` of the workload's stream, generated in HBM (SURVEY.md 8d generator, K0), and -- for shards
+    behind the first -- the decoder primed with the blocks in front of it (amr_prime), as a rank of a multi-GPU run
+    does.  -> (device pointer as ctypes.c_void_p, the shard's planted packets).  tests/golden/make_bench_golden.py
+    builds the same stream on the host for the oracle."""
+    from rtlamr_amd import _lib, synth
+    L = _lib.lib()
+    chip = wl["chip"]
+    bs, bs2 = dec.Cfg.BlockSize, dec.Cfg.BlockSize2
+    n_samples = n_blocks * bs
+    d_iq = C.c_void_p()
+    _lib.check(L.amr_dev_alloc(local_rank, n_blocks * bs2, C.byref(d_iq)), "amr_dev_alloc")
+    pk = build_packets(wl, shard_idx, bs, n_samples)
+    synth.device_fill(local_rank, d_iq.value, n_samples, seed=1, first_sample=shard_idx * n_samples, packets=pk,
+                      chip_length=chip)
+    if shard_idx > 0:   # rebuild the history a single decoder would carry into this shard
+        pb = dec.prime_blocks()
+        hb = pb + 1
+        d_h = C.c_void_p()
+        _lib.check(L.amr_dev_alloc(local_rank, hb * bs2, C.byref(d_h)), "amr_dev_alloc")
+        prev = build_packets(wl, shard_idx - 1, bs, n_samples)
+        synth.device_fill(local_rank, d_h.value, hb * bs, seed=1, first_sample=shard_idx * n_samples - hb * bs,
+                          packets=prev[-8:] + pk[:1], chip_length=chip)
+        dec.prime_device(d_h.value + bs2, pb, d_lead=d_h.value + bs2 - dec.halo_bytes())
+        dec.set_block_base(shard_idx * n_blocks)
+        _lib.check(L.amr_dev_free(local_rank, d_h), "amr_dev_free")
+    return d_iq, pk
+
+
+def result_digest(rows, pkt, q) -> dict:
+    """sha256 fingerprints of a decode result in the canonical form of oracle.result_digest (restated here so that the
+    timed path of bench.py imports nothing from oracle/): rows int64[n,3] (pid, call, idx) preamble-major, packet
+    bytes in the same order, packed bitstream MSB first."""
+    import hashlib
+    import numpy as np
+    return {"n_hits": int(len(rows)),
+            "hits_sha256": hashlib.sha256(np.ascontiguousarray(rows, np.int64).tobytes()).hexdigest(),
+            "pkt_sha256": hashlib.sha256(np.ascontiguousarray(pkt, np.uint8).tobytes()).hexdigest(),
+            "q_sha256": hashlib.sha256(np.ascontiguousarray(q, np.uint8).tobytes()).hexdigest()}
 
 
 def cpu_baseline(wl, dec, d_iq, bs2, seconds=12.0):
@@ -150,10 +196,9 @@ def verify_batch(ra, wl, local_rank, d_iq, n_blocks, pk, bs, n_samples):
         dec.close()
 
 
-def sharded_gather_check(ra, shard, wl, local_rank, rank, world, n_blocks=256, cabi=True, device=None):
+def sharded_gather_check(ra, shard, wl, local_rank, rank, world, n_blocks=256):
     """Every rank decodes its block range of one small stream (primed with the blocks before it), the hits are gathered
-    through the C ABI (cabi=False: with torch.distributed), and rank 0 compares them with its own single-decoder result
-    for the whole stream."""
+    through the C ABI, and rank 0 compares them with its own single-decoder result for the whole stream."""
     import numpy as np
     import torch.distributed as dist
     from rtlamr_amd import synth
@@ -177,20 +222,17 @@ def sharded_gather_check(ra, shard, wl, local_rank, rank, world, n_blocks=256, c
             fn, nbits = B[kinds[i % len(kinds)]]
             pk.append(synth.Packet(int(s), fn(900 + i), nbits, 27 if i % 2 else -27, -25 if i % 2 else 25))
         synth.plant(iq, pk, wl["chip"])
-        g = shard.CommGatherer(dec, cap_hits=1 << 16) if cabi else None
+        g = shard.CommGatherer(dec, cap_hits=1 << 16)
         k0, k1 = shard.shard_range(n_blocks, world, rank)
         p0, _ = shard.prime_range(k0, dec.prime_blocks())
         if k0 > p0:
             dec.prime(iq[p0 * bs2: k0 * bs2], iq[p0 * bs2 - dec.halo_bytes(): p0 * bs2] if p0 > 0 else None)
         dec.set_block_base(k0)
-        br_mine = dec.decode_batch(iq[k0 * bs2: k1 * bs2])
-        if cabi:
-            g.post()
-            got = g.result()
-        else:
-            got = shard.gather_hits(shard.batch_hits_array(br_mine, dec.n_preambles), device=device)
-        how = "C ABI gather" if cabi else "torch.distributed gather"
-        ok, detail = True, f"{n_blocks}-block stream over {world} rank(s), {how}: gathered hits == single decoder"
+        dec.decode_batch(iq[k0 * bs2: k1 * bs2])
+        g.post()
+        got = g.result()
+        g.wait()
+        ok, detail = True, f"{n_blocks}-block stream over {world} rank(s), C ABI gather: gathered hits == single decoder"
         if rank == 0:
             one = mk()
             try:
@@ -201,7 +243,7 @@ def sharded_gather_check(ra, shard, wl, local_rank, rank, world, n_blocks=256, c
             order = np.lexsort((got[:, 2], got[:, 1], got[:, 0]))
             ok = len(want) > 0 and np.array_equal(got[order], want)
             if not ok:
-                detail = f"MISMATCH ({how}): gathered {len(got)} hit records, single decoder {len(want)}"
+                detail = f"MISMATCH (C ABI gather): gathered {len(got)} hit records, single decoder {len(want)}"
         flag = [ok]
         dist.broadcast_object_list(flag, src=0)
         return bool(flag[0]), detail
@@ -220,11 +262,13 @@ def main():
     ap.add_argument("--depth", type=int, default=3, help="batches in flight (1..3)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-verify", action="store_true", help="skip the golden hit count / planted message check")
-    ap.add_argument("--write-golden", action="store_true", help="record this run's hit count as the workload's golden count")
     ap.add_argument("--k1-events", type=int, default=4,
                     help="HIP events around the K1 dispatch of every N-th timed step (0 = none: roofline fields are NaN)")
     ap.add_argument("--validate", action="store_true",
                     help="also run the parsers' checksum tests + repeat removal on the GPU (K5); only surviving hits are read back")
+    ap.add_argument("--gather", choices=["validated", "raw"], default="validated",
+                    help="N > 1: what travels to rank 0 every step -- the hits that pass the parsers' checksum tests on the "
+                         "GPU (default; turns --validate on) or every hit the search found")
     args = ap.parse_args()
     wl = workload(args.workload)
 
@@ -250,38 +294,28 @@ def main():
     for p in wl["protos"]:
         dec.RegisterProtocol(ra.new_parser(p, chip))
     dec.Allocate()
-    if args.validate:
-        dec.EnableValidation()
     bs, bs2 = dec.Cfg.BlockSize, dec.Cfg.BlockSize2
     n_blocks = args.blocks or wl["nbytes"] // bs2
     n_samples = n_blocks * bs
     nbytes = n_blocks * bs2
 
-    d_iq = C.c_void_p()
-    _lib.check(L.amr_dev_alloc(local_rank, nbytes, C.byref(d_iq)), "amr_dev_alloc")
-
-    # ---- synthetic workload, generated in HBM (K0) ----
     # developer hook: build the workload of shard AMR_BENCH_SHARD on a single GPU (exercises the priming path of
     # ranks > 0 without a second GPU); the process stays rank 0 of a world of 1
     shard_idx = int(os.environ.get("AMR_BENCH_SHARD", rank))
-    pk = build_packets(wl, shard_idx, bs, n_samples)
-    synth.device_fill(local_rank, d_iq.value, n_samples, seed=1, first_sample=shard_idx * n_samples, packets=pk,
-                      chip_length=chip)
-    if shard_idx > 0:   # rebuild the history a single decoder would carry into this shard
-        pb = dec.prime_blocks()
-        hb = pb + 1
-        d_h = C.c_void_p()
-        _lib.check(L.amr_dev_alloc(local_rank, hb * bs2, C.byref(d_h)), "amr_dev_alloc")
-        prev = build_packets(wl, shard_idx - 1, bs, n_samples)
-        synth.device_fill(local_rank, d_h.value, hb * bs, seed=1, first_sample=shard_idx * n_samples - hb * bs,
-                          packets=prev[-8:] + pk[:1], chip_length=chip)
-        dec.prime_device(d_h.value + bs2, pb, d_lead=d_h.value + bs2 - dec.halo_bytes())
-        dec.set_block_base(shard_idx * n_blocks)
-        _lib.check(L.amr_dev_free(local_rank, d_h), "amr_dev_free")
+    d_iq, pk = device_workload(dec, wl, shard_idx, n_blocks, local_rank)
 
     dev = torch.device("cuda", local_rank) if distributed else None
     gatherer = None
     gather_kind = "none (single GPU)"
+    check = {}
+    rc = 0
+    try:
+        gold = json.load(open(GOLDEN))
+    except Exception:
+        gold = {}
+    key = f"{wl['name']}|blocks={n_blocks}|shard={shard_idx}"
+    verify = not args.no_verify
+    aligned = n_blocks % 64 == 0       # otherwise deferral shifts the calls a result covers from step to step
 
     def sync_all():
         if distributed:
@@ -291,18 +325,114 @@ def main():
         if distributed:
             dist.barrier()
 
-    state = {"gather_truncated": False}
+    def rows_pkt(br):
+        """canonical form of a result: int64 rows (pid, call index within the N-shard stream, idx), packet bytes"""
+        rows, pkts = [], []
+        for pid in range(dec.n_preambles):
+            blk, idx, pkt = br.for_preamble(pid)
+            rows.append(np.stack([np.full(len(blk), pid, np.int64), blk.astype(np.int64) - (br.first_block - shard_idx * n_blocks),
+                                  idx.astype(np.int64)], axis=1))
+            pkts.append(pkt)
+        return np.concatenate(rows), np.concatenate(pkts)
+
+    def against_golden(br, state, label):
+        """sha256 of the complete result of one batch -- hit list, packet bytes, packed quantized bitstream -- against
+        what the CPU oracle computed for this (workload, size, shard, decoder state); tests/golden/make_bench_golden.py,
+        nothing in that file ever came from a GPU."""
+        nonlocal rc
+        if not verify:
+            return
+        if key not in gold:
+            check[label] = f"no oracle golden for {key} (tests/golden/make_bench_golden.py --blocks {n_blocks})"
+            return
+        g = gold[key][state]
+        rows, pkts = rows_pkt(br)
+        got = result_digest(rows, pkts, dec.quantized_packed())
+        want = dict(g["validated"], q_sha256=g["q_sha256"]) if validating else {k: g[k] for k in got}
+        bad = [k for k in got if got[k] != want[k]] + ([] if br.n_hits_searched == g["n_hits"] else ["n_hits_searched"])
+        what = "validated hit list + packet bytes" if validating else "hit list + packet bytes"
+        check[label] = (f"{br.n_hits_searched} hits searched, {what} + the whole quantized bitstream: sha256 == oracle golden "
+                        f"['{state}']" if not bad else f"MISMATCH against the oracle golden ['{state}'] in {bad}")
+        rc = rc or (3 if bad else 0)
+
+    # ---- N > 1: the hit gather.  Validated hits by default (the parsers' checksum + repeat filter on the GPU, K5): a
+    # step's 290 131 raw hits are 4 169 records after it, and the root consumes EVERY step's records inside the timed loop
+    validating = args.validate or (distributed and args.gather != "raw")
+    if validating:
+        dec.EnableValidation()
+    try:
+        dec.SetDeferral(True)      # any block count per batch at the full rate (--blocks N); no-op for multiples of 64
+        deferral = True
+    except _lib.AmrError:
+        deferral = False           # the r900 second stage reads the batch's IQ by block (cfg5)
+
+    # the first batch, from the state a single Decoder carries into this shard: against the oracle golden ["first"]
+    first = dec.decode_batch_device(d_iq.value, n_blocks)
+    against_golden(first, "first", "first_batch")
+    n_first = len(first.hit_idx)
+    gstat = {"consumed": 0, "records": 0, "bad": [], "checksum": 0, "local": {}}
+    if distributed:
+        t = torch.tensor([n_first], dtype=torch.int64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        cap = max(1024, int(int(t.item()) * 1.5))
+
+        # Every decision below is taken by all ranks together (all_reduce MIN), so that no rank waits in a collective
+        # the others never enter.
+        def all_agree(flag: bool) -> bool:
+            t = torch.tensor([1 if flag else 0], dtype=torch.int64, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MIN)
+            return bool(int(t.item()))
+        try:
+            shard.comm_unique_id()            # loads librccl through the library: fails here, not inside a collective
+            loadable = True
+        except Exception as e:
+            loadable = False
+            check["sharded_gather"] = f"C-ABI gather unavailable ({e})"
+        ok = all_agree(loadable)
+        if ok:
+            # Before anything is timed: a 256-block stream sharded over the ranks (HIP engine + amr_prime + the gather)
+            # must give exactly what rank 0's single decoder gives for the whole stream.
+            try:
+                ok, detail = sharded_gather_check(ra, shard, wl, local_rank, rank, world)
+            except Exception as e:
+                ok, detail = False, f"C-ABI gather failed ({e})"
+            check["sharded_gather"] = detail
+            ok = all_agree(ok)
+        if not ok:
+            rc = 5
+            print(f"bench.py: the multi-GPU hit gather is not usable: {check}", file=sys.stderr)
+            dist.destroy_process_group()
+            return rc
+        gatherer = shard.CommGatherer(dec, cap_hits=cap)
+        gather_kind = ("C ABI amr_gather_hits: RCCL send/recv of (call index, idx) records to rank 0 on the library's own stream, "
+                       "one per step, no host synchronisation; rank 0 reads every step's records from the pinned mirror "
+                       "(amr_gather_fetch) inside the timed loop, one gather behind")
+
+    def consume(seq):
+        """Rank 0, inside the timed loop: the records every rank contributed to gather `seq`, read from the library's
+        pinned mirror -- header checks, every record touched, rank 0's own records compared with its local result."""
+        for r in range(world):
+            n_true, off, blk, idx = gatherer.fetch(seq, r, copy=False)
+            if n_true != len(blk):
+                gstat["bad"].append(f"gather {seq} rank {r}: truncated ({n_true} > {len(blk)})")
+            gstat["checksum"] += int(blk.sum(dtype=np.uint64)) + int(idx.sum(dtype=np.uint64))
+            gstat["records"] += len(blk)
+            if r == rank and seq in gstat["local"]:
+                lb, li = gstat["local"].pop(seq)
+                if not (np.array_equal(lb, blk) and np.array_equal(li, idx)):
+                    gstat["bad"].append(f"gather {seq}: rank 0's gathered records differ from its local result")
+        gstat["consumed"] += 1
 
     def finish():
         """Collect the oldest batch: read back its hits and (N > 1) gather them on rank 0 over RCCL."""
         br = dec.collect(copy=False)
-        if distributed:   # records go device -> RCCL -> rank 0, asynchronously, behind the kernels of the next batch
-            if isinstance(gatherer, shard.CommGatherer):
-                gatherer.post()                    # C ABI: amr_gather_hits, no host synchronisation
-            else:
-                d_ptr, _ = dec.result_device()
-                if not gatherer.post(br, d_ptr):
-                    state["gather_truncated"] = True   # sent truncated; every rank keeps issuing the same collectives
+        if distributed:   # records go device -> RCCL -> rank 0, asynchronously, behind the kernels of the next batches
+            seq = gatherer.post()                  # C ABI: amr_gather_hits, no host synchronisation
+            if rank == 0:
+                if validating:
+                    gstat["local"][seq] = (np.array(br.hit_block, np.uint64), np.array(br.hit_idx, np.uint32))
+                if seq >= 1:
+                    consume(seq - 1)               # posted one step ago: normally there already
         return br
 
     def run(n, level, every=1):
@@ -330,56 +460,6 @@ def main():
             done += 1
         return out
 
-    # Timing events cost a ~5 us stream bubble each: the warm-up steps carry the full set
-    # (K1 + search); of the timed steps every --k1-events-th carries K1's start/stop pair, which the roofline figure
-    # needs (measured: events on every step cost 2 % of the step, on every 4th 0.5 %; the K1 average is the same).
-    dec.set_timing(2)
-    check = {"hit_count": "skipped", "planted": "skipped"}
-    rc = 0
-    if distributed:
-        # one untimed batch tells every rank how many hit records a batch yields; the capacity of the gather is agreed once
-        dec.submit_device(d_iq.value, n_blocks)
-        n_first = len(dec.collect(copy=False).hit_idx)
-        t = torch.tensor([n_first], dtype=torch.int64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        cap = max(1024, int(int(t.item()) * 1.5))
-        # Before anything is timed: a 256-block stream sharded over the ranks (HIP engine + amr_prime + the gather) must
-        # give exactly what rank 0's single decoder gives for the whole stream.  Every decision below is taken by all
-        # ranks together (all_reduce MIN), so that no rank waits in a collective the others never enter.
-        def all_agree(flag: bool) -> bool:
-            t = torch.tensor([1 if flag else 0], dtype=torch.int64, device=dev)
-            dist.all_reduce(t, op=dist.ReduceOp.MIN)
-            return bool(int(t.item()))
-
-        use_cabi = os.environ.get("AMR_BENCH_GATHER", "cabi") == "cabi"
-        if use_cabi:
-            try:
-                shard.comm_unique_id()            # loads librccl through the library: fails here, not inside a collective
-                loadable = True
-            except Exception as e:
-                loadable = False
-                check["sharded_gather"] = f"C-ABI gather unavailable ({e})"
-            use_cabi = all_agree(loadable)
-        if use_cabi:
-            try:
-                ok, detail = sharded_gather_check(ra, shard, wl, local_rank, rank, world)
-            except Exception as e:
-                ok, detail = False, f"C-ABI gather failed ({e})"
-            check["sharded_gather"] = detail
-            use_cabi = all_agree(ok)
-        if use_cabi:
-            gatherer = shard.CommGatherer(dec, cap_hits=cap)
-            gather_kind = ("C ABI amr_gather_hits: RCCL send/recv of (block, idx) records to rank 0 on the library's own "
-                           "stream, one per step, no host synchronisation")
-        else:   # the torch.distributed path, checked the same way; a mismatch here fails the run
-            ok, detail = sharded_gather_check(ra, shard, wl, local_rank, rank, world, cabi=False, device=dev)
-            check["sharded_gather"] = (check.get("sharded_gather", "") + "; " if "sharded_gather" in check else "") + detail
-            rc = rc or (0 if all_agree(ok) else 5)
-        if gatherer is None:
-            gatherer = shard.HitGatherer(dec.n_preambles, device=dev)
-            gatherer.negotiate(n_first)
-            gather_kind = "torch.distributed.gather (RCCL) of (block, idx) records to rank 0, one async collective per step"
-
     # ---- spin-up: untimed passes until the shader clock has ramped; they also give the steady-state step time ----
     spin_steps, steady_ms = 0, float("nan")
     if args.spinup_ms > 0:
@@ -400,57 +480,68 @@ def main():
             pairs.append((t_pair[1] - t_pair[0]) / chunk)
         steady_ms = float(np.median(pairs[-3:])) if pairs else float("nan")
 
+    # Timing events ride on the kernel dispatches (a separate event record costs a ~5 us stream bubble each): the warm-up
+    # steps and every --k1-events-th timed step carry the full set (K1 start/stop for the roofline figure, K2 and K3..
+    # for search_ms); measured: on every step 2 % of the step, on every 4th 0.5 %, the averages are the same.
     warm = run(max(args.warmup, 1), 2) if args.warmup else []
     sync_all()
+    c0, r0 = gstat["consumed"], gstat["records"]
     t0 = time.perf_counter()
-    res = run(args.steps, 1, args.k1_events)
+    res = run(args.steps, 2, args.k1_events)
     if distributed:
         gatherer.wait()
     sync_all()
     dt = time.perf_counter() - t0
-    demod_ms = [t["demod_ms"] for _, t in res if t is not None] or [float("nan")]
-    search_ms = [t["search_ms"] for _, t in warm] or [float("nan")]
-    n_hits = len(res[-1][0].hit_idx)
-    n_searched = res[-1][0].n_hits_searched
+    consumed_timed, records_timed = gstat["consumed"] - c0, gstat["records"] - r0
+    tms = [t for _, t in res if t is not None] or [t for _, t in warm]
+    demod_ms = [t["demod_ms"] for t in tms] or [float("nan")]
+    search_ms = [t["search_ms"] for t in tms] or [float("nan")]
+    last = res[-1][0]
+    n_hits = len(last.hit_idx)
+    n_searched = last.n_hits_searched
     if distributed:
         tt = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
 
-    # ---- what was timed is checked: golden hit count of this (workload, size, shard), planted messages on rank 0 ----
-    if distributed and isinstance(gatherer, shard.CommGatherer) and rank == 0:
-        try:        # the last step's gather on the root: every rank's records arrived untruncated
-            got = gatherer.result()
-            check["gathered_last_step"] = f"{len(got)} records from {world} rank(s)"
-        except OverflowError as e:
-            state["gather_truncated"] = True
-            check["gathered_last_step"] = str(e)
-    if not args.no_verify and not args.validate:
-        key = f"{wl['name']}|blocks={n_blocks}|shard={shard_idx}"
-        try:
-            gold = json.load(open(GOLDEN))
-        except Exception:
-            gold = {}
-        if args.write_golden:
-            gold[key] = int(n_searched)
-            json.dump(gold, open(GOLDEN, "w"), indent=1, sort_keys=True)
-        if key in gold:
-            ok = int(gold[key]) == int(n_searched)
-            check["hit_count"] = f"{n_searched} == golden" if ok else f"MISMATCH: {n_searched} != golden {gold[key]}"
-            rc = rc or (0 if ok else 3)
-        else:
-            check["hit_count"] = f"{n_searched} (no golden count for {key})"
-        if rank == 0 and shard_idx == 0:
-            n_want, n_missing, n_extra = verify_batch(ra, wl, local_rank, d_iq.value, n_blocks, pk, bs, n_samples)
-            ok = n_missing == 0 and n_extra == 0 and n_want > 0
-            check["planted"] = (f"{n_want} planted messages recovered, none missing, none unexpected" if ok else
-                                f"MISMATCH: {n_missing} of {n_want} planted messages missing, {n_extra} unexpected")
-            rc = rc or (0 if ok else 4)
+    # ---- what was timed is checked ----
+    # the last timed step saw the shard's own tail as history (the steps replay one buffer): oracle golden ["steady"]
+    if aligned:
+        against_golden(last, "steady", "last_timed_step")
+    else:
+        check["last_timed_step"] = f"{n_searched} hits searched (no digest: with {n_blocks} blocks per batch the calls a result covers shift from step to step)"
+    if distributed and rank == 0:
+        # the last gather, complete: every rank's records against the oracle golden of ITS shard, by sha256
+        seq = gatherer.last_seq
+        consume(seq)
+        for r in range(world):
+            n_true, off, blk, idx = gatherer.fetch(seq, r)
+            rows = shard.rows_from_gathered(off, blk, idx)
+            rows[:, 1] -= last.first_block - shard_idx * n_blocks   # every rank has made the same number of calls
+            kr = f"{wl['name']}|blocks={n_blocks}|shard={r if world > 1 else shard_idx}"
+            if verify and aligned and kr in gold:
+                g = gold[kr]["steady"]
+                want = (g["validated"] if validating else g)["hits_sha256"]
+                import hashlib
+                if hashlib.sha256(np.ascontiguousarray(rows, np.int64).tobytes()).hexdigest() != want:
+                    gstat["bad"].append(f"last gather: rank {r}'s records differ from the oracle golden of its shard")
+        check["gather"] = (f"{gstat['consumed']} gathers consumed on rank 0 ({consumed_timed} inside the timed region, "
+                           f"{records_timed} records), rank 0's records == its local result every step, the last gather's "
+                           f"records of all {world} rank(s) == oracle golden" if not gstat["bad"] else
+                           "MISMATCH: " + "; ".join(gstat["bad"][:4]))
+        rc = rc or (6 if gstat["bad"] else 0)
+    if verify and rank == 0 and shard_idx == 0 and not validating:
+        n_want, n_missing, n_extra = verify_batch(ra, wl, local_rank, d_iq.value, n_blocks, pk, bs, n_samples)
+        ok = n_missing == 0 and n_extra == 0 and n_want > 0
+        check["planted"] = (f"{n_want} planted messages recovered, none missing, none unexpected" if ok else
+                            f"MISMATCH: {n_missing} of {n_want} planted messages missing, {n_extra} unexpected")
+        rc = rc or (0 if ok else 4)
 
     if rank == 0:
         total_samples = float(world) * args.steps * n_samples
         k1_ms = float(np.mean(demod_ms))
-        achieved = ALG_BYTES_PER_SAMPLE * n_samples / (k1_ms * 1e-3) / 1e9
+        alg_bytes = ALG_BYTES_PER_SAMPLE * n_samples
+        achieved = alg_bytes / (k1_ms * 1e-3) / 1e9
         traffic, traffic_src = None, None
         tf = os.path.join(ROOT, "profiles", "k1_hbm_traffic.json")
         if wl["name"] == "cfg2" and n_blocks == GIB // bs2 and os.path.exists(tf):
@@ -461,7 +552,7 @@ def main():
             except Exception:
                 traffic = None
         # chip lengths up to 72 run the second-generation kernel (k1_tile.h), 80/88/96 the first (k1_demod.h)
-        k1_name = (f"k1t_demod<{chip}>" if chip <= 72 and os.environ.get("AMR_K1_IMPL") != "old" else f"k1_demod<{chip}>")
+        k1_name = f"k1t_demod<{chip}>" if chip <= 72 else f"k1_demod<{chip}>"
         ms_step = dt / args.steps * 1e3
         out = {
             "metric": "IQ Msamples/s through Decoder.Decode (SCM, 72 sym/len)" if wl["name"] == "cfg2" else
@@ -476,22 +567,31 @@ def main():
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"{wl['name']}: {'+'.join(wl['protos'])} chip {chip}, {n_blocks} blocks of {bs2} B per GPU",
                        "protocols": wl["protos"], "chip_length": chip,
-                       "block_size": bs, "bytes_per_gpu_per_step": nbytes, "planted_packets_per_gpu": wl["n_packets"],
+                       "block_size": bs, "bytes_per_gpu_per_step": nbytes, "planted_packets_per_gpu": len(pk),
                        "hits_per_step_rank0": n_hits, "hits_searched_per_step_rank0": n_searched,
-                       "gpu_validation": bool(args.validate),
+                       "gpu_validation": bool(validating), "deferral": deferral,
                        "spin_up": f"{spin_steps} untimed steps (~{args.spinup_ms:.0f} ms) before the warm-up: shader clock ramp",
                        "checks": check,
                        "iq_buffer": "first device allocation", "parallelism": f"block-range shards x{world}",
-                       "hit_gather": gather_kind,
-                       "hit_gather_truncated": state["gather_truncated"]},
+                       "hit_gather": gather_kind},
             "roofline": {"bound": "hbm", "kernel": k1_name, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                          "traffic_source": traffic_src,
-                         "k1_ms": round(k1_ms, 4), "k1_timing": ("HIP events on the K1 dispatch of every timed step" if args.k1_events == 1 else
-                                       f"HIP events on the K1 dispatch of every {args.k1_events}th timed step ({len(demod_ms)} launches)"),
-                         "search_ms": round(float(np.mean(search_ms)), 4), "search_timing": "warm-up steps; K2 duration + K3.. duration (they run on two streams once batches are in flight, K3 next to the following K2)",
-                         "algorithmic_bytes_per_launch": ALG_BYTES_PER_SAMPLE * n_samples},
+                         # the whole path, not only its dominant kernel: algorithmic bytes over the steady step / the timed step
+                         "whole_path_frac": round(alg_bytes / (steady_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                         "whole_path_frac_timed": round(alg_bytes / (ms_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                         "k1_ms": round(k1_ms, 4), "search_ms": round(float(np.mean(search_ms)), 4),
+                         "kernel_timing": (f"HIP events on the dispatches of every {args.k1_events}th timed step ({len(demod_ms)} steps): "
+                                           "K1 duration; search_ms = K2 duration + K3.. duration (two streams once batches are in "
+                                           "flight: K3 of a batch runs next to the following batch's K2)"),
+                         "algorithmic_bytes_per_launch": alg_bytes},
         }
+        if distributed:
+            slot = int(gatherer.slot_bytes)
+            out["config"].update({"rccl_ranks": dec.comm_ranks(),
+                                  "gather_bytes_per_step": {"sent_per_rank": slot, "payload_per_rank": 128 + 12 * n_hits,
+                                                            "into_root": slot * world},
+                                  "gather_records": "validated hits (K5)" if validating else "raw hits (--gather raw)"})
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(wl, dec, d_iq.value, bs2)
     else:

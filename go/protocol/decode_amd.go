@@ -6,7 +6,8 @@
 // constraint "//go:build !amd"); parse.go and every parser package stay as they
 // are.  The exported surface is the one of decode.go -- PacketConfig, Decoder
 // with its Cfg / Signal / Quantized fields, NewDecoder, Log, RegisterProtocol,
-// Allocate, Decode, Demodulator, MagLUT, NewMagLUT, NextPowerOf2 -- and the
+// Allocate, Decode, Filter, Search, Slice, Demodulator, MagLUT, NewMagLUT,
+// NextPowerOf2 -- and the
 // arithmetic of Decode (decode.go:163-172 and :255-375: history slide, magnitude
 // LUT, cumulative-sum matched filter, quantize, preamble Search, Slice) runs in
 // libamrdemod.so on the GPU, bit for bit (include/amrdemod.h).
@@ -28,6 +29,8 @@ import "C"
 import (
 	"log"
 	"math"
+	"os"
+	"strconv"
 	"strings"
 	"sync"
 	"unsafe"
@@ -64,8 +67,17 @@ type Decoder struct {
 	Quantized []byte
 
 	// KeepQuantized makes Decode copy the batch's bit decisions back into
-	// Quantized[PacketLength:] after every call (tests, tools); off by default.
+	// Quantized[PacketLength:] after every call (tests, tools, and the exported
+	// Search / Slice helpers below, which read Quantized); off by default.
 	KeepQuantized bool
+	// KeepSignal makes Decode refill Signal on the host even when no registered
+	// parser needs it (the exported Filter helper reads a caller's signal anyway).
+	KeepSignal bool
+
+	// Device is the HIP device ordinal Allocate opens.  -1 (NewDecoder's default)
+	// takes it from the environment: AMR_DEVICE, else LOCAL_RANK (one process per
+	// GPU, the deployment amr_comm_* is made for), else 0.
+	Device int
 
 	st *amdState // shared by the copies Decode's value receiver makes
 }
@@ -80,13 +92,25 @@ type amdState struct {
 	needSignal bool
 	lut        MagLUT
 	calls      uint64 // Decode calls (blocks) made so far = call index of the next block
+	csum       []float32 // scratch of the exported Filter helper
+	pkt        []byte    // scratch of the exported Slice helper (never cleared, like the reference's d.pkt)
 }
 
 func NewDecoder() Decoder {
 	return Decoder{
-		wg: new(sync.WaitGroup),
-		st: &amdState{preambles: make(map[string][]Parser), pid: make(map[string]int)},
+		wg:     new(sync.WaitGroup),
+		Device: -1,
+		st:     &amdState{preambles: make(map[string][]Parser), pid: make(map[string]int)},
 	}
+}
+
+func deviceFromEnv() int {
+	for _, name := range []string{"AMR_DEVICE", "LOCAL_RANK"} {
+		if v, err := strconv.Atoi(os.Getenv(name)); err == nil && v >= 0 {
+			return v
+		}
+	}
+	return 0
 }
 
 func (d Decoder) Log() {
@@ -105,13 +129,6 @@ func (d Decoder) Log() {
 		C.amr_describe(d.st.h, (*C.char)(unsafe.Pointer(&buf[0])), C.size_t(len(buf)))
 		log.Println("Device:", C.GoString((*C.char)(unsafe.Pointer(&buf[0]))))
 	}
-}
-
-func max(a, b int) int {
-	if a > b {
-		return a
-	}
-	return b
 }
 
 // RegisterProtocol: decode.go:100-128.  The field-wise maxima are kept here for
@@ -160,7 +177,11 @@ func (d *Decoder) Allocate() {
 			packet_symbols:   C.int32_t(c.PacketSymbols),
 		}
 	}
-	if st := C.amr_create(&protos[0], C.int32_t(len(protos)), 0, &s.h); st != C.AMR_OK {
+	dev := d.Device
+	if dev < 0 {
+		dev = deviceFromEnv()
+	}
+	if st := C.amr_create(&protos[0], C.int32_t(len(protos)), C.int32_t(dev), &s.h); st != C.AMR_OK {
 		fatal("amr_create", st)
 	}
 	var g C.amr_geometry
@@ -177,6 +198,8 @@ func (d *Decoder) Allocate() {
 	d.Signal = make([]float32, d.Cfg.BlockSize+d.Cfg.SymbolLength)
 	d.Quantized = make([]byte, d.Cfg.BufferLength)
 	s.lut = NewMagLUT()
+	s.csum = make([]float32, len(d.Signal)+1)
+	s.pkt = make([]byte, (d.Cfg.PacketSymbols+7)>>3)
 }
 
 // Decode accepts a sample block (or several) and returns a channel of messages,
@@ -206,7 +229,7 @@ func (d Decoder) Decode(input []byte) chan Message {
 		idx = unsafe.Slice((*uint32)(unsafe.Pointer(res.hit_idx)), n)
 		pkt = unsafe.Slice((*byte)(unsafe.Pointer(res.pkt)), n*pb)
 	}
-	first := s.calls
+	first := uint64(res.first_block) // = s.calls: amr_decode_batch never defers
 	s.calls += uint64(nBlocks)
 
 	// The result arrays belong to the handle until the next amr_* call: turn them
@@ -236,10 +259,8 @@ func (d Decoder) Decode(input []byte) chan Message {
 	msgCh := make(chan Message)
 	go func() {
 		for k := 0; k < nBlocks; k++ {
-			if s.needSignal || d.KeepQuantized {
-				copy(d.Signal, d.Signal[bs:]) // decode.go:165
-			}
-			if s.needSignal { // MagLUT.Execute on the host, same table: bit-identical to decode.go:169
+			if s.needSignal || d.KeepSignal { // MagLUT.Execute on the host, same table: bit-identical to decode.go:165,169
+				copy(d.Signal, d.Signal[bs:])
 				s.lut.Execute(input[k*bs2:(k+1)*bs2], d.Signal[d.Cfg.SymbolLength:])
 			}
 			if d.KeepQuantized {
@@ -271,6 +292,69 @@ func (d *Decoder) Close() {
 		C.amr_destroy(d.st.h)
 		d.st.h = nil
 	}
+}
+
+// Filter, Search and Slice are exported by the reference (decode.go:229, 255, 353) although only Decode calls them.
+// They stay available as HOST-side diagnostics with the reference's meaning, for third-party callers that compile
+// against them; the hot path does not go through them (it runs in the library).  Search and Slice read d.Quantized,
+// i.e. they need KeepQuantized; Filter works on the slices it is given.
+
+// Filter: running float32 sum restarted at zero, then the sign of (lower chip) - (upper chip) per output sample.
+func (d Decoder) Filter(input []float32, output []byte) {
+	c := d.st.csum
+	if len(c) < len(input)+1 {
+		c = make([]float32, len(input)+1)
+	}
+	c[0] = 0
+	var acc float32
+	for i := range input {
+		acc += input[i]
+		c[i+1] = acc
+	}
+	cl, sl := d.Cfg.ChipLength, d.Cfg.SymbolLength
+	for i := range output {
+		mid := c[i+cl]
+		f := (mid - c[i]) - (c[i+sl] - mid)
+		output[i] = 1 - byte(math.Float32bits(f)>>31)
+	}
+}
+
+// Search: every index in [0, BlockSize) at which all preamble bits match Quantized at a stride of SymbolLength,
+// ascending.  For every legal -symbollength this is exactly the set the reference's byte-prefiltered two-pass search
+// returns (SURVEY.md 8a; tests/test_oracle_golden.py compares the two forms).
+func (d *Decoder) Search(preamble []byte) []int {
+	var hits []int
+	sl := d.Cfg.SymbolLength
+	for idx := 0; idx < d.Cfg.BlockSize; idx++ {
+		ok := true
+		for p, bit := range preamble {
+			if d.Quantized[idx+p*sl] != bit {
+				ok = false
+				break
+			}
+		}
+		if ok {
+			hits = append(hits, idx)
+		}
+	}
+	return hits
+}
+
+// Slice: for every index, PacketSymbols decisions at a stride of SymbolLength shifted MSB-first into bytes.
+func (d Decoder) Slice(indices []int) (pkts []Data) {
+	pkt := d.st.pkt
+	for _, q := range indices {
+		if q > d.Cfg.BlockSize {
+			continue
+		}
+		for p := 0; p < d.Cfg.PacketSymbols; p++ {
+			pkt[p>>3] = pkt[p>>3]<<1 | d.Quantized[q+p*d.Cfg.SymbolLength]
+		}
+		data := NewData(pkt)
+		data.Idx = q
+		pkts = append(pkts, data)
+	}
+	return
 }
 
 // A Demodulator knows how to demodulate an array of uint8 IQ samples into an

@@ -96,6 +96,12 @@ typedef struct amr_result {
     const uint8_t *r900_digits;       /* [(off[r900_preamble+1]-off[r900_preamble]) * 42] */
     /* hits the search found; n_hits is smaller only when amr_set_validation dropped some on the device */
     uint64_t n_hits_searched;
+    /*
+     * The Decode calls this result covers: [first_block, first_block + n_blocks), call indices as in hit_block.
+     * Equal to the batch that was submitted unless amr_set_deferral is on (see there).
+     */
+    uint64_t first_block;
+    uint64_t n_blocks;
 } amr_result;
 
 /* Timing of the last batch, measured with HIP events on the handle's stream. */
@@ -199,6 +205,21 @@ amr_status amr_submit_device(amr_handle *h, const void *d_iq, size_t n_blocks);
 amr_status amr_collect(amr_handle *h, amr_result *res);
 
 /*
+ * Wave quantisation inside the library (main.go:166,235: the caller chooses the block count, not the library).
+ * The demodulation kernel works in wave-tiles of 64 blocks; a batch that does not end on one would end in a lone
+ * wavefront that takes as long as a whole chip-filling launch (100 000 blocks of SCM: 0.405 ms per step against 0.20
+ * for 98 304).  With deferral ON, amr_submit_device / amr_submit_host process a batch up to its last whole wave-tile
+ * and carry the (at most 63) blocks behind it into the next submit's launch; the library keeps its own copy of those
+ * blocks, so the caller's buffer is still free after the collect.  Nothing is lost or reordered: every hit carries the
+ * index of its Decode call, and amr_result.first_block / n_blocks say which calls a result covers -- the tail of
+ * batch i simply arrives with batch i+1.  amr_flush processes what is still deferred at the end of the stream (call it
+ * with nothing in flight) and returns its hits.  amr_decode_batch[_device] never defer: they process every block
+ * handed over so far, deferred ones included.  Off by default; not available with amr_r900_enable.
+ */
+amr_status amr_set_deferral(amr_handle *h, int32_t on);
+amr_status amr_flush(amr_handle *h, amr_result *res);
+
+/*
  * The same pipeline for input in HOST memory (file replay, many-SDR aggregation; the caller the reference
  * has is Receiver.Run, main.go:156-235): the batch is copied to a per-slot device buffer on a transfer
  * stream, the kernels wait for that copy only, so the host-to-device transfer of batch i+1 overlaps the
@@ -285,10 +306,12 @@ amr_status amr_synth_plant(int32_t device_id, void *d_iq, uint64_t n_samples, ui
  * A cgo host: rank 0 calls amr_comm_unique_id and hands the 128 bytes to the other processes (any transport), every
  * rank calls amr_comm_init, then after each amr_collect one amr_gather_hits. */
 #define AMR_COMM_ID_BYTES 128
+#define AMR_GATHER_HEADER_BYTES 128
 typedef struct amr_gathered {
     uint64_t n_true;                  /* hits the source rank had */
     uint64_t n_hits;                  /* records received = min(n_true, capacity); n_true > n_hits: raise the capacity */
     uint32_t n_preambles;
+    uint64_t seq;                     /* sequence number of the gather the records belong to (0, 1, 2 ... per communicator) */
     const uint64_t *preamble_offset;  /* [n_preambles+1] into the source rank's (untruncated) hit arrays */
     const uint64_t *hit_block;        /* [n_hits] global call indices */
     const uint32_t *hit_idx;          /* [n_hits] */
@@ -296,13 +319,25 @@ typedef struct amr_gathered {
 amr_status amr_comm_unique_id(void *id128);   /* ncclGetUniqueId */
 amr_status amr_comm_init(amr_handle *h, const void *id128, int32_t rank, int32_t world, int32_t root, uint64_t cap_hits);
 amr_status amr_comm_destroy(amr_handle *h);
-/* Enqueue the gather of the batch amr_collect returned last (with amr_set_validation: of its surviving hits).
- * Collective: every rank calls it once per batch, in the same order.  Returns at once. */
-amr_status amr_gather_hits(amr_handle *h);
+/* ranks the RCCL communicator spans (ncclCommCount): lets a bench line prove the gather ran over N ranks */
+amr_status amr_comm_ranks(const amr_handle *h, int32_t *n_ranks);
+/* Enqueue the gather of the batch amr_collect returned last (with amr_set_validation: of its surviving hits -- the
+ * natural companion: 70x fewer records).  Collective: every rank calls it once per batch, in the same order.  Returns
+ * at once; *seq (may be NULL) receives the gather's sequence number.  The library orders the kernel that reads the
+ * batch's result against the later reuse of its slot by itself. */
+amr_status amr_gather_hits(amr_handle *h, uint64_t *seq);
 amr_status amr_gather_wait(amr_handle *h);    /* block until every gather enqueued so far has completed */
-/* Root only: the records rank src_rank contributed to the last gather, copied to host memory owned by the handle
- * (valid until the next amr_gather_fetch). */
-amr_status amr_gather_fetch(amr_handle *h, int32_t src_rank, amr_gathered *out);
+/* Root only: the records rank src_rank contributed to gather `seq`.  Waits for the arrival of that gather's records in
+ * the handle's pinned host mirror (an event; no stream synchronisation, no copy) and returns pointers into it, valid
+ * until gather seq + 2 is posted. */
+amr_status amr_gather_fetch(amr_handle *h, uint64_t seq, int32_t src_rank, amr_gathered *out);
+/* The slot every rank sends, as ONE description shared by the device pack kernel, CPU hosts and the tests:
+ * [header AMR_GATHER_HEADER_BYTES | n_hits call indices u64 | n_hits idx u32], amr_gather_slot_bytes(cap) bytes.
+ * amr_gather_pack_host builds it from a host-side result (a transport other than RCCL, e.g. the gloo tests),
+ * amr_gather_unpack reads one (pointers into `slot`).  Neither needs a device. */
+size_t amr_gather_slot_bytes(uint64_t cap_hits);
+amr_status amr_gather_pack_host(const amr_result *res, uint64_t cap_hits, uint64_t seq, void *slot, size_t slot_bytes);
+amr_status amr_gather_unpack(const void *slot, size_t slot_bytes, amr_gathered *out);
 
 #ifdef __cplusplus
 }

@@ -15,11 +15,12 @@ AMR_OK, AMR_EINVAL, AMR_ENOMEM, AMR_EHIP, AMR_ENODEV, AMR_EOVERFLOW = 0, -1, -2,
 # every symbol include/amrdemod.h declares (checked by tests/test_abi.py)
 SYMBOLS = [
     "amr_create", "amr_plan", "amr_destroy", "amr_reset", "amr_get_geometry", "amr_preamble_id", "amr_get_mag_lut", "amr_r900_enable", "amr_set_validation",
-    "amr_set_stream", "amr_set_block_base", "amr_decode_batch", "amr_decode_batch_device", "amr_submit_device", "amr_collect", "amr_submit_host", "amr_host_alloc", "amr_host_free", "amr_result_device", "amr_prime",
+    "amr_set_stream", "amr_set_block_base", "amr_decode_batch", "amr_decode_batch_device", "amr_submit_device", "amr_collect", "amr_set_deferral", "amr_flush", "amr_submit_host", "amr_host_alloc", "amr_host_free", "amr_result_device", "amr_prime",
     "amr_halo_bytes", "amr_prime_blocks", "amr_copy_quantized", "amr_set_timing", "amr_get_timing", "amr_strerror",
     "amr_last_error", "amr_describe", "amr_dev_alloc", "amr_dev_free", "amr_dev_upload", "amr_dev_download",
     "amr_dev_sync", "amr_synth_noise", "amr_synth_plant",
-    "amr_comm_unique_id", "amr_comm_init", "amr_comm_destroy", "amr_gather_hits", "amr_gather_wait", "amr_gather_fetch",
+    "amr_comm_unique_id", "amr_comm_init", "amr_comm_destroy", "amr_comm_ranks", "amr_gather_hits", "amr_gather_wait", "amr_gather_fetch",
+    "amr_gather_slot_bytes", "amr_gather_pack_host", "amr_gather_unpack",
 ]
 
 
@@ -46,7 +47,7 @@ class AmrResult(C.Structure):
                 ("preamble_offset", C.POINTER(C.c_uint64)), ("hit_block", C.POINTER(C.c_uint64)),
                 ("hit_idx", C.POINTER(C.c_uint32)), ("pkt", C.POINTER(C.c_uint8)),
                 ("r900_preamble", C.c_int32), ("r900_digits", C.POINTER(C.c_uint8)),
-                ("n_hits_searched", C.c_uint64)]
+                ("n_hits_searched", C.c_uint64), ("first_block", C.c_uint64), ("n_blocks", C.c_uint64)]
 
 
 class AmrCrcCheck(C.Structure):
@@ -59,7 +60,7 @@ class AmrValidator(C.Structure):
 
 
 class AmrGathered(C.Structure):
-    _fields_ = [("n_true", C.c_uint64), ("n_hits", C.c_uint64), ("n_preambles", C.c_uint32),
+    _fields_ = [("n_true", C.c_uint64), ("n_hits", C.c_uint64), ("n_preambles", C.c_uint32), ("seq", C.c_uint64),
                 ("preamble_offset", C.POINTER(C.c_uint64)), ("hit_block", C.POINTER(C.c_uint64)),
                 ("hit_idx", C.POINTER(C.c_uint32))]
 
@@ -70,7 +71,7 @@ class AmrTiming(C.Structure):
 
 def build(force: bool = False) -> str:
     """Compile libamrdemod.so in-tree with hipcc for gfx950 (cross-compiles without a GPU)."""
-    srcs = [os.path.join(CSRC, f) for f in ("amrdemod.hip", "k1_demod.h", "k1_tile.h", "k2_search.h", "k2_stream.h", "k4_r900.h",
+    srcs = [os.path.join(CSRC, f) for f in ("amrdemod.hip", "k1_demod.h", "k1_tile.h", "k2_search.h", "k2_stream.h", "k2_walk.h", "k4_r900.h",
                                             "k5_validate.h", "synth.h")]
     srcs.append(os.path.join(_HERE, "..", "include", "amrdemod.h"))
     stale = (not os.path.exists(SO_PATH)) or any(os.path.getmtime(s) > os.path.getmtime(SO_PATH) for s in srcs)
@@ -108,6 +109,8 @@ def lib() -> C.CDLL:
     L.amr_decode_batch_device.argtypes = [vp, vp, C.c_size_t, C.POINTER(AmrResult)]
     L.amr_submit_device.argtypes = [vp, vp, C.c_size_t]
     L.amr_collect.argtypes = [vp, C.POINTER(AmrResult)]
+    L.amr_set_deferral.argtypes = [vp, C.c_int32]
+    L.amr_flush.argtypes = [vp, C.POINTER(AmrResult)]
     L.amr_prime.argtypes = [vp, vp, vp, C.c_size_t, C.c_int]
     L.amr_halo_bytes.argtypes = [vp]
     L.amr_halo_bytes.restype = C.c_size_t
@@ -137,12 +140,18 @@ def lib() -> C.CDLL:
     L.amr_comm_unique_id.argtypes = [vp]
     L.amr_comm_init.argtypes = [vp, vp, C.c_int32, C.c_int32, C.c_int32, C.c_uint64]
     L.amr_comm_destroy.argtypes = [vp]
-    L.amr_gather_hits.argtypes = [vp]
+    L.amr_comm_ranks.argtypes = [vp, C.POINTER(C.c_int32)]
+    L.amr_gather_hits.argtypes = [vp, C.POINTER(C.c_uint64)]
     L.amr_gather_wait.argtypes = [vp]
-    L.amr_gather_fetch.argtypes = [vp, C.c_int32, C.POINTER(AmrGathered)]
+    L.amr_gather_fetch.argtypes = [vp, C.c_uint64, C.c_int32, C.POINTER(AmrGathered)]
+    L.amr_gather_slot_bytes.argtypes = [C.c_uint64]
+    L.amr_gather_slot_bytes.restype = C.c_size_t
+    L.amr_gather_pack_host.argtypes = [C.POINTER(AmrResult), C.c_uint64, C.c_uint64, vp, C.c_size_t]
+    L.amr_gather_unpack.argtypes = [vp, C.c_size_t, C.POINTER(AmrGathered)]
     for name in SYMBOLS:
         fn = getattr(L, name)
-        if name not in ("amr_preamble_id", "amr_halo_bytes", "amr_prime_blocks", "amr_strerror", "amr_last_error"):
+        if name not in ("amr_preamble_id", "amr_halo_bytes", "amr_prime_blocks", "amr_strerror", "amr_last_error",
+                        "amr_gather_slot_bytes"):
             fn.restype = C.c_int
     _lib = L
     return L

@@ -25,6 +25,7 @@
 #include "k1_tile.h"
 #include "k2_search.h"
 #include "k2_stream.h"
+#include "k2_walk.h"
 #include "k4_r900.h"
 #include "k5_validate.h"
 #include "synth.h"
@@ -106,7 +107,7 @@ struct Slot {
     bool tail_split = false;      // ... on the second stream
     bool folded = false;          // the state update ran inside the search kernel: no stream-A ticket for this batch
     hipEvent_t ev_k2 = nullptr, ev_t = nullptr;   // K2 stop, K3 start (timing level 2 with the tail on the second stream)
-    hipEvent_t ev_k1done = nullptr, ev_tail = nullptr;   // dependencies between the two streams (no timing)
+    hipEvent_t ev_pack = nullptr; bool pack_pending = false;   // multi-GPU gather: its pack kernel still reads d_out / d_val of this slot
     // the batch in flight
     bool pending = false, search = false;
     const uint8_t *d_iq = nullptr;
@@ -139,12 +140,9 @@ struct amr_handle {
     hipStream_t own_stream = nullptr, stream = nullptr, copy_stream = nullptr, h2d_stream = nullptr;
     // K3 / K4 / K5 of batch i run here, next to the search of batch i+1, once the caller pipelines (lazy_tail)
     hipStream_t tail_stream = nullptr;
+    // The host launches the tail when it sees the next batch's search start (a pinned flag; no event on the compute
+    // stream: stream dependencies were tried and cost ~10 us of bubbles per batch, cfg2 0.237 ms per step against 0.227).
     bool lazy_tail = false;
-    bool allow_lazy = true;      // AMR_TAIL_OVERLAP=0: everything on one stream, as before
-    // false (default): the host launches the tail when it sees the next batch's search start (a pinned flag; no event on
-    // the compute stream).  AMR_TAIL_MODE=event: stream dependencies instead -- robust against a slow host, but the two
-    // events per batch cost ~10 us of stream bubbles (cfg2: 0.237 ms per step against 0.227)
-    bool tail_events = false;
     uint64_t *d_tail_done = nullptr;   // device word: ticket of the last batch whose second-stream part has finished
     uint64_t *h_flags = nullptr;  // pinned: [0] ticket of the last batch whose search has started, [1] whose stream-A part is done
     bool timing_valid = false;
@@ -153,7 +151,11 @@ struct amr_handle {
     uint64_t next_ticket = 1;
 
     float *d_lut = nullptr;
-    uint8_t *d_carry = nullptr;
+    // head buffer: [the HBA stream bytes in front of the next launch's row 0 (the IQ halo of that block) | 64 rows:
+    // blocks deferred from the last batch, completed by the next submit with its first blocks]
+    uint8_t *d_head = nullptr;
+    bool defer_on = false;       // amr_set_deferral
+    uint32_t n_head = 0;         // deferred blocks waiting in the head buffer
     bool zero_halo = true;
     bool dense_search = false;   // test hook (AMR_DENSE_SEARCH): always use the fallback search kernel
     uint64_t init_hit_cap = 1 << 16;   // hits the result buffers hold at first (test hook AMR_HIT_CAP: exercise the growth)
@@ -172,7 +174,7 @@ struct amr_handle {
     size_t last_n_blocks = 0;
     std::vector<uint64_t> r_off;
     uint64_t last_total = 0;
-    // r900 second stage: the preamble id, and the PL samples of IQ that precede the next batch (two buffers, alternating)
+    // r900 second stage: the preamble id; the PL samples of IQ that precede the next batch live in d_iqhist below
     int r900_pid = -1;
     // per-hit validation on the device
     bool validate = false;
@@ -213,25 +215,16 @@ amr_status host_realloc(T *&p, size_t count)
 
 // Timing events ride on the kernel dispatches themselves (hipExtLaunchKernelGGL start/stop events): a separate
 // hipEventRecord costs a ~6 us bubble on the stream each, four of them per batch were 6 % of a 1 GiB step.
-// K1 comes in two generations: k1t_demod (k1_tile.h: register-resident staging tile, two DMA tiles in flight, static
-// super-body) for every chip length whose csum rings leave room for it, k1_demod (k1_demod.h) for the rest
-// (chip 80/88/96).  AMR_K1_IMPL=old forces the first generation everywhere (A/B measurements, tests).
-bool k1_use_tile()
-{
-    static const bool on = [] { const char *e = getenv("AMR_K1_IMPL"); return !(e && strcmp(e, "old") == 0); }();
-    return on;
-}
+// K1 comes in two generations: k1t_demod (k1_tile.h: register-resident staging tile, static super-body) for every chip
+// length whose csum rings leave room for it, k1_demod (k1_demod.h) for the rest (chip 80/88/96).
 
 template <int CL, bool TAIL>
 void launch_k1_cl(dim3 grid, hipStream_t st, const amr::K1Args &a, hipEvent_t start, hipEvent_t stop)
 {
-    if constexpr (amr::K1TGeom<CL>::supported) {
-        if (k1_use_tile()) {
-            hipExtLaunchKernelGGL((amr::k1t_demod<CL, TAIL, amr::K1TDefault>), grid, dim3(64), amr::K1TDefault::kLds, st, start, stop, 0, a);
-            return;
-        }
-    }
-    hipExtLaunchKernelGGL((amr::k1_demod<CL, TAIL>), grid, dim3(64), 0, st, start, stop, 0, a);
+    if constexpr (amr::K1TGeom<CL>::supported)
+        hipExtLaunchKernelGGL((amr::k1t_demod<CL, TAIL, amr::K1TDefault>), grid, dim3(64), amr::K1TDefault::kLds, st, start, stop, 0, a);
+    else
+        hipExtLaunchKernelGGL((amr::k1_demod<CL, TAIL>), grid, dim3(64), 0, st, start, stop, 0, a);
 }
 
 template <bool TAIL>
@@ -333,13 +326,6 @@ amr_status ensure_capacity(amr_handle *h, Slot &s, Slot &other, size_t n_blocks)
     return AMR_OK;
 }
 
-// AMR_K2_IMPL=old: the first-generation search everywhere
-bool k2_use_stream()
-{
-    static const bool on = [] { const char *e = getenv("AMR_K2_IMPL"); return !(e && strcmp(e, "old") == 0); }();
-    return on;
-}
-
 // The search of the batch held by slot s in two parts: K2 on stream `st`, then K3 (+ K4, K5) -- the "tail" -- on the
 // same stream at once (enqueue_search; also every re-run after a capacity overflow) or later on the second stream
 // (pipelined callers: collect() launches it when the next batch's K1 has finished, so that it runs next to that
@@ -361,14 +347,6 @@ amr_status enqueue_k2(amr_handle *h, Slot &s, hipStream_t st, bool rerun, bool d
     k2.n_lo = -(int64_t)h->geom.packet_length;
     k2.n_hi = (int64_t)s.n_blocks * bs - (int64_t)h->geom.packet_length;
     k2.g = h->sg;
-    k2.dbg = nullptr;
-    static unsigned long long *k2dbg = nullptr;
-    static int k2dbg_calls = 0;
-    if (getenv("AMR_K2_DBG")) {
-        if (!k2dbg) HIP_TRY(hipMalloc((void **)&k2dbg, (size_t)s.n_tiles * 128 + 128));
-        k2.dbg = k2dbg;
-        HIP_TRY(hipMemsetAsync(k2dbg, 0, (size_t)s.n_tiles * 128, st));
-    }
     const bool t2 = s.timed >= 2;
     hipEvent_t k2stop = (t2 && split) ? s.ev_k2 : nullptr;
     k2.started = rerun ? nullptr : &h->h_flags[0];
@@ -382,23 +360,56 @@ amr_status enqueue_k2(amr_handle *h, Slot &s, hipStream_t st, bool rerun, bool d
     // applied to every position before the candidate lists take over: 10 for one preamble (2^-10 of the positions
     // survive: ~20 list entries per wave in noise), 12 when several preambles share the sweep and the lists
     const int k2d = n_pre == 1 ? AMR_K2S_D1 : AMR_K2S_DN;
-    bool stream_ok = !h->dense_search && !dense && k2_use_stream() && n_pre <= 4 && h->sg.wpb >= 64 && h->sg.wpb <= 256;
+    bool stream_ok = !h->dense_search && !dense && n_pre <= 4 && h->sg.wpb >= 64 && h->sg.wpb <= 256;
     for (uint32_t q = 0; q < n_pre; ++q) stream_ok = stream_ok && (int)h->sg.pre_len[q] >= k2d;
-    if (stream_ok) {
+    // the batch's state update as workgroup number n_tiles of the search launch, the copies of deferred blocks as the
+    // workgroups behind it (see K2Args::do_hist)
+    uint32_t extra = 0;
+    if (fold) {
+        k2.do_hist = 1;
+        k2.hist = *fold;
+        k2.hist.adone_flag = nullptr;     // no ticket from inside the search (see K2Args::do_hist)
+        k2.hist.done_flag = nullptr;
+        extra = 1u + fold->defer_wgs;
+        if (folded) *folded = true;
+    }
+    const uint32_t wgs = s.n_tiles + extra;
+    // third-generation search (k2_walk.h): one wave walks a whole tile out of global memory; every rtlamr parser set
+    // (at most four preambles of at least 16 symbols) at every BlockSize from 512 to 8192
+    bool walk_ok = !h->dense_search && !dense && n_pre <= 4 && h->sg.wpb >= 16 && h->sg.wpb <= 256;
+    for (uint32_t q = 0; q < n_pre; ++q) walk_ok = walk_ok && (int)h->sg.pre_len[q] >= amr::kK2WTaps;
+    {   // TEMPORARY (A/B on the GPU box): AMR_K2_IMPL=stream keeps the second generation
+        static const bool use_stream = [] { const char *e = getenv("AMR_K2_IMPL"); return e && strcmp(e, "stream") == 0; }();
+        if (use_stream) walk_ok = false;
+    }
+    if (walk_ok) {
+        const size_t lds2 = amr::k2_walk_lds_bytes(h->hist_rows * h->sg.wpb);
+        const uint32_t n_wg = (s.n_tiles + amr::kK2WWaves - 1) / amr::kK2WWaves + extra;
+        const uint32_t grid = 8u * ((n_wg + 7u) / 8u);   // XCD-contiguous tile order: 8 equal runs
+#define AMR_K2W_LAUNCH(S, N)                                                                                           \
+    do {                                                                                                             \
+        HIP_TRY(hipFuncSetAttribute((const void *)amr::k2_search_walk<S, N>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2)); \
+        hipExtLaunchKernelGGL((amr::k2_search_walk<S, N>), dim3(grid), dim3(64 * amr::kK2WWaves), lds2, st, t2 ? s.ev_s : nullptr, k2stop, 0, k2); \
+    } while (0)
+#define AMR_K2W_CASE(S)                                                                                               \
+    case S:                                                                                                          \
+        if (n_pre == 1) AMR_K2W_LAUNCH(S, 1); else if (n_pre == 2) AMR_K2W_LAUNCH(S, 2);                              \
+        else if (n_pre == 3) AMR_K2W_LAUNCH(S, 3); else AMR_K2W_LAUNCH(S, 4);                                         \
+        break;
+        switch (h->sg.symbol_length) {
+            AMR_K2W_CASE(16) AMR_K2W_CASE(64) AMR_K2W_CASE(80) AMR_K2W_CASE(96) AMR_K2W_CASE(112) AMR_K2W_CASE(128)
+            AMR_K2W_CASE(144) AMR_K2W_CASE(160) AMR_K2W_CASE(176) AMR_K2W_CASE(192)
+        default: walk_ok = false; break;
+        }
+#undef AMR_K2W_CASE
+#undef AMR_K2W_LAUNCH
+    }
+    if (walk_ok) stream_ok = false;
+    if (walk_ok) {
+    } else if (stream_ok) {
         const int nwv = amr::k2_stream_waves(h->sg.wpb);
         const size_t lds2 = amr::k2_stream_lds_bytes(h->sg.wpb, n_pre);
-        static const bool xcd = [] { const char *e = getenv("AMR_K2_XCD"); return !(e && e[0] == '0'); }();
-        k2.xcd = xcd ? 1u : 0u;
-        // the batch's state update as workgroup number n_tiles of this launch (see K2Args::do_hist)
-        if (fold) {
-            k2.do_hist = 1;
-            k2.hist = *fold;
-            k2.hist.adone_flag = nullptr;     // no ticket from inside the search (see K2Args::do_hist)
-            k2.hist.done_flag = nullptr;
-            if (folded) *folded = true;
-        }
-        const uint32_t wgs = s.n_tiles + (fold ? 1u : 0u);
-        const uint32_t grid = xcd ? 8u * ((wgs + 7u) / 8u) : wgs;
+        const uint32_t grid = 8u * ((wgs + 7u) / 8u);   // XCD-contiguous tile order: 8 equal runs
         bool launched = true;
 #define AMR_K2S_LAUNCH(S, DD, W)                                                                                       \
     do {                                                                                                             \
@@ -422,11 +433,10 @@ amr_status enqueue_k2(amr_handle *h, Slot &s, hipStream_t st, bool rerun, bool d
 #undef AMR_K2S_W
 #undef AMR_K2S_LAUNCH
         stream_ok = launched;
-        if (!launched && folded) *folded = false;
     }
     // the list-based kernel splits a row's words over 4 or 8 waves, 4 or 8 words per step: rows of fewer than 16 words
     // (BlockSize 256: scm+ alone at chip length 8) go through the dense kernel
-    if (stream_ok) {
+    if (stream_ok || walk_ok) {
     } else if (!h->dense_search && !dense && n_pre <= 4 && h->sg.wpb >= 16) {
         const int nwv = h->sg.wpb >= 64 ? 8 : 4;   // a wave needs at least JW words of a row: 8 x 8 or 4 x 4
         const size_t lds2 = amr::k2_fast_lds_bytes(h->sg.wpb, (int)n_pre, nwv);
@@ -434,7 +444,7 @@ amr_status enqueue_k2(amr_handle *h, Slot &s, hipStream_t st, bool rerun, bool d
     do {                                                                                                             \
         HIP_TRY(hipFuncSetAttribute((const void *)amr::k2_search_fast<N, W, J>, hipFuncAttributeMaxDynamicSharedMemorySize, \
                                     (int)lds2));                                                                     \
-        hipExtLaunchKernelGGL((amr::k2_search_fast<N, W, J>), dim3(s.n_tiles), dim3(64 * W), lds2, st, t2 ? s.ev_s : nullptr, \
+        hipExtLaunchKernelGGL((amr::k2_search_fast<N, W, J>), dim3(wgs), dim3(64 * W), lds2, st, t2 ? s.ev_s : nullptr, \
                               k2stop, 0, k2);                                                                       \
     } while (0)
 #define AMR_K2_CASE(N)                                                                                              \
@@ -449,46 +459,7 @@ amr_status enqueue_k2(amr_handle *h, Slot &s, hipStream_t st, bool rerun, bool d
         const size_t lds2 = ((size_t)h->sg.wpb * 65 + 8) * 4;
         HIP_TRY(hipFuncSetAttribute((const void *)amr::k2_search_dense, hipFuncAttributeMaxDynamicSharedMemorySize,
                                     (int)lds2));
-        hipExtLaunchKernelGGL(amr::k2_search_dense, dim3(s.n_tiles), dim3(256), lds2, st, t2 ? s.ev_s : nullptr, k2stop, 0, k2);
-    }
-    if (k2.dbg && (++k2dbg_calls == 6 || k2dbg_calls == 400)) {   // phase timestamps of the 6th search: mean duration of each phase over the workgroups
-        HIP_TRY(hipStreamSynchronize(st));
-        std::vector<unsigned long long> d((size_t)s.n_tiles * 16);
-        HIP_TRY(hipMemcpy(d.data(), k2dbg, d.size() * 8, hipMemcpyDeviceToHost));
-        double ph[6] = {0, 0, 0, 0, 0, 0}, tot = 0, cand = 0, keep = 0; unsigned long long r0 = ~0ull, r1 = 0; size_t n = 0;
-        std::vector<double> starts, durs;
-        for (size_t T = 0; T < s.n_tiles; ++T) {
-            const unsigned long long *x = &d[T * 16];
-            if (!x[0] || !x[6]) continue;
-            for (int i = 0; i < 6; ++i) ph[i] += (double)(x[i + 1] - x[i]);
-            tot += (double)(x[6] - x[0]); cand += (double)(x[7] >> 32); keep += (double)(x[7] & 0xffffffffu);
-            r0 = std::min(r0, x[8]); r1 = std::max(r1, x[9]); ++n;
-        }
-        for (size_t T = 0; T < s.n_tiles; ++T) {
-            const unsigned long long *x = &d[T * 16];
-            if (!x[0] || !x[6]) continue;
-            starts.push_back((double)(x[8] - r0) * 0.01); durs.push_back((double)(x[9] - x[8]) * 0.01);
-        }
-        for (int grp = 0; grp < 2; ++grp) {     // workgroups of the first wave of dispatches vs the ones that follow
-            double g[6] = {0, 0, 0, 0, 0, 0}, gd = 0; size_t gn = 0;
-            for (size_t T = 0; T < s.n_tiles; ++T) {
-                const unsigned long long *x = &d[T * 16];
-                if (!x[0] || !x[6]) continue;
-                const bool late = (double)(x[8] - r0) * 0.01 > 3.0;
-                if ((int)late != grp) continue;
-                for (int i = 0; i < 6; ++i) g[i] += (double)(x[i + 1] - x[i]);
-                gd += (double)(x[9] - x[8]) * 0.01; ++gn;
-            }
-            if (gn) fprintf(stderr, "[amr] k2 %s workgroups (%zu): prologue %.0f sweep %.0f stage2 %.0f barrier %.0f scan %.0f emit %.0f ticks, duration %.2f us\n",
-                            grp ? "later" : "first-round", gn, g[0] / gn, g[1] / gn, g[2] / gn, g[3] / gn, g[4] / gn, g[5] / gn, gd / gn);
-        }
-        std::sort(starts.begin(), starts.end()); std::sort(durs.begin(), durs.end());
-        auto pc = [](const std::vector<double> &v, double f) { return v.empty() ? 0.0 : v[(size_t)(f * (v.size() - 1))]; };
-        fprintf(stderr, "[amr] k2 phases (mean ticks over %zu WGs): prologue %.0f sweep %.0f stage2 %.0f barrier %.0f scan %.0f emit %.0f | total %.0f, cand %.1f keep %.1f per WG\n",
-                n, ph[0] / n, ph[1] / n, ph[2] / n, ph[3] / n, ph[4] / n, ph[5] / n, tot / n, cand / n, keep / n);
-        fprintf(stderr, "[amr] k2 timeline (us, 100 MHz clock): first start -> last end %.2f; WG start p25 %.2f p50 %.2f p75 %.2f p90 %.2f p99 %.2f max %.2f; WG duration p10 %.2f p50 %.2f p90 %.2f max %.2f\n",
-                (double)(r1 - r0) * 0.01, pc(starts, .25), pc(starts, .5), pc(starts, .75), pc(starts, .9), pc(starts, .99), pc(starts, 1.0),
-                pc(durs, .1), pc(durs, .5), pc(durs, .9), pc(durs, 1.0));
+        hipExtLaunchKernelGGL(amr::k2_search_dense, dim3(wgs), dim3(256), lds2, st, t2 ? s.ev_s : nullptr, k2stop, 0, k2);
     }
     AMR_DBG(st, "k2_search");
     return AMR_OK;
@@ -499,16 +470,17 @@ amr_status enqueue_tail(amr_handle *h, Slot &s, hipStream_t st, bool split)
     const uint32_t n_pre = h->sg.n_pre;
     const uint32_t bs = (uint32_t)h->geom.block_size;
     const bool t2 = s.timed >= 2;
+    if (s.pack_pending) {   // a multi-GPU gather's pack kernel may still be reading the result this tail overwrites
+        HIP_TRY(hipStreamWaitEvent(st, s.ev_pack, 0));
+        s.pack_pending = false;
+    }
     amr::K3Args k3{};
     k3.qt = s.d_qt; k3.counts = s.d_counts; k3.gcnt = s.d_gcnt; k3.staging = s.d_staging;
     k3.out = s.d_out; k3.offs_pre = s.d_offs_pre; k3.h_offs_pre = s.h_off; k3.h_overflow = s.h_ovf;
     k3.out_cap = s.out_cap; k3.overflow = s.d_overflow;
     k3.block_base = s.calls_base; k3.n_tiles = s.n_tiles; k3.cap = s.stage_cap; k3.g = h->sg;
-    // AMR_K3_IMPL=old: the per-hit slicing of round 1 (A/B measurements, tests)
-    static const bool k3_old = [] { const char *e = getenv("AMR_K3_IMPL"); return e && strcmp(e, "old") == 0; }();
     hipEvent_t k3e0 = (t2 && split) ? s.ev_t : nullptr, k3e1 = t2 ? s.ev2 : nullptr;
-    if (k3_old) hipExtLaunchKernelGGL(amr::k3_slice, dim3(s.n_tiles, n_pre), dim3(256), 0, st, k3e0, k3e1, 0, k3);
-    else hipExtLaunchKernelGGL(amr::k3_slice_words, dim3(s.n_tiles, n_pre), dim3(256), 0, st, k3e0, k3e1, 0, k3);
+    hipExtLaunchKernelGGL(amr::k3_slice_words, dim3(s.n_tiles, n_pre), dim3(256), 0, st, k3e0, k3e1, 0, k3);
     HIP_TRY(hipGetLastError());
     AMR_DBG(st, "k3_slice");
     if (h->r900_pid >= 0) {
@@ -547,95 +519,112 @@ amr_status enqueue_search(amr_handle *h, Slot &s, bool rerun = false, bool dense
 
 amr_status launch_ready_tails(amr_handle *h, bool last_too = false);
 
+__global__ void k_copy16(const uint4 *src, uint4 *dst, uint32_t n16)
+{
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n16; i += gridDim.x * blockDim.x) dst[i] = src[i];
+}
+
 // Enqueue one batch on the compute stream: K1, (search), history + carry update.  Returns at once.
-amr_status submit(amr_handle *h, const uint8_t *d_iq, size_t n_blocks, bool search)
+//
+// Wave quantisation (amr_set_deferral): K1 works in wave-tiles of 64 blocks, and a batch that does not end on one would
+// end in a lone wave that takes as long as a whole chip-filling launch (every wave walks its BlockSize + SymbolLength
+// samples in order, whatever the others do).  With `may_defer` the launch stops at the last whole wave-tile; the up to
+// 63 blocks behind it are copied into the head buffer (by workgroups of the search launch) and become the first rows of
+// the NEXT launch's wave-tile 0, completed with that batch's first blocks.  The stream position of a launch never
+// depended on batch boundaries (the carry / history mechanism below), so nothing else changes: hits keep their call
+// index, they just arrive with the following batch's result (or with amr_flush).
+amr_status submit(amr_handle *h, const uint8_t *d_iq, size_t n_blocks, bool search, bool may_defer = false)
 {
     HIP_TRY(hipSetDevice(h->device));
-    if (n_blocks == 0 || n_blocks > 0x7fffffffull) return fail(AMR_EINVAL, "n_blocks out of range");
+    const uint32_t n_head = h->n_head;                  // blocks deferred by the previous batch, waiting in the head buffer
+    const size_t total = n_head + n_blocks;
+    if (total == 0 || total > 0x7fffffffull) return fail(AMR_EINVAL, "n_blocks out of range");
     if (h->n_pending >= kMaxPending) return fail(AMR_EINVAL, "three batches already in flight: call amr_collect first");
-    if (!h->tail_events) AMR_TRY(launch_ready_tails(h));
+    AMR_TRY(launch_ready_tails(h));
+    const bool defer = may_defer && h->defer_on && search && h->r900_pid < 0 && total >= 64;
+    const size_t rows = defer ? (total & ~(size_t)63) : total;   // rows (blocks) this launch processes
+    const uint32_t new_head = (uint32_t)(total - rows);
     Slot &s = h->slot[h->next_slot];
     Slot &other = h->slot[(h->next_slot + 1) % kSlots];   // the slot the next batch will use: never one in flight
     Slot &prev = h->slot[(h->next_slot + kSlots - 1) % kSlots];   // the batch submitted before this one (if still in flight)
-    AMR_TRY(ensure_capacity(h, s, other, n_blocks));
+    AMR_TRY(ensure_capacity(h, s, other, rows));
     hipStream_t st = h->stream;
     const uint32_t bs = (uint32_t)h->geom.block_size;
-    const uint32_t full = (uint32_t)(n_blocks / 64), rem = (uint32_t)(n_blocks % 64);
+    const size_t bs2 = (size_t)h->geom.block_size2;
+    const uint32_t full = (uint32_t)(rows / 64), rem = (uint32_t)(rows % 64);
 
     s.ticket = h->next_ticket++;
     s.d_iq = d_iq;
-    s.n_blocks = n_blocks;
-    s.n_tiles = (uint32_t)((n_blocks + 63) / 64) + 1;
+    s.n_blocks = rows;
+    s.n_tiles = (uint32_t)((rows + 63) / 64) + 1;
     s.search = search;
     s.calls_base = h->calls_done + h->block_base;
     s.iqhist_valid = h->iqhist_valid;
     s.iqhist_buf = h->iqhist_cur;
 
+    // wave-tile 0 of a launch that starts with deferred blocks: completed in the head buffer with this batch's first blocks
+    uint8_t *head_rows = h->d_head + h->halo_bytes;
+    if (n_head && n_blocks) {
+        const size_t c = std::min<size_t>(n_blocks, 64 - n_head);
+        const uint32_t n16 = (uint32_t)(c * bs2 / 16);
+        hipLaunchKernelGGL(k_copy16, dim3(std::min<uint32_t>(256, (n16 + 255) / 256)), dim3(256), 0, st,
+                           reinterpret_cast<const uint4 *>(d_iq), reinterpret_cast<uint4 *>(head_rows + n_head * bs2), n16);
+        HIP_TRY(hipGetLastError());
+    }
+
     amr::K1Args k1{};
-    k1.iq = d_iq;
-    k1.carry = h->d_carry;
+    k1.iq = d_iq - n_head * bs2;      // row r >= 64 of the launch is block r - n_head of the caller's batch
+    k1.carry = h->d_head;
     k1.lut = h->d_lut;
     k1.qt = s.d_qt;
-    k1.n_blocks = (uint32_t)n_blocks;
+    k1.n_blocks = (uint32_t)rows;
     k1.block_size = bs;
     k1.zero_halo = h->zero_halo ? 1u : 0u;
+    k1.head_rows = n_head ? 1u : 0u;
 
     s.timed = h->timing_level;
     hipEvent_t e0 = s.timed ? s.ev0 : nullptr, e1 = s.timed ? s.ev1 : nullptr;
-    // The batch submitted before this one left its K3.. for the second stream: they go there now, behind the end of
-    // THIS batch's K1 (its last launch carries the event), i.e. next to this batch's search.
-    const bool prev_tail_now = h->tail_events && prev.pending && prev.search && prev.tail_split && !prev.tail_enqueued;
-    if (prev_tail_now && !e1) e1 = s.ev_k1done;
     // One launch per "round" for long blocks: K1 holds 8 waves per CU, and a launch that exactly fills the chip keeps its
     // waves in step -- all of them read together and write their output bursts together.  A larger grid runs the later
     // rounds out of step (output stores trickle into the read stream all the time): BlockSize 4096, 4 GiB: 0.895 ms in
     // one launch, 4 x 0.179 ms in four; IDM (BlockSize 8192, 4 GiB) 0.860 -> 0.804 ms.  Short blocks (a round lasts
     // under 0.1 ms) lose more at the extra launch boundaries than they gain: BlockSize 2048 0.182 -> 0.256 ms, so they
-    // keep the single launch.  AMR_K1_ROUND=0 / =N: never split / rounds of N wave-tiles.
-    static const int round_env = [] { const char *e = getenv("AMR_K1_ROUND"); return e ? atoi(e) : -1; }();
-    const uint32_t round = round_env == 0 ? full : round_env > 0 ? (uint32_t)round_env
-                         : bs >= 4096 ? (uint32_t)h->n_cus * 8u : full;
+    // keep the single launch.
+    const uint32_t round = bs >= 4096 ? (uint32_t)h->n_cus * 8u : full;
     for (uint32_t w0 = 0; w0 < full; w0 += round) {
         const uint32_t n = std::min(round, full - w0);
         k1.wg_first = w0;
         launch_k1<false>(h->geom.chip_length, dim3(n), st, k1, w0 == 0 ? e0 : nullptr, (w0 + n == full && !rem) ? e1 : nullptr);
     }
-    if (rem) {   // the partial wave-tile: one wave (wave quantisation)
+    if (rem) {   // the partial wave-tile: one wave (sync callers, flush, batches under 64 blocks)
         k1.wg_first = full;
         launch_k1<true>(h->geom.chip_length, dim3(1), st, k1, full ? nullptr : e0, e1);
     }
     HIP_TRY(hipGetLastError());
     AMR_DBG(st, "k1_demod");
-    if (prev_tail_now) {
-        HIP_TRY(hipStreamWaitEvent(h->tail_stream, e1, 0));
-        AMR_TRY(enqueue_tail(h, prev, h->tail_stream, true));
-        hipLaunchKernelGGL(amr::k_done, dim3(1), dim3(1), 0, h->tail_stream, prev.h_done, prev.ticket, h->d_tail_done);
-        HIP_TRY(hipGetLastError());
-        HIP_TRY(hipEventRecord(prev.ev_tail, h->tail_stream));
-        prev.tail_enqueued = true;
-    }
     s.dense = h->dense_hold > 0;
     if (s.dense) h->dense_hold--;
-    // A caller that keeps batches in flight gets K3 (K4, K5) of this batch on the second stream, launched by collect()
+    // A caller that keeps batches in flight gets K3 (K4, K5) of this batch on the second stream, launched by the host
     // when the NEXT batch's K1 has finished: they then share the machine with that batch's search (which leaves room)
     // instead of standing between two K1 launches (which do not).
-    const bool lazy = search && h->allow_lazy && (h->lazy_tail || h->n_pending >= 1);
+    const bool lazy = search && (h->lazy_tail || h->n_pending >= 1);
     if (lazy) h->lazy_tail = true;
     // state carried to the next batch (decode.go:165-166): the last rows of this slot's bitstream become the history
-    // tile of the NEXT slot, the last HBA bytes of IQ the carry, the next slot's search words are reset.  The kernel
-    // that does it is also the last one in front of the next K1 launch, which must not meet the previous batch's K3..
-    // (it needs every wave slot): it waits for them on a device word.
-    amr::HistArgs ha{s.d_qt, other.d_qt, (uint32_t)n_blocks, h->hist_rows, h->sg.wpb, h->sg.lg_wpb,
-                     d_iq + n_blocks * (size_t)h->geom.block_size2 - h->halo_bytes, h->d_carry, h->halo_bytes, other.d_overflow,
+    // tile of the NEXT slot, the last HBA bytes of IQ (and the deferred blocks behind them) go to the head buffer, the
+    // next slot's search words are reset.  Whatever does it is also the last thing in front of the next K1 launch, which
+    // must not meet the previous batch's K3.. (it needs every wave slot): it waits for them on a device word.
+    const uint8_t *launch_end = rows > n_head ? d_iq + (rows - n_head) * bs2 : head_rows + rows * bs2;
+    amr::HistArgs ha{s.d_qt, other.d_qt, (uint32_t)rows, h->hist_rows, h->sg.wpb, h->sg.lg_wpb,
+                     launch_end - h->halo_bytes, h->d_head, h->halo_bytes,
+                     (uint32_t)(new_head * bs2), new_head ? 16u : 0u, other.d_overflow,
                      other.d_gcnt, other.gcnt_words,
                      lazy ? nullptr : s.h_done, s.ticket, &h->h_flags[1],
-                     (!prev_tail_now && prev.pending && prev.search && prev.tail_split) ? h->d_tail_done : nullptr, prev.ticket};
-    // pipelined callers: the update rides along with the search as one more workgroup (stream kernel only) instead of
-    // following it as a 5 us kernel; AMR_HIST_FOLD=0 keeps the kernel
-    static const bool fold_ok = [] { const char *e = getenv("AMR_HIST_FOLD"); return !(e && e[0] == '0'); }();
+                     (prev.pending && prev.search && prev.tail_split) ? h->d_tail_done : nullptr, prev.ticket};
+    // pipelined callers: the update rides along with the search as more workgroups of its launch instead of following it
+    // as a 5 us kernel
     bool folded = false;
     if (search) {
-        if (lazy) AMR_TRY(enqueue_k2(h, s, st, false, s.dense, true, (fold_ok && !prev_tail_now) ? &ha : nullptr, &folded));
+        if (lazy) AMR_TRY(enqueue_k2(h, s, st, false, s.dense, true, &ha, &folded));
         else AMR_TRY(enqueue_search(h, s, false, s.dense));
     }
     s.tail_enqueued = !lazy;
@@ -653,13 +642,13 @@ amr_status submit(amr_handle *h, const uint8_t *d_iq, size_t n_blocks, bool sear
         h->iqhist_valid = (uint32_t)std::min<uint64_t>(v, (uint64_t)h->geom.packet_length);
     }
     if (!folded) {
-        if (prev_tail_now) HIP_TRY(hipStreamWaitEvent(st, prev.ev_tail, 0));
-        hipLaunchKernelGGL(amr::k_hist_update, dim3(1), dim3(1024), (size_t)h->hist_rows * h->sg.wpb * 4, st, ha);
+        hipLaunchKernelGGL(amr::k_hist_update, dim3(1 + ha.defer_wgs), dim3(1024), (size_t)h->hist_rows * h->sg.wpb * 4, st, ha);
         HIP_TRY(hipGetLastError());
         AMR_DBG(st, "k_hist_update");
     }
     h->zero_halo = false;
-    if (search) h->calls_done += n_blocks;
+    h->n_head = new_head;
+    if (search) h->calls_done += rows;
     s.pending = true;
     h->n_pending++;
     h->next_slot = (h->next_slot + 1) % kSlots;
@@ -908,6 +897,8 @@ amr_status collect(amr_handle *h, amr_result *res)
             res->r900_preamble = h->r900_pid;
             res->r900_digits = h->r900_pid >= 0 ? s.h_r900 : nullptr;
             res->n_hits_searched = searched;
+            res->first_block = s.calls_base;
+            res->n_blocks = s.n_blocks;
         }
     }
     return AMR_OK;
@@ -1049,8 +1040,6 @@ amr_status amr_create(const amr_protocol *protos, int32_t n_protos, int32_t devi
     if (e == hipSuccess) { h->h_flags[0] = 0; h->h_flags[1] = 0; }
     if (e == hipSuccess) e = hipMalloc((void **)&h->d_tail_done, 8);
     if (e == hipSuccess) e = hipMemset(h->d_tail_done, 0, 8);
-    if (const char *ov = getenv("AMR_TAIL_OVERLAP")) h->allow_lazy = ov[0] != '0';
-    if (const char *tm = getenv("AMR_TAIL_MODE")) h->tail_events = strcmp(tm, "event") == 0;
     h->stream = h->own_stream;
     for (Slot &sl : h->slot) {
         if (e == hipSuccess) e = hipEventCreate(&sl.ev0);
@@ -1059,8 +1048,7 @@ amr_status amr_create(const amr_protocol *protos, int32_t n_protos, int32_t devi
         if (e == hipSuccess) e = hipEventCreate(&sl.ev_s);
         if (e == hipSuccess) e = hipEventCreate(&sl.ev_k2);
         if (e == hipSuccess) e = hipEventCreate(&sl.ev_t);
-        if (e == hipSuccess) e = hipEventCreateWithFlags(&sl.ev_k1done, hipEventDisableTiming);
-        if (e == hipSuccess) e = hipEventCreateWithFlags(&sl.ev_tail, hipEventDisableTiming);
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&sl.ev_pack, hipEventDisableTiming);
         if (e == hipSuccess) e = hipEventCreateWithFlags(&sl.ev_h2d, hipEventDisableTiming);
         if (e == hipSuccess) e = hipHostMalloc((void **)&sl.h_done, 8, hipHostMallocCoherent);
         if (e == hipSuccess) *sl.h_done = 0;
@@ -1073,9 +1061,10 @@ amr_status amr_create(const amr_protocol *protos, int32_t n_protos, int32_t devi
         if (e == hipSuccess) e = hipHostMalloc((void **)&sl.h_ovf, 4, hipHostMallocDefault);
     }
     if (e == hipSuccess) e = hipMalloc((void **)&h->d_lut, 1024);
-    if (e == hipSuccess) e = hipMalloc((void **)&h->d_carry, h->halo_bytes);
+    const size_t head_bytes = h->halo_bytes + (size_t)64 * h->geom.block_size2;
+    if (e == hipSuccess) e = hipMalloc((void **)&h->d_head, head_bytes);
     if (e == hipSuccess) e = hipMemcpy(h->d_lut, h->lut, 1024, hipMemcpyHostToDevice);
-    if (e == hipSuccess) e = hipMemset(h->d_carry, 0, h->halo_bytes);
+    if (e == hipSuccess) e = hipMemset(h->d_head, 0, head_bytes);
     if (e == hipSuccess) e = hipDeviceSynchronize();   // the memsets above ran on the null stream; ours is non-blocking
     if (e != hipSuccess) { amr_destroy(h); return fail(AMR_EHIP, "amr_create: device setup", e); }
     *out = h;
@@ -1098,10 +1087,12 @@ amr_status amr_destroy(amr_handle *h)
 {
     if (!h) return AMR_OK;
     (void)hipSetDevice(h->device);
+    // the communicator first: its stream may still hold a pack kernel that reads the slots' result buffers
+    if (h->comm) (void)amr_comm_destroy(h);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
     if (h->tail_stream) (void)hipStreamSynchronize(h->tail_stream);
     if (h->copy_stream) (void)hipStreamSynchronize(h->copy_stream);
-    void *ptrs[] = {h->d_lut, h->d_carry, h->d_iq, h->d_untile, h->d_tail_done};
+    void *ptrs[] = {h->d_lut, h->d_head, h->d_iq, h->d_untile, h->d_tail_done};
     for (void *p : ptrs) if (p) (void)hipFree(p);
     for (uint8_t *p : h->d_iqhist) if (p) (void)hipFree(p);
     if (h->h_flags) (void)hipHostFree(h->h_flags);
@@ -1113,11 +1104,10 @@ amr_status amr_destroy(amr_handle *h)
         for (void *p : dp) if (p) (void)hipFree(p);
         void *hp[] = {sl.h_off, sl.h_ovf, sl.h_out, sl.h_offv};
         for (void *p : hp) if (p) (void)hipHostFree(p);
-        hipEvent_t evs[] = {sl.ev0, sl.ev1, sl.ev_s, sl.ev2, sl.ev_k2, sl.ev_t, sl.ev_k1done, sl.ev_tail};
+        hipEvent_t evs[] = {sl.ev0, sl.ev1, sl.ev_s, sl.ev2, sl.ev_k2, sl.ev_t, sl.ev_pack};
         if (sl.h_done) (void)hipHostFree(sl.h_done);
         for (hipEvent_t ev : evs) if (ev) (void)hipEventDestroy(ev);
     }
-    if (h->comm) (void)amr_comm_destroy(h);
     if (h->own_stream) (void)hipStreamDestroy(h->own_stream);
     if (h->copy_stream) (void)hipStreamDestroy(h->copy_stream);
     if (h->h2d_stream) (void)hipStreamDestroy(h->h2d_stream);
@@ -1139,6 +1129,7 @@ amr_status amr_reset(amr_handle *h)
     h->calls_done = 0;
     h->last_n_blocks = 0;
     h->iqhist_valid = 0;
+    h->n_head = 0;            // deferred blocks belong to the stream that is forgotten
     return AMR_OK;
 }
 
@@ -1168,6 +1159,7 @@ amr_status amr_r900_enable(amr_handle *h, int32_t proto_index)
     // zero_halo is cleared by every submit, also by amr_prime (which does not advance calls_done): enabling afterwards
     // would zero the IQ history the primed blocks left
     if (h->calls_done != 0 || h->n_pending != 0 || !h->zero_halo) return fail(AMR_EINVAL, "amr_r900_enable: call before the first batch");
+    if (h->defer_on) return fail(AMR_EINVAL, "amr_r900_enable: not available with amr_set_deferral");
     HIP_TRY(hipSetDevice(h->device));
     h->r900_pid = h->proto_pid[(size_t)proto_index];
     h->rules[h->r900_pid] = amr::ValRule{};   // its hits carry digits by position: never filtered
@@ -1250,7 +1242,38 @@ amr_status amr_decode_batch_device(amr_handle *h, const void *d_iq, size_t n_blo
 amr_status amr_submit_device(amr_handle *h, const void *d_iq, size_t n_blocks)
 {
     if (!h || !d_iq) return fail(AMR_EINVAL, "null argument");
-    return submit(h, (const uint8_t *)d_iq, n_blocks, true);
+    if (n_blocks == 0) return fail(AMR_EINVAL, "n_blocks out of range");
+    return submit(h, (const uint8_t *)d_iq, n_blocks, true, true);
+}
+
+amr_status amr_set_deferral(amr_handle *h, int32_t on)
+{
+    if (!h) return fail(AMR_EINVAL, "null handle");
+    if (on && h->r900_pid >= 0) return fail(AMR_EINVAL, "amr_set_deferral: not available with amr_r900_enable (its second stage reads the batch's IQ by block)");
+    if (!on && h->n_head) return fail(AMR_EINVAL, "amr_set_deferral: blocks are deferred: amr_flush first");
+    h->defer_on = on != 0;
+    return AMR_OK;
+}
+
+amr_status amr_flush(amr_handle *h, amr_result *res)
+{
+    if (!h) return fail(AMR_EINVAL, "null handle");
+    if (h->n_pending) return fail(AMR_EINVAL, "amr_flush: batches in flight: collect them first");
+    if (h->n_head == 0) {          // nothing deferred: an empty result
+        h->r_off.assign(h->sg.n_pre + 1, 0);
+        h->last_total = 0;
+        if (res) {
+            *res = amr_result{};
+            res->n_preambles = h->sg.n_pre;
+            res->pkt_bytes = h->sg.pkt_bytes;
+            res->preamble_offset = h->r_off.data();
+            res->r900_preamble = h->r900_pid;
+            res->first_block = h->calls_done + h->block_base;
+        }
+        return AMR_OK;
+    }
+    AMR_TRY(submit(h, h->d_head + h->halo_bytes, 0, true));   // the deferred blocks alone: one partial wave-tile
+    return collect(h, res);
 }
 
 amr_status amr_submit_host(amr_handle *h, const uint8_t *iq, size_t iq_bytes, size_t n_blocks)
@@ -1269,7 +1292,7 @@ amr_status amr_submit_host(amr_handle *h, const uint8_t *iq, size_t iq_bytes, si
     HIP_TRY(hipMemcpyAsync(s.d_iq_stage, iq, need, hipMemcpyHostToDevice, h->h2d_stream));
     HIP_TRY(hipEventRecord(s.ev_h2d, h->h2d_stream));
     HIP_TRY(hipStreamWaitEvent(h->stream, s.ev_h2d, 0));
-    return submit(h, s.d_iq_stage, n_blocks, true);
+    return submit(h, s.d_iq_stage, n_blocks, true, true);
 }
 
 amr_status amr_host_alloc(size_t bytes, void **ptr)
@@ -1309,7 +1332,7 @@ amr_status amr_prime(amr_handle *h, const uint8_t *lead, const uint8_t *halo_iq,
     if (!h || !halo_iq) return fail(AMR_EINVAL, "null argument");
     HIP_TRY(hipSetDevice(h->device));
     if (lead) {
-        HIP_TRY(hipMemcpyAsync(h->d_carry, lead, h->halo_bytes,
+        HIP_TRY(hipMemcpyAsync(h->d_head, lead, h->halo_bytes,
                                on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, h->stream));
         h->zero_halo = false;
     }
@@ -1463,12 +1486,27 @@ amr_status amr_synth_plant(int32_t device_id, void *d_iq, uint64_t n_samples, ui
 // =====================================================================================================================
 // Multi-GPU: gather of the hit records on one rank.  One process per GPU; independent shards of whole
 // blocks need no data-path collective, the only exchange is this gather.  It runs on its own stream through RCCL
-// point-to-point calls (every peer sends its few MB to the root over its own xGMI link; no ring), is enqueued from the
-// host without any synchronisation -- amr_collect has already seen the batch complete, its packed result stays valid
-// until the slot is submitted again, two batches later -- and overlaps the kernels of the following batches.
+// point-to-point calls (every peer sends its records to the root over its own xGMI link; no ring) and is enqueued from
+// the host without any synchronisation, so that it overlaps the kernels of the following batches.
+//
+// Ordering.  amr_collect has seen the batch complete, so its packed result is there; it stays there until K3 / K5 of the
+// batch that REUSES the slot (the fourth submit after this one) overwrite it.  The pack kernel that reads it runs on the
+// communicator's stream, behind the previous gather's send -- which completes only when the root has posted its
+// receive, i.e. a lagging root or peer can hold it back for any length of time.  So the pack kernel is followed by an
+// event (Slot::ev_pack) and enqueue_tail() makes the stream that is about to overwrite the slot wait for it: back-pressure
+// instead of a timing assumption.  The send buffer of set k is reused by the pack of gather seq + 2 on the same stream,
+// i.e. in order behind the send that read it.
+//
+// Root side.  Behind the receives of a gather, on the same stream, an asynchronous copy brings every rank's slot
+// (header + the records it holds, sized by the capacity) into a pinned host mirror and an event marks its arrival:
+// amr_gather_fetch(seq, rank) waits for that event only -- no stream synchronisation, no blocking copy -- and returns
+// pointers into the mirror.  Two sets alternate: the records of gather `seq` stay valid until gather seq + 2 is posted.
+//
 // RCCL is bound at run time (dlopen): libamrdemod.so has no link-time dependency on it, and a process that already
 // carries a copy (PyTorch ships one) keeps using that one.
 // =====================================================================================================================
+#include <mutex>
+
 namespace {
 
 struct Id128 { char b[128]; };   // ncclUniqueId (rccl.h: char internal[128]), passed by value
@@ -1478,6 +1516,7 @@ struct Rccl {
     int (*GetUniqueId)(void *) = nullptr;
     int (*CommInitRank)(void **, int, Id128, int) = nullptr;
     int (*CommDestroy)(void *) = nullptr;
+    int (*CommCount)(void *, int *) = nullptr;
     int (*GroupStart)() = nullptr;
     int (*GroupEnd)() = nullptr;
     int (*Send)(const void *, size_t, int, int, void *, hipStream_t) = nullptr;
@@ -1488,26 +1527,26 @@ struct Rccl {
 Rccl *rccl()
 {
     static Rccl r;
-    static bool tried = false;
-    if (tried) return r.so ? &r : nullptr;
-    tried = true;
-    // a copy already in the process first (torch's librccl.so), then the ROCm one
-    const char *names[] = {"librccl.so", "librccl.so.1"};
-    for (const char *n : names) if (!r.so) r.so = dlopen(n, RTLD_NOW | RTLD_NOLOAD | RTLD_GLOBAL);
-    for (const char *n : names) if (!r.so) r.so = dlopen(n, RTLD_NOW | RTLD_GLOBAL);
-    if (!r.so) r.so = dlopen("/opt/rocm/lib/librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
-    if (!r.so) return nullptr;
+    static std::once_flag once;
+    std::call_once(once, [] {
+        // a copy already in the process first (torch's librccl.so), then the ROCm one
+        const char *names[] = {"librccl.so", "librccl.so.1"};
+        for (const char *n : names) if (!r.so) r.so = dlopen(n, RTLD_NOW | RTLD_NOLOAD | RTLD_GLOBAL);
+        for (const char *n : names) if (!r.so) r.so = dlopen(n, RTLD_NOW | RTLD_GLOBAL);
+        if (!r.so) r.so = dlopen("/opt/rocm/lib/librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
+        if (!r.so) return;
 #define AMR_SYM(field, name) *(void **)(&r.field) = dlsym(r.so, name)
-    AMR_SYM(GetUniqueId, "ncclGetUniqueId"); AMR_SYM(CommInitRank, "ncclCommInitRank"); AMR_SYM(CommDestroy, "ncclCommDestroy");
-    AMR_SYM(GroupStart, "ncclGroupStart"); AMR_SYM(GroupEnd, "ncclGroupEnd"); AMR_SYM(Send, "ncclSend"); AMR_SYM(Recv, "ncclRecv");
-    AMR_SYM(GetErrorString, "ncclGetErrorString");
+        AMR_SYM(GetUniqueId, "ncclGetUniqueId"); AMR_SYM(CommInitRank, "ncclCommInitRank"); AMR_SYM(CommDestroy, "ncclCommDestroy");
+        AMR_SYM(CommCount, "ncclCommCount");
+        AMR_SYM(GroupStart, "ncclGroupStart"); AMR_SYM(GroupEnd, "ncclGroupEnd"); AMR_SYM(Send, "ncclSend"); AMR_SYM(Recv, "ncclRecv");
+        AMR_SYM(GetErrorString, "ncclGetErrorString");
 #undef AMR_SYM
-    if (!r.GetUniqueId || !r.CommInitRank || !r.CommDestroy || !r.GroupStart || !r.GroupEnd || !r.Send || !r.Recv) { r.so = nullptr; return nullptr; }
-    return &r;
+        if (!r.GetUniqueId || !r.CommInitRank || !r.CommDestroy || !r.GroupStart || !r.GroupEnd || !r.Send || !r.Recv) r.so = nullptr;
+    });
+    return r.so ? &r : nullptr;
 }
 
 constexpr int kNcclUint8 = 1;              // ncclDataType_t: ncclInt8 0, ncclUint8 1 (rccl.h)
-constexpr uint32_t kGatherHdr = 16;        // u64 words in front of the records: [n_true, n_sent, n_pre, offs[0..n_pre]]
 
 amr_status nccl_fail(const char *what, int rc)
 {
@@ -1518,18 +1557,52 @@ amr_status nccl_fail(const char *what, int rc)
 }
 #define NCCL_TRY(expr) do { int rc_ = (expr); if (rc_ != 0) return nccl_fail(#expr, rc_); } while (0)
 
-// header + the first min(n, cap) (block, idx) records of a packed result -> one contiguous send buffer
-__global__ void k_gather_pack(const uint8_t *packed, const uint64_t *offs, uint32_t n_pre, uint64_t cap, uint64_t *send)
+// ---- the gather slot: ONE description of its layout, used by the device pack kernel, by amr_gather_pack_host (CPU
+// hosts and the gloo tests) and by amr_gather_unpack / amr_gather_fetch --------------------------------------------------
+//   u64 words [0] n_true  [1] n_sent = min(n_true, cap)  [2] n_pre  [3 .. 3+n_pre] per-preamble offsets into the
+//   source rank's (untruncated) hit arrays  [12] gather sequence number  -- header of kGatherHdr words, then
+//   n_sent call indices (u64), then n_sent idx (u32).
+constexpr uint32_t kGatherHdr = AMR_GATHER_HEADER_BYTES / 8;
+static_assert(3 + AMR_MAX_PREAMBLES + 1 <= 12 && kGatherHdr >= 13, "gather header layout");
+
+__host__ __device__ inline size_t gather_slot_bytes(uint64_t cap)
+{
+    return ((size_t)kGatherHdr * 8 + (size_t)cap * 12 + 255) & ~(size_t)255;
+}
+
+// element i of `stride` workers: header words and records of a packed result [blk u64 x n | idx u32 x n | ...]
+__host__ __device__ inline void gather_pack_part(const uint64_t *blk, const uint32_t *idx, const uint64_t *offs, uint32_t n_pre,
+                                                 uint64_t cap, uint64_t seq, uint64_t *slot, uint64_t t, uint64_t stride)
 {
     const uint64_t n = offs[n_pre], m = n < cap ? n : cap;
-    const uint64_t *blk = reinterpret_cast<const uint64_t *>(packed);
-    const uint32_t *idx = reinterpret_cast<const uint32_t *>(packed + n * 8);
-    uint64_t *rb = send + kGatherHdr;
+    uint64_t *rb = slot + kGatherHdr;
     uint32_t *ri = reinterpret_cast<uint32_t *>(rb + m);
-    const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x, stride = (uint64_t)gridDim.x * blockDim.x;
-    if (t == 0) { send[0] = n; send[1] = m; send[2] = n_pre; }
-    if (t <= n_pre) send[3 + t] = offs[t];
+    if (t == 0) { slot[0] = n; slot[1] = m; slot[2] = n_pre; slot[12] = seq; }
+    for (uint64_t i = t; i <= n_pre; i += stride) slot[3 + i] = offs[i];
     for (uint64_t i = t; i < m; i += stride) { rb[i] = blk[i]; ri[i] = idx[i]; }
+}
+
+__global__ void k_gather_pack(const uint8_t *packed, const uint64_t *offs, uint32_t n_pre, uint64_t cap, uint64_t seq, uint64_t *slot)
+{
+    const uint64_t n = offs[n_pre];
+    gather_pack_part(reinterpret_cast<const uint64_t *>(packed), reinterpret_cast<const uint32_t *>(packed + n * 8), offs, n_pre,
+                     cap, seq, slot, (uint64_t)blockIdx.x * blockDim.x + threadIdx.x, (uint64_t)gridDim.x * blockDim.x);
+}
+
+amr_status gather_unpack(const void *slot, size_t slot_bytes, amr_gathered *out)
+{
+    const uint64_t *hdr = reinterpret_cast<const uint64_t *>(slot);
+    if (slot_bytes < (size_t)kGatherHdr * 8) return fail(AMR_EINVAL, "gather slot shorter than its header");
+    if (hdr[2] > AMR_MAX_PREAMBLES || hdr[1] > hdr[0] || (size_t)kGatherHdr * 8 + hdr[1] * 12 > slot_bytes)
+        return fail(AMR_EINVAL, "gather slot header inconsistent");
+    out->n_true = hdr[0];
+    out->n_hits = hdr[1];
+    out->n_preambles = (uint32_t)hdr[2];
+    out->seq = hdr[12];
+    out->preamble_offset = hdr + 3;
+    out->hit_block = hdr + kGatherHdr;
+    out->hit_idx = reinterpret_cast<const uint32_t *>(hdr + kGatherHdr + hdr[1]);
+    return AMR_OK;
 }
 
 }  // namespace
@@ -1542,9 +1615,31 @@ struct Comm {
     hipStream_t stream = nullptr;
     uint8_t *d_send[2] = {nullptr, nullptr};
     uint8_t *d_recv[2] = {nullptr, nullptr};   // root: world slots each
-    int next = 0, last = -1;
-    std::vector<uint8_t> host;   // amr_gather_fetch staging
+    uint8_t *h_recv[2] = {nullptr, nullptr};   // root: pinned mirror of d_recv
+    hipEvent_t ev_host[2] = {nullptr, nullptr};   // root: the mirror of set k has arrived
+    uint64_t seq_of[2] = {~0ull, ~0ull};       // gather sequence number each set holds
+    uint64_t next_seq = 0;
 };
+
+extern "C" {
+
+size_t amr_gather_slot_bytes(uint64_t cap_hits) { return gather_slot_bytes(cap_hits); }
+
+amr_status amr_gather_pack_host(const amr_result *res, uint64_t cap_hits, uint64_t seq, void *slot, size_t slot_bytes)
+{
+    if (!res || !slot || !res->preamble_offset || res->n_preambles > AMR_MAX_PREAMBLES) return fail(AMR_EINVAL, "null argument");
+    if (slot_bytes < gather_slot_bytes(cap_hits)) return fail(AMR_EINVAL, "amr_gather_pack_host: slot too small for the capacity");
+    if (res->preamble_offset[res->n_preambles] != res->n_hits) return fail(AMR_EINVAL, "amr_gather_pack_host: offsets do not end at n_hits");
+    gather_pack_part(res->hit_block, res->hit_idx, res->preamble_offset, res->n_preambles, cap_hits, seq,
+                     reinterpret_cast<uint64_t *>(slot), 0, 1);
+    return AMR_OK;
+}
+
+amr_status amr_gather_unpack(const void *slot, size_t slot_bytes, amr_gathered *out)
+{
+    if (!slot || !out) return fail(AMR_EINVAL, "null argument");
+    return gather_unpack(slot, slot_bytes, out);
+}
 
 amr_status amr_comm_unique_id(void *id128)
 {
@@ -1566,7 +1661,7 @@ amr_status amr_comm_init(amr_handle *h, const void *id128, int32_t rank, int32_t
     Comm *c = new (std::nothrow) Comm();
     if (!c) return fail(AMR_ENOMEM, "Comm");
     c->rank = rank; c->world = world; c->root = root; c->cap = cap_hits;
-    c->slot_bytes = ((size_t)kGatherHdr * 8 + (size_t)cap_hits * 12 + 255) & ~(size_t)255;
+    c->slot_bytes = gather_slot_bytes(cap_hits);
     Id128 id;
     memcpy(id.b, id128, 128);
     int rc = r->CommInitRank(&c->comm, world, id, rank);
@@ -1575,9 +1670,22 @@ amr_status amr_comm_init(amr_handle *h, const void *id128, int32_t rank, int32_t
     for (int k = 0; k < 2 && e == hipSuccess; ++k) {
         e = hipMalloc((void **)&c->d_send[k], c->slot_bytes);
         if (e == hipSuccess && rank == root) e = hipMalloc((void **)&c->d_recv[k], c->slot_bytes * (size_t)world);
+        if (e == hipSuccess && rank == root) e = hipHostMalloc((void **)&c->h_recv[k], c->slot_bytes * (size_t)world, hipHostMallocDefault);
+        if (e == hipSuccess && rank == root) e = hipEventCreateWithFlags(&c->ev_host[k], hipEventDisableTiming);
     }
     h->comm = c;
     if (e != hipSuccess) { (void)amr_comm_destroy(h); return fail(AMR_ENOMEM, "amr_comm_init: buffers", e); }
+    return AMR_OK;
+}
+
+amr_status amr_comm_ranks(const amr_handle *h, int32_t *n_ranks)
+{
+    if (!h || !h->comm || !n_ranks) return fail(AMR_EINVAL, "amr_comm_ranks: amr_comm_init first");
+    Rccl *r = rccl();
+    if (!r || !r->CommCount) return fail(AMR_ENODEV, "ncclCommCount not available");
+    int n = 0;
+    NCCL_TRY(r->CommCount(h->comm->comm, &n));
+    *n_ranks = n;
     return AMR_OK;
 }
 
@@ -1587,39 +1695,52 @@ amr_status amr_comm_destroy(amr_handle *h)
     Comm *c = h->comm;
     (void)hipSetDevice(h->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
+    for (Slot &sl : h->slot) sl.pack_pending = false;
     Rccl *r = rccl();
     if (r && c->comm) (void)r->CommDestroy(c->comm);
-    for (int k = 0; k < 2; ++k) { if (c->d_send[k]) (void)hipFree(c->d_send[k]); if (c->d_recv[k]) (void)hipFree(c->d_recv[k]); }
+    for (int k = 0; k < 2; ++k) {
+        if (c->d_send[k]) (void)hipFree(c->d_send[k]);
+        if (c->d_recv[k]) (void)hipFree(c->d_recv[k]);
+        if (c->h_recv[k]) (void)hipHostFree(c->h_recv[k]);
+        if (c->ev_host[k]) (void)hipEventDestroy(c->ev_host[k]);
+    }
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
     h->comm = nullptr;
     return AMR_OK;
 }
 
-amr_status amr_gather_hits(amr_handle *h)
+amr_status amr_gather_hits(amr_handle *h, uint64_t *seq_out)
 {
     if (!h || !h->comm) return fail(AMR_EINVAL, "amr_gather_hits: amr_comm_init first");
     if (h->last_slot < 0) return fail(AMR_EINVAL, "amr_gather_hits: no batch collected yet");
     Rccl *r = rccl();
     Comm *c = h->comm;
     HIP_TRY(hipSetDevice(h->device));
-    const Slot &s = h->slot[h->last_slot];
+    Slot &s = h->slot[h->last_slot];
     const uint8_t *packed = h->validate ? s.d_val : s.d_out;
     const uint64_t *offs = h->validate ? s.d_offs_val : s.d_offs_pre;
-    const int k = c->next;
-    // everything below is ordered by the communicator's stream: the pack kernel of this gather runs behind the
-    // collective that last used buffer set k
-    hipLaunchKernelGGL(k_gather_pack, dim3(64), dim3(256), 0, c->stream, packed, offs, h->sg.n_pre, c->cap,
+    const uint64_t seq = c->next_seq++;
+    const int k = (int)(seq & 1);
+    // on the communicator's stream: behind the send (and the root's mirror copy) that last used buffer set k
+    hipLaunchKernelGGL(k_gather_pack, dim3(64), dim3(256), 0, c->stream, packed, offs, h->sg.n_pre, c->cap, seq,
                        reinterpret_cast<uint64_t *>(c->d_send[k]));
     HIP_TRY(hipGetLastError());
+    // whoever overwrites this slot's result next waits for the pack kernel (enqueue_tail)
+    HIP_TRY(hipEventRecord(s.ev_pack, c->stream));
+    s.pack_pending = true;
     NCCL_TRY(r->GroupStart());
     NCCL_TRY(r->Send(c->d_send[k], c->slot_bytes, kNcclUint8, c->root, c->comm, c->stream));
     if (c->rank == c->root)
         for (int p = 0; p < c->world; ++p)
             NCCL_TRY(r->Recv(c->d_recv[k] + (size_t)p * c->slot_bytes, c->slot_bytes, kNcclUint8, p, c->comm, c->stream));
     NCCL_TRY(r->GroupEnd());
-    c->last = k;
-    c->next ^= 1;
+    if (c->rank == c->root) {
+        HIP_TRY(hipMemcpyAsync(c->h_recv[k], c->d_recv[k], c->slot_bytes * (size_t)c->world, hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(hipEventRecord(c->ev_host[k], c->stream));
+    }
+    c->seq_of[k] = seq;
+    if (seq_out) *seq_out = seq;
     return AMR_OK;
 }
 
@@ -1631,22 +1752,19 @@ amr_status amr_gather_wait(amr_handle *h)
     return AMR_OK;
 }
 
-amr_status amr_gather_fetch(amr_handle *h, int32_t src_rank, amr_gathered *out)
+amr_status amr_gather_fetch(amr_handle *h, uint64_t seq, int32_t src_rank, amr_gathered *out)
 {
     if (!h || !h->comm || !out) return fail(AMR_EINVAL, "amr_gather_fetch: null argument / no communicator");
     Comm *c = h->comm;
     if (c->rank != c->root) return fail(AMR_EINVAL, "amr_gather_fetch: only the root holds the gathered records");
-    if (c->last < 0 || src_rank < 0 || src_rank >= c->world) return fail(AMR_EINVAL, "amr_gather_fetch: nothing gathered / bad rank");
+    if (src_rank < 0 || src_rank >= c->world) return fail(AMR_EINVAL, "amr_gather_fetch: bad rank");
+    const int k = (int)(seq & 1);
+    if (c->seq_of[k] != seq) return fail(AMR_EINVAL, "amr_gather_fetch: that gather was never posted or its records have been overwritten (two sets)");
     HIP_TRY(hipSetDevice(h->device));
-    HIP_TRY(hipStreamSynchronize(c->stream));
-    c->host.resize(c->slot_bytes);
-    HIP_TRY(hipMemcpy(c->host.data(), c->d_recv[c->last] + (size_t)src_rank * c->slot_bytes, c->slot_bytes, hipMemcpyDeviceToHost));
-    const uint64_t *hdr = reinterpret_cast<const uint64_t *>(c->host.data());
-    out->n_true = hdr[0];
-    out->n_hits = hdr[1];
-    out->n_preambles = (uint32_t)hdr[2];
-    out->preamble_offset = hdr + 3;
-    out->hit_block = hdr + kGatherHdr;
-    out->hit_idx = reinterpret_cast<const uint32_t *>(hdr + kGatherHdr + hdr[1]);
+    HIP_TRY(hipEventSynchronize(c->ev_host[k]));      // the mirror copy of this gather, nothing else
+    AMR_TRY(gather_unpack(c->h_recv[k] + (size_t)src_rank * c->slot_bytes, c->slot_bytes, out));
+    if (out->seq != seq) return fail(AMR_EHIP, "amr_gather_fetch: a rank's slot carries another gather's sequence number (ranks out of step)");
     return AMR_OK;
 }
+
+}  // extern "C"

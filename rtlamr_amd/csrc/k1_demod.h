@@ -81,15 +81,26 @@ constexpr int kTileBytes = 128;                 // IQ bytes per row per staging 
 constexpr int kTileBuf = kRows * kTileBytes;    // 8 KiB per buffer
 
 struct K1Args {
-    const uint8_t *iq;     // batch block 0, byte 0 (device)
-    const uint8_t *carry;  // the HBA stream bytes that precede iq (device, always valid memory)
+    const uint8_t *iq;     // row 0 of the launch, byte 0 (device); with head_rows the rows below 64 are never read from here
+    const uint8_t *carry;  // the "head" buffer: the HBA stream bytes that precede row 0 of the launch, and behind them
+                           // (head_rows) the 64 rows of wave-tile 0, contiguous like a caller's batch
     const float *lut;      // NewMagLUT, 256 floats (device)
     uint32_t *qt;          // tiled bitstream; tile 0 = history tile
     uint32_t n_blocks;     // blocks in the batch
     uint32_t block_size;   // BlockSize in samples (power of two >= 512)
     uint32_t wg_first;     // first wave-tile of this launch
     uint32_t zero_halo;    // 1: magnitudes before batch block 0 are 0.0 (fresh Decoder, decode.go:144)
+    // 1: wave-tile 0 of the launch lies in the head buffer (blocks deferred from the previous batch in front, the first
+    // blocks of this batch copied in behind them, see submit() in amrdemod.hip); wave-tiles >= 1 are at iq + row * bs2
+    uint32_t head_rows;
 };
+
+// start of the row stream (block 0 of the wave-tile, byte 0) a wave-tile reads
+template <int HBA>
+__device__ __forceinline__ const uint8_t *k1_tile_base(const K1Args &a, uint32_t wg, uint32_t bs2)
+{
+    return (wg == 0 && a.head_rows) ? a.carry + HBA : a.iq + (int64_t)wg * kRows * bs2;
+}
 
 template <int CL>
 struct K1Geom {
@@ -165,9 +176,10 @@ __device__ __forceinline__ void k1_prefetch(const K1Args &a, uint32_t lds_base, 
     using G = K1Geom<CL>;
     const uint32_t bs2 = a.block_size * 2;
     // uniform: first row of this wave-tile, shifted to staging tile t of the (aligned-halo + block) stream
-    const uint8_t *sb = a.iq + (int64_t)wg * kRows * bs2 - G::HBA + (int64_t)t * kTileBytes;
+    const uint8_t *sb = k1_tile_base<G::HBA>(a, wg, bs2) - G::HBA + (int64_t)t * kTileBytes;
     const uint32_t rl = lane >> 3;
-    const bool carry_tile = (wg == 0) && (t < (uint32_t)G::NPT);
+    // row 0 of the launch takes its halo from the head buffer; with head_rows the whole wave-tile sits behind it anyway
+    const bool carry_tile = (wg == 0) && (t < (uint32_t)G::NPT) && !a.head_rows;
     // LDS-DMA: 64 lanes x 16 bytes -> 1 KiB of LDS at M0.  Issued from inline asm on purpose: when hipcc sees an
     // LDS-DMA in flight it guards EVERY later LDS load that may alias its target with s_waitcnt vmcnt(0), which
     // would serialise the prefetch of tile t+1 with the consumption of tile t.  Hidden in asm, the DMA is

@@ -438,7 +438,7 @@ __global__ __launch_bounds__(64, 2) void k1t_demod(const K1Args a)
     // per piece q: start of the (aligned-halo + block) stream of row 8q of this wave-tile
     const uint8_t *sb[8];
 #pragma unroll
-    for (int q = 0; q < 8; ++q) sb[q] = a.iq + (int64_t)wg * kRows * bs2 - G::HBA + (int64_t)q * 8 * bs2;
+    for (int q = 0; q < 8; ++q) sb[q] = k1_tile_base<G::HBA>(a, wg, bs2) - G::HBA + (int64_t)q * 8 * bs2;
 
     K1TLane<CL, C> L;
 #pragma unroll

@@ -59,6 +59,10 @@ struct HistArgs {
     const uint8_t *carry_src;
     uint8_t *carry_dst;
     uint32_t carry_bytes;   // multiple of 16
+    // blocks deferred to the next launch (amr_set_deferral): they follow the carry bytes in the stream and in the head
+    // buffer (carry_src + carry_bytes -> carry_dst + carry_bytes), copied by `defer_wgs` extra workgroups of the launch
+    uint32_t defer_bytes;   // multiple of 16
+    uint32_t defer_wgs;
     uint32_t *ovf_next;
     uint32_t *gcnt_next;    // the group sums the next batch's K2 adds into
     uint32_t gcnt_words;
@@ -104,6 +108,16 @@ __device__ __forceinline__ void hist_body(const HistArgs &a, uint32_t *tmp, uint
     __syncthreads();
 }
 
+// slice `part` of `parts` of the deferred blocks, by a workgroup of `nt` threads
+__device__ __forceinline__ void defer_copy_body(const HistArgs &a, uint32_t part, uint32_t nt)
+{
+    const uint32_t n16 = a.defer_bytes / 16, per = (n16 + a.defer_wgs - 1) / a.defer_wgs;
+    const uint32_t lo = part * per, hi = lo + per < n16 ? lo + per : n16;
+    const uint4 *src = reinterpret_cast<const uint4 *>(a.carry_src + a.carry_bytes);
+    uint4 *dst = reinterpret_cast<uint4 *>(a.carry_dst + a.carry_bytes);
+    for (uint32_t i = lo + threadIdx.x; i < hi; i += nt) dst[i] = src[i];
+}
+
 // the tickets, by one thread, once everything of the batch on this stream has completed
 __device__ __forceinline__ void hist_publish(const HistArgs &a)
 {
@@ -120,6 +134,7 @@ __device__ __forceinline__ void hist_publish(const HistArgs &a)
 __global__ __launch_bounds__(1024) void k_hist_update(const HistArgs a)
 {
     extern __shared__ uint32_t hist_tmp[];  // hr*wpb words
+    if (blockIdx.x) { defer_copy_body(a, blockIdx.x - 1, 1024); return; }
     hist_body(a, hist_tmp, 1024);
     // every earlier kernel of the batch has completed (same stream); the host polls these words
     if (threadIdx.x == 0) hist_publish(a);
@@ -134,20 +149,36 @@ struct K2Args {
     uint32_t n_tiles;      // tiles searched: ceil(n_blocks/64) + 1 (history tile first)
     uint32_t cap;
     int64_t n_lo, n_hi;    // valid positions: n_lo <= n < n_hi, n relative to batch sample 0
-    unsigned long long *dbg;   // developer diagnostics (AMR_K2_DBG): 16 words of timestamps per workgroup, or null
-    uint32_t xcd;              // stream kernel: XCD-contiguous tile order (the grid is then 8 * ceil(n_tiles / 8))
+    unsigned long long *dbg;   // harness builds only (AMR_K2S_DBG): 16 words of timestamps per workgroup, or null
     // pinned host word that receives `started_value` when the search starts, i.e. when everything before it on the
     // stream (this batch's K1) has finished: the host then launches the previous batch's K3 on the second stream
     uint64_t *started;
     uint64_t started_value;
-    // stream kernel, pipelined callers: the state update rides along as one more workgroup (tile index n_tiles) instead
-    // of a 5 us kernel of its own behind the search.  It carries no completion ticket (the search is still running
+    // pipelined callers: the state update rides along as one more workgroup (tile index n_tiles; the hist.defer_wgs
+    // workgroups behind it copy the deferred blocks) instead of a 5 us kernel of its own behind the search.  It carries
+    // no completion ticket (the search is still running
     // when it is done; a ticket from inside the kernel would also need every workgroup to release its writes, an L2
     // write-back each): the host takes "the next search has started" or "the stream is idle" as the signal instead.
     uint32_t do_hist;
     HistArgs hist;
     SearchGeom g;
 };
+
+// Workgroups behind the last tile of a search launch: the folded state update and the deferred-block copies.
+// Returns true when this workgroup was one of them (and is done).
+__device__ __forceinline__ bool k2_extra_workgroup(const K2Args &a, uint32_t T, uint32_t *lds, uint32_t nt)
+{
+    if (T < a.n_tiles) return false;
+    if (a.do_hist) {
+        if (T == a.n_tiles) {
+            hist_body(a.hist, lds, nt);
+            if (threadIdx.x == 0) hist_publish(a.hist);   // no tickets here (the search is still running): only the wait
+        } else if (T - a.n_tiles - 1 < a.hist.defer_wgs) {
+            defer_copy_body(a.hist, T - a.n_tiles - 1, nt);
+        }
+    }
+    return true;
+}
 
 __device__ __forceinline__ void k2_announce(const K2Args &a)
 {
@@ -180,6 +211,7 @@ __global__ __launch_bounds__(256) void k2_search_dense(const K2Args a)
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];  // wpb*65 words + 8 counters
     const SearchGeom &g = a.g;
     const uint32_t T = blockIdx.x;
+    if (k2_extra_workgroup(a, T, lds, 256)) return;
     const uint32_t tid = threadIdx.x;
     const uint32_t wpb = g.wpb, lg_wpb = g.lg_wpb, wpb_mask = wpb - 1;
     const uint32_t tile_words = 64u << lg_wpb;
@@ -300,6 +332,7 @@ __global__ __launch_bounds__(64 * NWV) void k2_search_fast(const K2Args a)
     k2_announce(a);
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
     const uint32_t T = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
+    if (k2_extra_workgroup(a, T, lds, 64 * NWV)) return;
     // the wave index is wave-uniform, but hipcc cannot know that of tid >> 6: without readfirstlane the whole
     // window addressing below is done per lane in VALU and its branches become exec-masked double execution
     const uint32_t v = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -551,117 +584,16 @@ struct K3Args {
     SearchGeom g;
 };
 
-// bit q[n] for n relative to batch sample 0 (n >= -64*BS): tiled row 64 + floor(n/BS)
-__device__ __forceinline__ uint32_t k3_bit(const uint32_t *qt, int64_t n, const SearchGeom &g)
-{
-    const uint64_t u = (uint64_t)(n + ((int64_t)64 << g.lg_block_size));
-    const uint64_t R = u >> g.lg_block_size;
-    const uint32_t b = (uint32_t)u & (g.block_size - 1);
-    const uint32_t word = qt[qt_index(R, b >> 5, g.lg_wpb)];
-    return (word >> (31 - (b & 31))) & 1u;
-}
-
-__global__ __launch_bounds__(256) void k3_slice(const K3Args a)
-{
-    const SearchGeom &g = a.g;
-    const uint32_t T = blockIdx.x, q = blockIdx.y;
-    // Slot of this (tile, preamble) list in the packed result = the hits of all lists before it (preamble-major), and
-    // the layout needs the grand total.  No scan kernel between K2 and K3 (a dispatch costs the stream ~5 us): K2 left
-    // sums over groups of 64 tiles, so a workgroup adds up the group sums before its group, the <= 63 counts before
-    // it inside the group, and all group sums for the total -- one load per lane.  The workgroups of tile 0 publish
-    // the per-preamble bases, (0,0) also the total and K2's overflow word, for the later kernels and for the host.
-    __shared__ uint64_t red[2][4];
-    const uint32_t cnt = a.counts[q * a.n_tiles + T];
-    if (cnt == 0 && T != 0) return;
-    const uint32_t n_groups = k2_groups(a.n_tiles), my_g = q * n_groups + (T >> 6);
-    uint64_t before = 0, all = 0;
-    for (uint32_t i = threadIdx.x; i < g.n_pre * n_groups; i += 256) {
-        const uint32_t c = a.gcnt[i];
-        all += c;
-        before += i < my_g ? c : 0u;
-    }
-    if (threadIdx.x < (T & 63)) before += a.counts[q * a.n_tiles + (T & ~63u) + threadIdx.x];
-    for (int d = 32; d; d >>= 1) {
-        before += __shfl_down((unsigned long long)before, d);
-        all += __shfl_down((unsigned long long)all, d);
-    }
-    if ((threadIdx.x & 63) == 0) { red[0][threadIdx.x >> 6] = before; red[1][threadIdx.x >> 6] = all; }
-    __syncthreads();
-    const uint64_t off = red[0][0] + red[0][1] + red[0][2] + red[0][3];
-    const uint64_t total = red[1][0] + red[1][1] + red[1][2] + red[1][3];
-    if (T == 0 && threadIdx.x == 0) {
-        a.offs_pre[q] = off;
-        a.h_offs_pre[q] = off;
-        if (q == 0) { a.offs_pre[g.n_pre] = total; a.h_offs_pre[g.n_pre] = total; *a.h_overflow = *a.overflow; }
-    }
-    // After an overflow the staging slots are incomplete (a wave whose sparse list overflowed counted hits it
-    // never emitted), so their contents must not be used as positions; the host re-runs the search anyway.
-    if (*a.overflow || cnt == 0) return;
-    if (total > a.out_cap) return;   // the host grows the buffer and searches again
-    uint64_t *hit_block = reinterpret_cast<uint64_t *>(a.out);
-    uint32_t *hit_idx = reinterpret_cast<uint32_t *>(a.out + total * 8);
-    uint8_t *pkt = a.out + total * 12;
-    const uint32_t *src = a.staging + ((size_t)T * g.n_pre + q) * a.cap;
-    // One lane = 32 symbols of one hit (rounds = ceil(PacketSymbols/32) lanes per hit; rounds-major so that the lanes
-    // of a wave hold neighbouring hits).  A real packet yields a run of adjacent hit positions: for every symbol
-    // the lanes of a wave then read the same one or two bitstream words (one cache line).  The 32 word loads of a
-    // lane are independent and all in flight together -- the bitstream is larger than the L2, a load costs ~1 us.
-    const uint32_t rounds = (g.packet_symbols + 31) >> 5;
-    for (uint32_t i = threadIdx.x; i < cnt * rounds; i += 256) {
-        const uint32_t r = i / cnt, h = i - r * cnt;
-        const uint64_t slot = off + h;
-        const uint32_t local = src[h];
-        if (local >= (64u << g.lg_block_size)) continue;   // defensive: never index the bitstream with a bad position
-        // n relative to batch sample 0 of the first preamble bit
-        const int64_t n = ((int64_t)T * 64 - 64) * (int64_t)g.block_size + local;
-        if (r == 0) {
-            const uint64_t pos = (uint64_t)(n + g.packet_length);
-            hit_block[slot] = a.block_base + (pos >> g.lg_block_size);
-            hit_idx[slot] = (uint32_t)pos & (g.block_size - 1);
-        }
-        uint8_t *out = pkt + slot * g.pkt_bytes;
-        const uint32_t p0 = r * 32;
-        // 32-bit tile-local arithmetic: bit position v = local + p*SL counts from row 0 of tile T (it may run a few
-        // rows into tile T+1); the word of v is at tile_base + (row>>6)*tile_words + (w>>2)*256 + (row&63)*4 + (w&3)
-        const uint32_t *tbase = a.qt + ((size_t)T << (6 + g.lg_wpb));
-        const uint32_t lg_bs = g.lg_block_size, bs_mask = g.block_size - 1, lg_tw = 6 + g.lg_wpb;
-        const uint32_t last = g.packet_symbols - 1;
-        uint32_t wv[32], sh[32];
-#pragma unroll
-        for (uint32_t k = 0; k < 32; ++k) {
-            const uint32_t p = p0 + k < g.packet_symbols ? p0 + k : last;
-            const uint32_t v = local + p * g.symbol_length;
-            const uint32_t row = v >> lg_bs, w = (v & bs_mask) >> 5;
-            wv[k] = tbase[((row >> 6) << lg_tw) + ((w >> 2) << 8) + ((row & 63) << 2) + (w & 3)];
-            sh[k] = 31 - (v & 31);
-        }
-        uint32_t bits = 0;
-#pragma unroll
-        for (uint32_t k = 0; k < 32; ++k) bits = (bits << 1) | ((wv[k] >> sh[k]) & 1u);
-        // bits holds symbols p0..p0+31, first symbol in bit 31: bytes p0/8 .. p0/8+3 (MSB first, decode.go:363-366)
-#pragma unroll
-        for (uint32_t j = 0; j < 4; ++j) {
-            const uint32_t bj = p0 / 8 + j;
-            if (bj < g.pkt_bytes) {
-                uint32_t byte = (bits >> (24 - 8 * j)) & 0xffu;
-                const uint32_t valid = g.packet_symbols - bj * 8;     // symbols that exist in this byte
-                if (valid < 8) byte >>= (8 - valid);                  // PacketSymbols % 8 != 0: right-aligned like Go's shift-in
-                out[bj] = (uint8_t)byte;
-            }
-        }
-    }
-}
-
-// K3, second generation.  The hits of a real packet (and most noise hits' neighbours) come in runs of adjacent
-// positions, so the per-hit slicing above reads every bitstream word ~20 times and spends ~13 VALU operations per
-// (hit, symbol).  Here the unit of work is a bitstream WORD that holds hits: for symbol p the 32 positions of the word
+// K3 slices by bitstream word, not by hit.  The hits of a real packet (and most noise hits' neighbours) come in runs of
+// adjacent positions, so slicing hit by hit (round 1: one lane = 32 symbols of one hit) read every bitstream word ~20
+// times and spent ~13 VALU operations per (hit, symbol).  Here the unit of work is a bitstream WORD that holds hits: for symbol p the 32 positions of the word
 // need the 32 stream bits starting at word*32 + p*SL -- one window, one or two word loads (SL is a multiple of 16) --
 // and the packets of all 32 positions are the columns of the bit matrix [symbol][position].  A wave takes 64 symbols
 // at a time, lane = symbol (two 32 x 32 blocks), transposes the blocks in five exchange steps (ds_swizzle, no LDS
 // memory), after which lane c of a block holds 32 consecutive packet bits of position 31-c: one dword of that packet,
 // already in the byte order of Decoder.Slice (decode.go:363-366) because the symbols were dealt to the lanes
 // bit-reversed inside every byte.  Positions that are hits store their dword, the others are dropped.
-// Input and output are those of k3_slice (positions in the staging slots, ascending; packed result).
+// Input: positions in the staging slots, ascending; output: the packed result (K3Args).
 // (Tried and dropped: one workgroup per tile that first stages the tile's 64 rows in LDS -- LDS-DMA, rows XOR-swizzled
 // against bank conflicts -- and takes the windows from there: 64 vs 54 us of search per 1 GiB with scm, 1.05 vs 0.67 ms
 // per 4 GiB with four preambles.  The preambles of a tile run one after the other, half as many workgroups fit a CU,
@@ -686,7 +618,11 @@ __global__ __launch_bounds__(256) void k3_slice_words(const K3Args a)
     const uint32_t T = blockIdx.x, q = blockIdx.y;
     __shared__ uint64_t red[2][4];
     __shared__ uint32_t tab[4][kK3Batch][32];   // per wave and entry: staging index of the hit at bit b of the word, or ~0
-    // slot of this (tile, preamble) list and the grand total, as in k3_slice; all loads go out before the first use
+    // Slot of this (tile, preamble) list in the packed result = the hits of all lists before it (preamble-major), and the
+    // layout needs the grand total.  No scan kernel between K2 and K3 (a dispatch costs the stream ~5 us): K2 left sums
+    // over groups of 64 tiles, so a workgroup adds up the group sums before its group, the <= 63 counts before it inside
+    // the group, and all group sums for the total -- one load per lane, all in flight before the first use.  The
+    // workgroups of tile 0 publish the per-preamble bases, (0,0) also the total and K2's overflow word.
     const uint32_t n_groups = k2_groups(a.n_tiles), my_g = q * n_groups + (T >> 6);
     const uint32_t cnt = a.counts[q * a.n_tiles + T];
     uint64_t before = 0, all = 0;
@@ -725,7 +661,7 @@ __global__ __launch_bounds__(256) void k3_slice_words(const K3Args a)
     // symbol offset of this lane inside a 64-symbol step: the 32 lanes of a block take the symbols bit-reversed
     // within every byte, so that bit i of the transposed dword is the symbol Decoder.Slice puts into bit i
     const uint32_t sym_lane = half * 32 + ((l32 & ~7u) | (7u - (l32 & 7u)));
-    const uint32_t bad = 64u << lg_bs;                 // defensive bound for positions, as in k3_slice
+    const uint32_t bad = 64u << lg_bs;                 // defensive: never index the bitstream with a bad position
     auto word_at = [&](uint32_t v) {                   // bitstream word holding bit v (counted from row 0 of tile T)
         const uint32_t row = v >> lg_bs, w = (v & bs_mask) >> 5;
         return tbase[((row >> 6) << lg_tw) + ((w >> 2) << 8) + ((row & 63) << 2) + (w & 3)];

@@ -29,6 +29,9 @@
 #ifndef AMR_K2S_DN
 #define AMR_K2S_DN 12   // taps of the register sweep, several preambles
 #endif
+#ifndef AMR_K2S_DBG
+#define AMR_K2S_DBG 0
+#endif
 #ifndef AMR_K2S_OCC
 #define AMR_K2S_OCC 4   // waves per SIMD the register allocation aims at (launch bound)
 #endif
@@ -182,19 +185,20 @@ __global__ __launch_bounds__(64 * NWV, AMR_K2S_OCC) void k2_search_stream(const 
     constexpr int MAXP = 4;
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
     if ((uint32_t)(uintptr_t)(__attribute__((address_space(3))) void *)lds != 0) __builtin_trap();   // the M0 values below
+#if AMR_K2S_DBG   // harness builds: per-workgroup phase stamps (shader clock) and 100 MHz start / end ticks
 #define K2S_STAMP(i) do { if (a.dbg && threadIdx.x == 0) a.dbg[(size_t)blockIdx.x * 16 + (i)] = __builtin_readcyclecounter(); } while (0)
-    // a.xcd: workgroup b runs on XCD b % 8; give every XCD one contiguous run of tiles (the grid is rounded up to 8 runs)
-    const uint32_t T = a.xcd ? (blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3) : blockIdx.x;
+#else
+#define K2S_STAMP(i) do { } while (0)
+#endif
+    // workgroup b runs on XCD b % 8: every XCD gets one contiguous run of tiles (the grid is rounded up to 8 equal runs;
+    // -5 us: the prologue of a later round finds the next tile's row 0 in its own L2)
+    const uint32_t T = (blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3);
     k2_announce(a);
-    if (T >= a.n_tiles) {
-        if (a.do_hist && T == a.n_tiles) {     // the state update of the batch, next to the search instead of behind it
-            hist_body(a.hist, lds, 64 * NWV);
-            if (threadIdx.x == 0) hist_publish(a.hist);   // no tickets here (the search is still running): only the wait
-        }
-        return;
-    }
+    if (k2_extra_workgroup(a, T, lds, 64 * NWV)) return;   // the state update of the batch, next to the search
     K2S_STAMP(0);
+#if AMR_K2S_DBG
     if (a.dbg && threadIdx.x == 0) a.dbg[(size_t)blockIdx.x * 16 + 8] = __builtin_amdgcn_s_memrealtime();
+#endif
     const uint32_t tid = threadIdx.x, lane = tid & 63;
     const uint32_t v = __builtin_amdgcn_readfirstlane(tid >> 6);
     const uint32_t wpb = a.g.wpb, lg_wpb = a.g.lg_wpb, wpb_mask = wpb - 1;
@@ -352,10 +356,12 @@ __global__ __launch_bounds__(64 * NWV, AMR_K2S_OCC) void k2_search_stream(const 
             if (q == (uint32_t)qq) run[qq] += add;
     }
     K2S_STAMP(6);
+#if AMR_K2S_DBG
     if (a.dbg && tid == 0) {
         a.dbg[(size_t)blockIdx.x * 16 + 7] = ((unsigned long long)n_cand << 32) | n_keep;
         a.dbg[(size_t)blockIdx.x * 16 + 9] = __builtin_amdgcn_s_memrealtime();
     }
+#endif
 
     if (tid == 0) {
 #pragma unroll

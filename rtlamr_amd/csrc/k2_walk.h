@@ -1,0 +1,325 @@
+// K2 (third generation) -- the preamble search of Decoder.Search (protocol/decode.go:255-328: every idx with
+// Quantized[idx + p*SymbolLength] == preamble[p] for all p, ascending), as a STREAM WALK: one wave = one tile of 64 rows,
+// lane = row = one reference block, every lane walks ITS row from the first word to the last, straight out of global
+// memory into a register ring.
+//
+// Why.  The second generation (k2_stream.h) staged a tile in LDS, split a row's words over 2 / 4 / 8 waves and met three
+// barriers per tile; with rows of 256 words (BlockSize 8192: idm, "all") a workgroup held 79 KB of LDS, two fitted a CU, and
+// the kernel took 0.22 ms (one preamble) to 0.54 ms (four) per 4 GiB of IQ for ~30 us of VALU work and 256 MiB of
+// reads -- a chain of exposed latencies.  Here nothing is staged and nothing is shared:
+//   * the "tiled4" bitstream puts words 4c..4c+3 of all 64 rows into one contiguous KiB, so chunk c of the wave's 64
+//     rows is ONE coalesced global_load_dwordx4 (16 bytes per lane) -- no LDS round trip, no transpose;
+//   * a lane keeps the words its first D taps can reach in a register ring of RC chunks, refilled PF chunks ahead of
+//     their use (ordinary loads: the compiler counts the vmcnt);
+//   * the stream of a row continues in the next row: past the row end a lane's loads simply go on at row l+1 (lane 63:
+//     row 0 of the next tile) -- the look-ahead is re-read (LOOK words per row), not exchanged;
+//   * all preambles share the window words (one SymbolLength), so the taps are outermost and the preambles innermost:
+//     per word and tap one v_alignbit (odd multiples of 16 bits only) and ONE v_bitop3 per preamble (M & (W ^ inv), the
+//     preamble bit as a scalar 0 / ~0);
+//   * D = 16 taps run on every position: 2^-16 of them survive in noise (8 per preamble and wave at BlockSize 8192), so
+//     the remaining taps of the longer preambles (scm 21, idm / netidm / r900 32) are rare enough to fetch their words
+//     from memory one candidate per lane;
+//   * a wave owns its tile alone: hit counts per row, the exclusive scan over the rows (DPP) and the ordered emission into
+//     the staging slot need no barrier.  Four waves (four consecutive tiles) make a workgroup only so that the folded
+//     state update (K2Args::do_hist) has 256 threads.
+// Output (counts, group sums, staging slots, overflow protocol) is that of the other search kernels: K3 and the host see
+// no difference.  Used when every preamble has at least 16 symbols (all of rtlamr's: scm+ 16, scm 21, idm / netidm /
+// r900 32), there are at most four of them and a row has 16..256 words; otherwise k2_search_fast / k2_search_dense run.
+#pragma once
+#include "k2_search.h"
+
+#ifndef AMR_K2W_DBG
+#define AMR_K2W_DBG 0     // harness builds: phase stamps per wave in K2Args::dbg
+#endif
+
+namespace amr {
+
+constexpr int kK2WTaps = 16;              // taps applied to every position
+constexpr int kK2WList = 192;             // (key, mask) entries per wave
+constexpr int kK2WWaves = 4;              // waves (tiles) per workgroup
+
+template <int SL, int PF>
+struct K2WGeom {
+    static constexpr int D = kK2WTaps;
+    static constexpr int LOOK = ((D - 1) * SL + 31) / 32;           // words beyond w that the taps of word w reach
+    static constexpr int NEED = (3 + LOOK) / 4 + 1;                 // chunks (4 words) a group of 4 words needs
+    static constexpr int RC = NEED + PF;                            // ring size in chunks
+    static constexpr int RW = RC * 4;                               // ring size in words
+};
+
+// prefetch depth by window length: a group of a short-symbol geometry is little work, its loads need more lead
+template <int SL, int NPRE> struct K2WPf { static constexpr int value = NPRE >= 3 ? 3 : NPRE == 2 ? 4 : 6; };
+
+inline size_t k2_walk_lds_bytes(uint32_t hist_words)
+{
+    const size_t per_wave = (size_t)kK2WList * 2 + 2 * 4 * 64;      // list + counts + bases (four preambles)
+    const size_t need = per_wave * kK2WWaves;
+    return (need > hist_words ? need : hist_words) * 4;
+}
+
+typedef uint32_t k2w_v4u __attribute__((ext_vector_type(4)));
+
+template <int RC>
+struct K2WRing { k2w_v4u c[RC]; };
+
+struct K2WCtx {
+    const uint8_t *tile;      // wave-uniform: chunk 0 of row 0 of the wave's tile
+    uint32_t voff_own;        // byte offset of this lane's row inside a chunk: lane * 16
+    uint32_t voff_next;       // ... of the row behind it: (lane + 1) * 16, lane 63: row 0 of the next tile (a whole tile on)
+    uint32_t cpr;             // chunks per row
+};
+
+// chunk k of the lane's stream (k counts from the row start and runs past the row end into the next row).  k is
+// wave-uniform, so the address is a scalar base (tile + chunk) plus one of two per-lane offsets: no 64-bit lane arithmetic.
+template <int RC>
+__device__ __forceinline__ void k2w_load(K2WRing<RC> &R, const K2WCtx &cx, int slot, uint32_t k)
+{
+    const bool in_row = k < cx.cpr;                                               // wave-uniform
+    const uint8_t *base = cx.tile + (size_t)(in_row ? k : k - cx.cpr) * 1024;     // wave-uniform
+    R.c[slot] = *reinterpret_cast<const k2w_v4u *>(base + (in_row ? cx.voff_own : cx.voff_next));
+}
+
+// one group of four words (ring slot GG of the current ring turn), all taps, all preambles; then the group's chunk is
+// dead and its slot takes the chunk RC further on.  Template recursion: every ring index has to be a constant.
+template <int SL, int NPRE, int PF, int GG>
+__device__ __forceinline__ void k2w_groups(K2WRing<K2WGeom<SL, PF>::RC> &R, const K2WCtx &cx, uint32_t g0, uint32_t n_groups,
+                                           uint32_t n_chunks, const uint32_t (&inv)[NPRE][kK2WTaps], uint32_t w_lo, uint32_t w_hi,
+                                           uint32_t lane, uint32_t *mylist, uint32_t &list_n)
+{
+    using G = K2WGeom<SL, PF>;
+    if constexpr (GG < G::RC) {
+        const uint32_t g = g0 + GG;
+        if (g >= n_groups) return;                                  // wave-uniform
+        uint32_t M[NPRE][4];
+#pragma unroll
+        for (int q = 0; q < NPRE; ++q)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) M[q][j] = 0xffffffffu;
+#pragma unroll
+        for (int p = 0; p < G::D; ++p) {
+            const int x = (p * SL) >> 5;
+            const bool half = ((p * SL) & 31) != 0;                 // SL is a multiple of 16: the shift is 0 or 16
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int i0 = (GG * 4 + j + x) % G::RW, i1 = (i0 + 1) % G::RW;
+                const uint32_t W = half ? __builtin_amdgcn_alignbit(R.c[i0 >> 2][i0 & 3], R.c[i1 >> 2][i1 & 3], 16) : R.c[i0 >> 2][i0 & 3];
+#pragma unroll
+                for (int q = 0; q < NPRE; ++q) M[q][j] = __builtin_amdgcn_bitop3_b32(M[q][j], W, inv[q][p], 0x60);   // M & (W ^ inv)
+            }
+        }
+        uint32_t any = 0;
+#pragma unroll
+        for (int q = 0; q < NPRE; ++q) any |= M[q][0] | M[q][1] | M[q][2] | M[q][3];
+        if (__ballot(any != 0)) {                                   // rare: record the non-zero masks of valid words
+#pragma unroll
+            for (int q = 0; q < NPRE; ++q) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const uint32_t w = g * 4 + j;
+                    const uint32_t m = (w >= w_lo && w < w_hi) ? M[q][j] : 0u;
+                    const uint64_t b = __ballot(m != 0);
+                    if (b) {
+                        const uint32_t idx = list_n + __builtin_amdgcn_mbcnt_hi((uint32_t)(b >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)b, 0));
+                        if (m != 0 && idx < (uint32_t)kK2WList) {
+                            mylist[idx * 2] = ((uint32_t)q << 16) | (lane << 8) | w;
+                            mylist[idx * 2 + 1] = m;
+                        }
+                        list_n += __popcll(b);
+                    }
+                }
+            }
+        }
+        if (g + G::RC < n_chunks) k2w_load<G::RC>(R, cx, GG, g + G::RC);
+        k2w_groups<SL, NPRE, PF, GG + 1>(R, cx, g0, n_groups, n_chunks, inv, w_lo, w_hi, lane, mylist, list_n);
+    }
+}
+
+template <int RC, int K>
+__device__ __forceinline__ void k2w_fill(K2WRing<RC> &R, const K2WCtx &cx, uint32_t n_chunks)
+{
+    if constexpr (K < RC) {
+        if ((uint32_t)K < n_chunks) k2w_load<RC>(R, cx, K, K);
+        else R.c[K] = k2w_v4u{0, 0, 0, 0};
+        k2w_fill<RC, K + 1>(R, cx, n_chunks);
+    }
+}
+
+// inclusive prefix sum over the 64 lanes of a wave: four row_shr steps inside the rows of 16, then the two row broadcasts
+__device__ __forceinline__ uint32_t k2w_wave_scan(uint32_t x)
+{
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x111, 0xf, 0xf, true);    // row_shr:1
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x112, 0xf, 0xf, true);    // row_shr:2
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x114, 0xf, 0xf, true);    // row_shr:4
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x118, 0xf, 0xf, true);    // row_shr:8
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x142, 0xa, 0xf, false);   // row_bcast:15 into rows 1 and 3
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x143, 0xc, 0xf, false);   // row_bcast:31 into rows 2 and 3
+    return x;
+}
+
+template <int SL, int NPRE>
+__global__ __launch_bounds__(64 * kK2WWaves) void k2_search_walk(const K2Args a)
+{
+    constexpr int PF = K2WPf<SL, NPRE>::value;
+    using G = K2WGeom<SL, PF>;
+    extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
+#if AMR_K2W_DBG
+#define K2W_STAMP(i) do { if (a.dbg && lane == 0) a.dbg[(size_t)T * 16 + (i)] = __builtin_readcyclecounter(); } while (0)
+#else
+#define K2W_STAMP(i) do { } while (0)
+#endif
+    // workgroup b runs on XCD b % 8: every XCD gets one contiguous run of tiles (the grid is rounded up to 8 equal runs)
+    const uint32_t wgT = (blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3);
+    const uint32_t n_wg = (a.n_tiles + kK2WWaves - 1) / kK2WWaves;      // workgroups that search
+    k2_announce(a);
+    if (wgT >= n_wg) {
+        (void)k2_extra_workgroup(a, a.n_tiles + (wgT - n_wg), lds, 64 * kK2WWaves);   // state update / deferred-block copies
+        return;
+    }
+    const uint32_t tid = threadIdx.x, lane = tid & 63;
+    const uint32_t v = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const uint32_t T = wgT * kK2WWaves + v;
+    if (T >= a.n_tiles) return;                                      // the last workgroup may hold fewer tiles (no barrier below)
+#if AMR_K2W_DBG
+    if (a.dbg && lane == 0) a.dbg[(size_t)T * 16 + 8] = __builtin_amdgcn_s_memrealtime();
+#endif
+    K2W_STAMP(0);
+    const uint32_t wpb = a.g.wpb, lg_wpb = a.g.lg_wpb;
+    const uint32_t lg_bs = a.g.lg_block_size;
+    const uint32_t tile_words = 64u << lg_wpb;
+    const uint32_t cpr = wpb >> 2;                                   // chunks per row
+    uint32_t *mylist = lds + v * (kK2WList * 2 + 2 * 4 * 64);        // [kK2WList][2]
+    uint32_t *cnts = mylist + kK2WList * 2;                          // [4][64] hits per (preamble, row)
+    uint32_t *bases = cnts + 4 * 64;                                 // [4][64]
+#pragma unroll
+    for (int q = 0; q < 4; ++q) cnts[q * 64 + lane] = 0;
+
+    // ---- preamble bits as scalars: inv[q][p] = ~0 where preamble q has a 0 at tap p (and at taps it does not have) ----
+    uint32_t inv[NPRE][kK2WTaps];
+    uint64_t pbits[NPRE];
+    uint32_t plen[NPRE];
+#pragma unroll
+    for (int q = 0; q < NPRE; ++q) {
+        pbits[q] = a.g.pre_bits[q];
+        plen[q] = a.g.pre_len[q];
+#pragma unroll
+        for (int p = 0; p < kK2WTaps; ++p) inv[q][p] = ((pbits[q] >> p) & 1) ? 0u : 0xffffffffu;
+    }
+
+    // ---- valid word range of this lane's row: n_lo <= R*BS + 32w < n_hi ----
+    const int64_t rowbase = ((int64_t)T * 64 + lane - 64) << lg_bs;
+    int64_t lo64 = (a.n_lo - rowbase) >> 5, hi64 = (a.n_hi - rowbase) >> 5;
+    const uint32_t w_lo = (uint32_t)(lo64 < 0 ? 0 : lo64 > (int64_t)wpb ? wpb : lo64);
+    const uint32_t w_hi = (uint32_t)(hi64 < 0 ? 0 : hi64 > (int64_t)wpb ? wpb : hi64);
+
+    // ---- stage 1: the walk ----
+    const uint8_t *tile = reinterpret_cast<const uint8_t *>(a.qt + (size_t)T * tile_words);
+    K2WCtx cx;
+    cx.cpr = cpr;
+    cx.tile = tile;
+    cx.voff_own = lane * 16;
+    cx.voff_next = lane == 63 ? tile_words * 4 : (lane + 1) * 16;
+    const uint32_t n_chunks = cpr + G::NEED - 1;                     // chunks of the stream the walk touches
+    K2WRing<G::RC> R;
+    k2w_fill<G::RC, 0>(R, cx, n_chunks);
+    uint32_t list_n = 0;                                             // wave-uniform
+    for (uint32_t g0 = 0; g0 < cpr; g0 += G::RC)
+        k2w_groups<SL, NPRE, PF, 0>(R, cx, g0, cpr, n_chunks, inv, w_lo, w_hi, lane, mylist, list_n);
+    K2W_STAMP(1);
+
+    // ---- stage 2: the taps behind the first 16 on the list entries (one per lane), words from memory; compaction in place ----
+    const uint32_t maxL = a.g.max_pre_len;
+    const uint32_t n_cand = list_n < (uint32_t)kK2WList ? list_n : (uint32_t)kK2WList;
+    uint32_t n_keep = 0;                                             // wave-uniform
+    const uint32_t *tw = a.qt + (size_t)T * tile_words;
+    for (uint32_t e0 = 0; e0 < n_cand; e0 += 64) {
+        const uint32_t e = e0 + lane;
+        uint32_t key = 0, m = 0;
+        if (e < n_cand) { key = mylist[e * 2]; m = mylist[e * 2 + 1]; }
+        const uint32_t q = key >> 16, l = (key >> 8) & 63, w = key & 0xff;
+        uint64_t pb = pbits[0];
+        uint32_t pl = plen[0];
+#pragma unroll
+        for (int qq = 1; qq < NPRE; ++qq)
+            if (q == (uint32_t)qq) { pb = pbits[qq]; pl = plen[qq]; }
+        for (uint32_t p = kK2WTaps; p < maxL; p += 4) {              // four taps per round: their eight loads are in flight together
+            if (!__any(m != 0)) break;
+            uint32_t Wd[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const uint32_t pk = p + k < maxL ? p + k : maxL - 1;
+                const uint32_t o = pk * SL;
+                const uint32_t x = w + (o >> 5);
+                // word x of the stream that starts with row l of this tile: tiled row l + x / wpb (may be row 0 of the next tile)
+                const uint32_t A = tw[qt_index(l + (x >> lg_wpb), x & (wpb - 1), lg_wpb)];
+                const uint32_t B = tw[qt_index(l + ((x + 1) >> lg_wpb), (x + 1) & (wpb - 1), lg_wpb)];
+                Wd[k] = (o & 31) ? __builtin_amdgcn_alignbit(A, B, 16) : A;
+            }
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+                if (p + k < pl) m &= ((pb >> (p + k)) & 1) ? Wd[k] : ~Wd[k];
+        }
+        const uint64_t b = __ballot(m != 0);
+        if (m != 0) {   // survivors move to the front, order preserved (slot <= e, earlier entries already read)
+            const uint32_t slot = n_keep + __builtin_amdgcn_mbcnt_hi((uint32_t)(b >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)b, 0));
+            mylist[slot * 2] = key;
+            mylist[slot * 2 + 1] = m;
+            atomicAdd(&cnts[q * 64 + l], (uint32_t)__popc(m));
+        }
+        n_keep += __popcll(b);
+    }
+    K2W_STAMP(2);
+
+    // ---- ranks: exclusive scan over the rows in stream order (row-major: all of row l before row l+1) ----
+    uint32_t total[NPRE];
+#pragma unroll
+    for (int q = 0; q < NPRE; ++q) {
+        const uint32_t val = cnts[q * 64 + lane];
+        const uint32_t inc = k2w_wave_scan(val);
+        total[q] = __builtin_amdgcn_readlane(inc, 63);
+        bases[q * 64 + lane] = inc - val;
+    }
+
+    // ---- emit: every surviving entry by 32 lanes at once, lane b = bit b (MSB first = stream order).  The list is in
+    // walk order: word-major across the rows, ascending words inside a row -- which is all the ranks need ----
+    uint32_t run[NPRE];
+#pragma unroll
+    for (int q = 0; q < NPRE; ++q) run[q] = 0;
+    for (uint32_t e = 0; e < n_keep; ++e) {
+        const uint32_t key = __builtin_amdgcn_readfirstlane(mylist[e * 2]);
+        const uint32_t m = __builtin_amdgcn_readfirstlane(mylist[e * 2 + 1]);
+        const uint32_t q = key >> 16, l = (key >> 8) & 63, w = key & 0xff;
+        uint32_t r = 0;
+#pragma unroll
+        for (int qq = 0; qq < NPRE; ++qq)
+            if (q == (uint32_t)qq) r = __builtin_amdgcn_readlane(run[qq], l);
+        const uint32_t base = bases[q * 64 + l] + r;
+        if (lane < 32 && ((m >> (31 - lane)) & 1)) {
+            const uint32_t before = lane ? __popc(m >> (32 - lane)) : 0;
+            const uint32_t rank = base + before;
+            if (rank < a.cap) a.staging[((size_t)T * NPRE + q) * a.cap + rank] = (l << lg_bs) + (w << 5) + lane;
+        }
+        const uint32_t add = (lane == l) ? __popc(m) : 0;
+#pragma unroll
+        for (int qq = 0; qq < NPRE; ++qq)
+            if (q == (uint32_t)qq) run[qq] += add;
+    }
+    K2W_STAMP(3);
+#if AMR_K2W_DBG
+    if (a.dbg && lane == 0) {
+        a.dbg[(size_t)T * 16 + 7] = ((unsigned long long)n_cand << 32) | n_keep;
+        a.dbg[(size_t)T * 16 + 9] = __builtin_amdgcn_s_memrealtime();
+    }
+#endif
+    if (lane == 0) {
+#pragma unroll
+        for (int q = 0; q < NPRE; ++q) {
+            const uint32_t c = total[q] < a.cap ? total[q] : a.cap;
+            a.counts[q * a.n_tiles + T] = c;
+            if (c) atomicAdd(&a.gcnt[q * k2_groups(a.n_tiles) + (T >> 6)], c);
+            if (total[q] > a.cap) atomicOr(a.overflow, 1u);
+        }
+        if (list_n > (uint32_t)kK2WList) atomicOr(a.overflow, 2u);
+    }
+}
+
+}  // namespace amr

@@ -6,8 +6,9 @@ process per GPU).  Blocks are independent except for the history a Decoder carri
 search.  A rank rebuilds that history by first running ("priming") the few blocks that precede its
 range through the demodulator without reporting hits, so every call index is reported by exactly
 one rank and the union of the ranks' hit lists equals the single-decoder result.  There is no
-data-path collective; the only exchange is the gather of the (tiny) hit lists, done with
-torch.distributed (backend "nccl" = RCCL over xGMI on the GPU box, "gloo" in the CPU tests).
+data-path collective; the only exchange is the gather of the (tiny) hit lists: behind the C ABI
+over RCCL on the GPU box (CommGatherer), and -- the same slot layout, packed and unpacked by the same
+C functions -- over torch.distributed "gloo" in the CPU tests (HitGatherer).
 """
 from __future__ import annotations
 
@@ -69,93 +70,67 @@ def batch_hits_array(br, n_preambles: int) -> np.ndarray:
     return np.concatenate(rows) if rows else np.zeros((0, 3), np.int64)
 
 
-class _DevBuf:
-    """Zero-copy torch view of raw device memory (the packed result buffer of libamrdemod)."""
+def _result_struct(br, n_preambles: int):
+    """A host-side amr_result over the arrays of a BatchResult (what amr_gather_pack_host reads); keeps them alive."""
+    import ctypes as C
+    from . import _lib
+    off = np.ascontiguousarray(br.preamble_offset[: n_preambles + 1], np.uint64)
+    blk = np.ascontiguousarray(br.hit_block, np.uint64)
+    idx = np.ascontiguousarray(br.hit_idx, np.uint32)
+    r = _lib.AmrResult()
+    r.n_preambles, r.n_hits = n_preambles, len(idx)
+    r.preamble_offset = off.ctypes.data_as(C.POINTER(C.c_uint64))
+    r.hit_block = blk.ctypes.data_as(C.POINTER(C.c_uint64))
+    r.hit_idx = idx.ctypes.data_as(C.POINTER(C.c_uint32))
+    return r, (off, blk, idx)
 
-    def __init__(self, ptr: int, nbytes: int):
-        self.__cuda_array_interface__ = {"shape": (nbytes,), "typestr": "|u1", "data": (ptr, False), "version": 2}
+
+def rows_from_gathered(off, blk, idx) -> np.ndarray:
+    """(preamble offsets, call indices, idx) of one rank's slot -> int64[n,3] rows (pid, block, idx).  A truncated slot
+    (fewer records than the offsets span) keeps the records it has."""
+    n = len(blk)
+    pid = np.zeros(n, np.int64)
+    for q in range(len(off) - 1):
+        pid[min(int(off[q]), n):min(int(off[q + 1]), n)] = q
+    return np.stack([pid, blk.astype(np.int64), idx.astype(np.int64)], axis=1)
 
 
 class HitGatherer:
-    """(Fallback path; the production gather is CommGatherer below, behind the C ABI and without the host-side stream
-    synchronisation this one needs to protect the library's result slot.)
+    """The hit gather for hosts WITHOUT RCCL (CPU ranks, gloo): the same slot -- header, call indices, idx, laid out by
+    the C library's amr_gather_pack_host / amr_gather_unpack, the very code the device pack kernel and amr_gather_fetch
+    are built from -- moved by torch.distributed.gather instead of ncclSend/ncclRecv.  Same protocol as CommGatherer:
+    fixed capacity agreed up front, one collective per batch, two buffer sets, a sequence number per gather, a batch
+    with more records than the capacity arrives truncated with its true count."""
 
-    Gather of the per-rank hit records (call index u64, idx u32) on rank 0, once per batch, without a host
-    round trip: the records are copied device-to-device out of the library's packed result buffer into a
-    fixed-capacity send buffer and gathered with ONE collective (torch.distributed.gather, backend "nccl" =
-    RCCL: on the fully connected xGMI fabric every peer sends its few MB to rank 0 over its own link).  The
-    collective is asynchronous; two buffer sets alternate, so the gather of batch i overlaps the kernels of
-    batch i+1.  The capacity is agreed once (all_reduce MAX) and re-agreed only when a rank outgrows it; the
-    record count and the per-preamble offsets travel in a small header in front of the records.
-
-    With device=None (CPU tensors, gloo) the same code path is exercised by the CPU tests: `post` then takes the
-    records from the host result instead of the device buffer."""
-
-    HDR = 16   # int64 words: [n, n_pre, offs[0..n_pre], ...]
-
-    def __init__(self, n_preambles: int, device=None, group=None, slack: float = 1.5):
+    def __init__(self, n_preambles: int, cap_hits: int, root: int = 0, group=None):
         import torch
         import torch.distributed as dist
-        self.torch, self.dist = torch, dist
-        self.dev = device if device is not None else torch.device("cpu")
-        self.group = group
-        self.world = dist.get_world_size(group)
-        self.rank = dist.get_rank(group)
-        self.n_pre = n_preambles
-        self.slack = slack
-        self.cap = 0
-        self.send = [None, None]
-        self.recv = [None, None]
+        from . import _lib
+        self.torch, self.dist, self.L = torch, dist, _lib.lib()
+        self.group, self.root = group, root
+        self.world, self.rank = dist.get_world_size(group), dist.get_rank(group)
+        self.n_pre, self.cap = n_preambles, cap_hits
+        self.slot_bytes = int(self.L.amr_gather_slot_bytes(cap_hits))
+        self.send = [torch.zeros(self.slot_bytes, dtype=torch.uint8) for _ in range(2)]
+        self.recv = [[torch.zeros(self.slot_bytes, dtype=torch.uint8) for _ in range(self.world)]
+                     if self.rank == root else None for _ in range(2)]
         self.work = [None, None]
-        self.i = 0
+        self.seq_of = [None, None]
+        self.next_seq = 0
 
-    def _nbytes(self, cap):
-        return self.HDR * 8 + cap * 12
-
-    def negotiate(self, n_local: int) -> None:
-        """Collective: agree on a capacity that holds every rank's hit count (with slack)."""
-        t = self.torch.tensor([n_local], dtype=self.torch.int64, device=self.dev)
-        self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX, group=self.group)
-        cap = max(1024, int(int(t.item()) * self.slack))
-        if cap > self.cap:
-            self.wait()
-            self.cap = cap
-            nb = self._nbytes(cap)
-            self.send = [self.torch.zeros(nb, dtype=self.torch.uint8, device=self.dev) for _ in range(2)]
-            self.recv = [[self.torch.zeros(nb, dtype=self.torch.uint8, device=self.dev) for _ in range(self.world)]
-                         if self.rank == 0 else None for _ in range(2)]
-
-    def post(self, br, d_ptr: int = 0) -> bool:
-        """Enqueue the gather of one batch -- always, so that every rank issues the same collectives in the same
-        order.  A batch that does not fit the agreed capacity is sent truncated with its true count in the header
-        (result() then refuses it); returns False in that case: at the next point where all ranks synchronise
-        anyway the caller runs negotiate() and posts the batch again."""
-        torch = self.torch
-        n_true = len(br.hit_idx)
-        n = min(n_true, self.cap)
-        i = self.i
-        if self.work[i] is not None:
-            self.work[i].wait()
-        buf = self.send[i]
-        hdr = np.zeros(self.HDR, np.int64)
-        hdr[0], hdr[1] = n_true, self.n_pre
-        hdr[2:3 + self.n_pre] = br.preamble_offset[: self.n_pre + 1]
-        buf[: self.HDR * 8].copy_(torch.from_numpy(hdr.view(np.uint8)), non_blocking=True)
-        if n:
-            if d_ptr and self.dev.type == "cuda":
-                # packed result = [block u64 x n_true | idx u32 x n_true | ...]: two pieces when truncated
-                src = torch.as_tensor(_DevBuf(d_ptr, 12 * n_true), device=self.dev)
-                buf[self.HDR * 8: self.HDR * 8 + 8 * n].copy_(src[: 8 * n], non_blocking=True)
-                buf[self.HDR * 8 + 8 * n: self.HDR * 8 + 12 * n].copy_(src[8 * n_true: 8 * n_true + 4 * n], non_blocking=True)
-                torch.cuda.current_stream(self.dev).synchronize()                   # before the library reuses the slot
-            else:
-                rec = np.concatenate([np.ascontiguousarray(br.hit_block[:n], np.uint64).view(np.uint8),
-                                      np.ascontiguousarray(br.hit_idx[:n], np.uint32).view(np.uint8)])
-                buf[self.HDR * 8: self.HDR * 8 + 12 * n].copy_(torch.from_numpy(rec))
-        self.work[i] = self.dist.gather(buf, self.recv[i], dst=0, group=self.group, async_op=True)
-        self.last = i
-        self.i ^= 1
-        return n_true <= self.cap
+    def post(self, br) -> int:
+        """Enqueue the gather of one batch result; returns its sequence number."""
+        from . import _lib
+        seq = self.next_seq
+        self.next_seq += 1
+        k = seq & 1
+        if self.work[k] is not None:
+            self.work[k].wait()
+        r, keep = _result_struct(br, self.n_pre)
+        _lib.check(self.L.amr_gather_pack_host(r, self.cap, seq, self.send[k].data_ptr(), self.slot_bytes), "amr_gather_pack_host")
+        self.work[k] = self.dist.gather(self.send[k], self.recv[k], dst=self.root, group=self.group, async_op=True)
+        self.seq_of[k] = seq
+        return seq
 
     def wait(self) -> None:
         for k in range(2):
@@ -163,25 +138,35 @@ class HitGatherer:
                 self.work[k].wait()
                 self.work[k] = None
 
-    def result(self) -> np.ndarray:
-        """Rank 0: the records of the batch posted last, all ranks, as int64[n,3] rows (pid, block, idx)."""
-        self.wait()
-        if self.rank != 0:
+    def fetch(self, seq: int, src_rank: int):
+        """Root: (n_true, offsets, call indices, idx) of rank src_rank in gather `seq`."""
+        import ctypes as C
+        from . import _lib
+        from .protocol import unpack_gathered
+        k = seq & 1
+        if self.seq_of[k] != seq:
+            raise KeyError(f"gather {seq} was never posted or has been overwritten")
+        if self.work[k] is not None:
+            self.work[k].wait()
+            self.work[k] = None
+        g = _lib.AmrGathered()
+        _lib.check(self.L.amr_gather_unpack(self.recv[k][src_rank].data_ptr(), self.slot_bytes, C.byref(g)), "amr_gather_unpack")
+        if int(g.seq) != seq:
+            raise RuntimeError(f"rank {src_rank}'s slot carries gather {int(g.seq)}, expected {seq}")
+        return unpack_gathered(g)
+
+    def result(self, seq: int = None) -> np.ndarray:
+        """Root: the records of gather `seq` (default: the last), all ranks in rank order, int64[n,3] (pid, block, idx)."""
+        seq = self.next_seq - 1 if seq is None else seq
+        if self.rank != self.root:
+            self.wait()
             return np.zeros((0, 3), np.int64)
         rows = []
-        for t in self.recv[self.last]:
-            raw = t.cpu().numpy()
-            hdr = raw[: self.HDR * 8].view(np.int64)
-            n, n_pre = int(hdr[0]), int(hdr[1])
-            if n > self.cap:
-                raise OverflowError(f"a rank sent {n} hit records, agreed capacity is {self.cap}: negotiate() and post again")
-            offs = hdr[2:3 + n_pre]
-            blk = raw[self.HDR * 8: self.HDR * 8 + 8 * n].view(np.uint64).astype(np.int64)
-            idx = raw[self.HDR * 8 + 8 * n: self.HDR * 8 + 12 * n].view(np.uint32).astype(np.int64)
-            pid = np.zeros(n, np.int64)
-            for q in range(n_pre):
-                pid[offs[q]:offs[q + 1]] = q
-            rows.append(np.stack([pid, blk, idx], axis=1))
+        for r in range(self.world):
+            n_true, off, blk, idx = self.fetch(seq, r)
+            if n_true > len(blk):
+                raise OverflowError(f"rank {r} had {n_true} hit records, the gather capacity is {self.cap}")
+            rows.append(rows_from_gathered(off, blk, idx))
         return np.concatenate(rows) if rows else np.zeros((0, 3), np.int64)
 
 
@@ -195,13 +180,12 @@ def comm_unique_id() -> bytes:
 
 
 class CommGatherer:
-    """The hit gather of the C ABI (amr_comm_init / amr_gather_hits: RCCL point-to-point on a stream of the
-    library's own, no host synchronisation), for hosts that are Python.  The unique id travels over whatever the
-    caller has -- here torch.distributed (any backend), because bench.py and the tests have it anyway; a cgo host
-    would use its own transport."""
+    """The hit gather of the C ABI (amr_comm_init / amr_gather_hits / amr_gather_fetch: RCCL point-to-point on a stream
+    of the library's own, the root's records mirrored into pinned host memory, no host synchronisation), for hosts that
+    are Python.  The unique id travels over whatever the caller has -- here torch.distributed (any backend), because
+    bench.py and the tests have it anyway; a cgo host would use its own transport."""
 
     def __init__(self, dec, cap_hits: int, root: int = 0, group=None):
-        import torch
         import torch.distributed as dist
         self.dec, self.root = dec, root
         self.world, self.rank = dist.get_world_size(group), dist.get_rank(group)
@@ -209,26 +193,29 @@ class CommGatherer:
         dist.broadcast_object_list(box, src=root, group=group)
         dec.comm_init(box[0], self.rank, self.world, root, cap_hits)
         self.cap = cap_hits
+        self.slot_bytes = int(dec.gather_slot_bytes(cap_hits))
+        self.last_seq = -1
 
-    def post(self) -> None:
-        self.dec.gather_hits()
+    def post(self) -> int:
+        """Enqueue the gather of the batch collected last; returns its sequence number at once."""
+        self.last_seq = self.dec.gather_hits()
+        return self.last_seq
 
     def wait(self) -> None:
         self.dec.gather_wait()
 
-    def result(self):
-        """Root: int64[n,3] rows (pid, block, idx) of the last gather, all ranks in rank order."""
-        import numpy as np
-        self.wait()
+    def fetch(self, seq: int, src_rank: int, copy: bool = True):
+        return self.dec.gather_fetch(src_rank, seq, copy)
+
+    def result(self, seq: int = None) -> np.ndarray:
+        """Root: int64[n,3] rows (pid, block, idx) of gather `seq` (default: the last), all ranks in rank order."""
+        seq = self.last_seq if seq is None else seq
         if self.rank != self.root:
             return np.zeros((0, 3), np.int64)
         rows = []
         for r in range(self.world):
-            n_true, off, blk, idx = self.dec.gather_fetch(r)
+            n_true, off, blk, idx = self.fetch(seq, r)
             if n_true > len(blk):
                 raise OverflowError(f"rank {r} had {n_true} hit records, the gather capacity is {self.cap}")
-            pid = np.zeros(len(blk), np.int64)
-            for q in range(len(off) - 1):
-                pid[int(off[q]):int(off[q + 1])] = q
-            rows.append(np.stack([pid, blk.astype(np.int64), idx.astype(np.int64)], axis=1))
+            rows.append(rows_from_gathered(off, blk, idx))
         return np.concatenate(rows) if rows else np.zeros((0, 3), np.int64)

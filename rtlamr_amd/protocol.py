@@ -113,6 +113,17 @@ def next_power_of_2(v: int) -> int:
     return 1 << int(math.ceil(math.log2(float(v))))
 
 
+def unpack_gathered(g: "_lib.AmrGathered", copy: bool = True):
+    """amr_gathered -> (n_true, preamble_offset[n_pre+1], hit_block u64[n], hit_idx u32[n])."""
+    n, n_pre = int(g.n_hits), int(g.n_preambles)
+    off = np.ctypeslib.as_array(g.preamble_offset, shape=(n_pre + 1,))
+    blk = np.ctypeslib.as_array(g.hit_block, shape=(n,)) if n else np.zeros(0, np.uint64)
+    idx = np.ctypeslib.as_array(g.hit_idx, shape=(n,)) if n else np.zeros(0, np.uint32)
+    if copy:
+        off, blk, idx = off.copy(), blk.copy(), idx.copy()
+    return int(g.n_true), off, blk, idx
+
+
 @dataclass
 class BatchResult:
     """Hits of one batch, per preamble id: (block, idx) ascending + packet bytes."""
@@ -147,7 +158,7 @@ class Decoder:
         self._calls = 0
         self._last_blocks = 0
         self._block_base = 0
-        self._inflight: List[tuple] = []   # (n_blocks, first_block) of submitted, uncollected batches
+        self._last_gather = 0
         # The exported buffers of the Go Decoder (decode.go:46-50).  No parser reads Quantized; r900 reads Signal
         # (r900/r900.go:162-170).  Both stay on the GPU unless asked for: with KeepSignal / KeepQuantized set before a
         # decode_batch() call, the buffers hold afterwards what the Go fields hold after the batch's last Decode call
@@ -230,22 +241,34 @@ class Decoder:
         buf = C.create_string_buffer(bytes(unique_id), 128)
         _lib.check(_lib.lib().amr_comm_init(self._require(), buf, rank, world, root, cap_hits), "amr_comm_init")
 
-    def gather_hits(self) -> None:
-        """Enqueue the gather of the batch collected last (every rank, once per batch); returns at once."""
-        _lib.check(_lib.lib().amr_gather_hits(self._require()), "amr_gather_hits")
+    def gather_slot_bytes(self, cap_hits: int) -> int:
+        return int(_lib.lib().amr_gather_slot_bytes(cap_hits))
+
+    def comm_ranks(self) -> int:
+        """Ranks the RCCL communicator spans (ncclCommCount)."""
+        n = C.c_int32()
+        _lib.check(_lib.lib().amr_comm_ranks(self._require(), C.byref(n)), "amr_comm_ranks")
+        return int(n.value)
+
+    def gather_hits(self) -> int:
+        """Enqueue the gather of the batch collected last (every rank, once per batch); returns at once with the
+        gather's sequence number."""
+        seq = C.c_uint64()
+        _lib.check(_lib.lib().amr_gather_hits(self._require(), C.byref(seq)), "amr_gather_hits")
+        self._last_gather = int(seq.value)
+        return self._last_gather
 
     def gather_wait(self) -> None:
         _lib.check(_lib.lib().amr_gather_wait(self._require()), "amr_gather_wait")
 
-    def gather_fetch(self, src_rank: int):
-        """Root: (n_true, preamble_offset[n_pre+1], hit_block u64[n], hit_idx u32[n]) rank src_rank sent last."""
+    def gather_fetch(self, src_rank: int, seq: Optional[int] = None, copy: bool = True):
+        """Root: (n_true, preamble_offset[n_pre+1], hit_block u64[n], hit_idx u32[n]) of rank src_rank in gather `seq`
+        (default: the one posted last).  Waits for that gather's records only; copy=False returns views into the
+        library's pinned mirror (valid until gather seq + 2 is posted)."""
         g = _lib.AmrGathered()
-        _lib.check(_lib.lib().amr_gather_fetch(self._require(), src_rank, C.byref(g)), "amr_gather_fetch")
-        n, n_pre = int(g.n_hits), int(g.n_preambles)
-        off = np.ctypeslib.as_array(g.preamble_offset, shape=(n_pre + 1,)).copy()
-        blk = np.ctypeslib.as_array(g.hit_block, shape=(n,)).copy() if n else np.zeros(0, np.uint64)
-        idx = np.ctypeslib.as_array(g.hit_idx, shape=(n,)).copy() if n else np.zeros(0, np.uint32)
-        return int(g.n_true), off, blk, idx
+        seq = self._last_gather if seq is None else seq
+        _lib.check(_lib.lib().amr_gather_fetch(self._require(), seq, src_rank, C.byref(g)), "amr_gather_fetch")
+        return unpack_gathered(g, copy)
 
     def close(self) -> None:
         if self._handle is not None:
@@ -278,9 +301,12 @@ class Decoder:
             raise RuntimeError("Decoder.Allocate() has not been called")
         return self._handle
 
-    def _collect(self, res: "_lib.AmrResult", n_blocks: int, first_block: int, copy: bool = True) -> BatchResult:
+    def _collect(self, res: "_lib.AmrResult", copy: bool = True) -> BatchResult:
         """copy=False returns views into the library's pinned result buffers (valid until the second
-        submit after this collect) -- for throughput loops that only inspect the result."""
+        submit after this collect) -- for throughput loops that only inspect the result.  The calls a result covers
+        come from the library (amr_result.first_block / n_blocks): with SetDeferral they differ from the batch that
+        was submitted."""
+        n_blocks, first_block = int(res.n_blocks), int(res.first_block)
         self._last_blocks = n_blocks
         n = int(res.n_hits)
         npre = int(res.n_preambles)
@@ -313,9 +339,8 @@ class Decoder:
         n_blocks = iq.size // self.Cfg.BlockSize2
         res = _lib.AmrResult()
         _lib.check(_lib.lib().amr_decode_batch(h, iq.ctypes.data, iq.size, n_blocks, C.byref(res)), "amr_decode_batch")
-        first = self._calls + self._block_base
         self._calls += n_blocks
-        out = self._collect(res, n_blocks, first)
+        out = self._collect(res)
         if self.KeepSignal or self.KeepQuantized:
             self._refill_exports(iq, n_blocks)
         return out
@@ -343,14 +368,25 @@ class Decoder:
         res = _lib.AmrResult()
         _lib.check(_lib.lib().amr_decode_batch_device(h, C.c_void_p(d_ptr), n_blocks, C.byref(res)),
                    "amr_decode_batch_device")
-        first = self._calls + self._block_base
         self._calls += n_blocks
-        return self._collect(res, n_blocks, first)
+        return self._collect(res)
+
+    def SetDeferral(self, on: bool = True) -> None:
+        """Binding-level option (include/amrdemod.h, amr_set_deferral): pipelined submits process a batch up to its
+        last whole 64-block wave-tile and carry the rest into the next submit's launch; the hits of those blocks
+        arrive with the next result (BatchResult.first_block / n_blocks say which calls a result covers) or with
+        flush().  Lets a caller hand over ANY block count per batch at the full rate."""
+        _lib.check(_lib.lib().amr_set_deferral(self._require(), 1 if on else 0), "amr_set_deferral")
+
+    def flush(self, copy: bool = True) -> BatchResult:
+        """Decode what SetDeferral left over at the end of the stream (nothing may be in flight)."""
+        res = _lib.AmrResult()
+        _lib.check(_lib.lib().amr_flush(self._require(), C.byref(res)), "amr_flush")
+        return self._collect(res, copy)
 
     def submit_device(self, d_ptr: int, n_blocks: int) -> None:
         """Pipelined form: enqueue a device-resident batch and return (at most three in flight)."""
         _lib.check(_lib.lib().amr_submit_device(self._require(), C.c_void_p(d_ptr), n_blocks), "amr_submit_device")
-        self._inflight.append((n_blocks, self._calls + self._block_base))
         self._calls += n_blocks
 
     def submit_host(self, iq: np.ndarray) -> None:
@@ -360,7 +396,6 @@ class Decoder:
         iq = np.ascontiguousarray(iq, dtype=np.uint8).reshape(-1)
         n_blocks = iq.size // self.Cfg.BlockSize2
         _lib.check(_lib.lib().amr_submit_host(self._require(), iq.ctypes.data, iq.size, n_blocks), "amr_submit_host")
-        self._inflight.append((n_blocks, self._calls + self._block_base))
         self._keep = getattr(self, "_keep", [])[-1:] + [iq]   # keep the last two inputs alive
         self._calls += n_blocks
 
@@ -368,8 +403,7 @@ class Decoder:
         """Result of the oldest submitted batch."""
         res = _lib.AmrResult()
         _lib.check(_lib.lib().amr_collect(self._require(), C.byref(res)), "amr_collect")
-        n_blocks, first = self._inflight.pop(0)
-        return self._collect(res, n_blocks, first, copy)
+        return self._collect(res, copy)
 
     def result_device(self):
         """(device pointer, n_hits) of the packed result [hit_block u64 x n | hit_idx u32 x n | pkt x n] of the

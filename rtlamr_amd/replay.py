@@ -37,10 +37,19 @@ def replay(dec: ra.Decoder, stream: BinaryIO, batch_blocks: int = 16384, unique:
         k = 0
         eof = False
 
-        def drain_one():
+        # any batch size at the full rate: the blocks behind a batch's last whole 64-block wave-tile ride with the next
+        # batch (amr_set_deferral); the results say which Decode calls they cover, flush() brings in the last blocks
+        try:
+            dec.SetDeferral(True)
+            deferring = True
+        except Exception:           # a decoder with the r900 second stage: batches are decoded as handed over
+            deferring = False
+
+        def drain_one(flush=False):
             nonlocal prev_seen
-            br = dec.collect(copy=False)
-            pending.pop(0)
+            br = dec.flush(copy=False) if flush else dec.collect(copy=False)
+            if not flush:
+                pending.pop(0)
             if not parse:
                 return
             for j, msgs in enumerate(dec.run_parsers(br)):
@@ -73,6 +82,8 @@ def replay(dec: ra.Decoder, stream: BinaryIO, batch_blocks: int = 16384, unique:
                 k += 1
             if pending:
                 yield from drain_one()
+        if deferring:
+            yield from drain_one(flush=True)
     finally:
         # a generator closed early (or a parser that raised) leaves up to two batches in flight whose host-to-device
         # copies still read the pinned buffers: collect them before the buffers go

@@ -102,42 +102,84 @@ def _w_gatherer(rank, world, port, out):
     tdist.init_process_group("gloo", rank=rank, world_size=world)
     from rtlamr_amd import dist
     from rtlamr_amd.protocol import BatchResult
-    g = dist.HitGatherer(2)
-    got = []
-    for step in range(4):   # more steps than buffer sets; growing hit counts force a re-negotiation
-        n0, n1 = 3 + step * (rank + 1) * 700, 2 + step
+    g = dist.HitGatherer(2, cap_hits=2000)
+    got, trunc = [], []
+    for step in range(5):   # more steps than buffer sets, different data every step; the last one overflows rank 1's slot
+        n0, n1 = 3 + step * (rank + 1) * 300, 2 + step
         blk = np.arange(n0 + n1, dtype=np.uint64) + 1000 * rank + step
         idx = (np.arange(n0 + n1, dtype=np.uint32) * 7 + rank) % 4096
         br = BatchResult(8, 0, np.array([0, n0, n0 + n1], np.uint64), blk, idx, np.zeros((n0 + n1, 12), np.uint8))
-        if step == 0:
-            g.negotiate(len(idx))
-        fits = g.post(br)                 # always posts: collectives stay in lockstep
-        import torch
-        t = torch.tensor([1 if fits else 0])
-        tdist.all_reduce(t, op=tdist.ReduceOp.MIN)
-        if int(t.item()) == 0:            # some rank was truncated: everybody re-negotiates and posts again
-            g.negotiate(len(idx))
-            assert g.post(br)
-        res = g.result()
-        if rank == 0:
-            got.append(res)
+        seq = g.post(br)
+        assert seq == step
+        if rank == 1 and step % 2:      # a lagging rank: the root's records must still be the ones of THIS gather
+            import time
+            time.sleep(0.05)
+        if rank == 0 and step >= 1:     # the root consumes one gather behind, like bench.py
+            for r in range(world):
+                n_true, off, b, i = g.fetch(step - 1, r)
+                (trunc if n_true > len(b) else got).append((step - 1, r, n_true, dist.rows_from_gathered(off, b, i)))
     if rank == 0:
-        np.save(os.path.join(out, "hg.npy"), np.concatenate(got))
+        for r in range(world):
+            n_true, off, b, i = g.fetch(4, r)
+            (trunc if n_true > len(b) else got).append((4, r, n_true, dist.rows_from_gathered(off, b, i)))
+        np.save(os.path.join(out, "hg.npy"), np.concatenate([x[3] for x in got]))
+        np.save(os.path.join(out, "trunc.npy"), np.array([(x[0], x[1], x[2], len(x[3])) for x in trunc], np.int64))
+    g.wait()
+    tdist.barrier()
     tdist.destroy_process_group()
 
 
-def test_hit_gatherer_async_fixed_capacity(tmp_path):
-    """rtlamr_amd.dist.HitGatherer on gloo/CPU tensors: header + records of every rank arrive on rank 0, across
-    buffer-set reuse and a capacity re-negotiation."""
+def test_hit_gatherer_drives_the_c_slot_layout(tmp_path):
+    """rtlamr_amd.dist.HitGatherer on gloo: the slot every rank sends is packed by amr_gather_pack_host and read by
+    amr_gather_unpack -- the code the device pack kernel and amr_gather_fetch are built from -- across buffer-set
+    reuse, a lagging rank, different data per gather, and a slot that overflows (truncated, true count kept)."""
     port = 33500 + (os.getpid() % 2000)
     mp.spawn(_w_gatherer, args=(2, port, str(tmp_path)), nprocs=2, join=True)
     got = np.load(os.path.join(str(tmp_path), "hg.npy"))
+    trunc = np.load(os.path.join(str(tmp_path), "trunc.npy"))
     want = []
-    for step in range(4):
+    for step in range(5):
         for rank in range(2):
-            n0, n1 = 3 + step * (rank + 1) * 700, 2 + step
+            n0, n1 = 3 + step * (rank + 1) * 300, 2 + step
+            if n0 + n1 > 2000:
+                assert [step, rank, n0 + n1, 2000] in trunc.tolist()
+                continue
             blk = np.arange(n0 + n1, dtype=np.int64) + 1000 * rank + step
             idx = (np.arange(n0 + n1, dtype=np.int64) * 7 + rank) % 4096
             pid = np.concatenate([np.zeros(n0, np.int64), np.ones(n1, np.int64)])
             want.append(np.stack([pid, blk, idx], axis=1))
+    assert len(trunc) == 1
     assert np.array_equal(got, np.concatenate(want))
+
+
+def test_slot_layout_pack_unpack_on_cpu():
+    """amr_gather_pack_host / amr_gather_unpack / amr_gather_slot_bytes need no device: round trip, truncation, and the
+    argument checks (short slot, inconsistent offsets, corrupt header)."""
+    import ctypes as C
+    from rtlamr_amd import _lib, dist
+    from rtlamr_amd.protocol import BatchResult, unpack_gathered
+    L = _lib.lib()
+    n0, n1, n2 = 5, 0, 9
+    blk = np.arange(n0 + n1 + n2, dtype=np.uint64) * 3 + (1 << 40)
+    idx = np.arange(n0 + n1 + n2, dtype=np.uint32) * 11 % 8192
+    br = BatchResult(4, 0, np.array([0, n0, n0 + n1, n0 + n1 + n2], np.uint64), blk, idx, np.zeros((14, 12), np.uint8))
+    r, keep = dist._result_struct(br, 3)
+    for cap in (64, 14, 6):
+        nb = int(L.amr_gather_slot_bytes(cap))
+        assert nb % 256 == 0 and nb >= 128 + 12 * cap
+        slot = np.zeros(nb, np.uint8)
+        assert L.amr_gather_pack_host(r, cap, 77, slot.ctypes.data, nb) == _lib.AMR_OK
+        g = _lib.AmrGathered()
+        assert L.amr_gather_unpack(slot.ctypes.data, nb, C.byref(g)) == _lib.AMR_OK
+        n_true, off, b, i = unpack_gathered(g)
+        m = min(cap, 14)
+        assert (n_true, int(g.seq), int(g.n_preambles)) == (14, 77, 3)
+        assert off.tolist() == [0, 5, 5, 14] and np.array_equal(b, blk[:m]) and np.array_equal(i, idx[:m])
+    slot = np.zeros(int(L.amr_gather_slot_bytes(64)), np.uint8)
+    assert L.amr_gather_pack_host(r, 64, 0, slot.ctypes.data, 256) == _lib.AMR_EINVAL          # slot too small
+    r.n_hits = 13
+    assert L.amr_gather_pack_host(r, 64, 0, slot.ctypes.data, slot.size) == _lib.AMR_EINVAL    # offsets do not end at n_hits
+    bad = np.zeros(256, np.uint8)
+    bad.view(np.uint64)[:3] = (5, 9, 1)                                                        # n_sent > n_true
+    g = _lib.AmrGathered()
+    assert L.amr_gather_unpack(bad.ctypes.data, 256, C.byref(g)) == _lib.AMR_EINVAL

@@ -20,11 +20,12 @@ def test_gather_world1_returns_the_batch_hits():
     try:
         iq, _ = util.synth_stream(["scm", "idm"], 72, 160, dec.Cfg.BlockSize, seed=21, n_packets=8)
         dec.comm_init(dist.comm_unique_id(), 0, 1, 0, cap_hits=1 << 16)
+        assert dec.comm_ranks() == 1
         for part in (slice(0, 100), slice(100, 160)):             # two gathers: the buffer sets alternate
             bs2 = dec.Cfg.BlockSize2
             br = dec.decode_batch(iq[part.start * bs2: part.stop * bs2])
-            dec.gather_hits()
-            n_true, off, blk, idx = dec.gather_fetch(0)
+            seq = dec.gather_hits()
+            n_true, off, blk, idx = dec.gather_fetch(0, seq)
             assert n_true == len(br.hit_idx) > 0
             assert np.array_equal(off, np.asarray(br.preamble_offset[: dec.n_preambles + 1], np.uint64))
             assert np.array_equal(blk, np.asarray(br.hit_block, np.uint64))
@@ -44,6 +45,8 @@ def test_gather_reports_truncation():
         dec.gather_hits()
         n_true, off, blk, idx = dec.gather_fetch(0)
         assert n_true == len(br.hit_idx) and len(blk) == 50
+        with pytest.raises(Exception):
+            dec.gather_fetch(0, seq=5)                  # never posted
         assert np.array_equal(blk, np.asarray(br.hit_block[:50], np.uint64))
     finally:
         dec.close()
@@ -51,10 +54,12 @@ def test_gather_reports_truncation():
 
 def _rank(rank, world, uid_path, out_path, protos, chip, n_blocks):
     sys.path.insert(0, ROOT)
+    import ctypes as C
     import time
     import rtlamr_amd as ra
-    from rtlamr_amd import dist
+    from rtlamr_amd import _lib, dist
     from tests import util as u
+    L = _lib.lib()
     dec = ra.new_decoder(rank)
     for p in protos:
         dec.RegisterProtocol(ra.new_parser(p, chip))
@@ -73,18 +78,35 @@ def _rank(rank, world, uid_path, out_path, protos, chip, n_blocks):
         lead = iq[p0 * bs2 - dec.halo_bytes(): p0 * bs2] if p0 > 0 else None
         dec.prime(iq[p0 * bs2: k0 * bs2], lead)
     dec.set_block_base(k0)
-    dec.decode_batch(iq[k0 * bs2: k1 * bs2])
-    dec.gather_hits()
-    dec.gather_wait()
+    assert dec.comm_ranks() == world
+    # the shard in three pipelined batches, one gather each; rank 1 lags (the root must still get THIS gather's records,
+    # and nobody's pack kernel may read a result slot that a later batch has overwritten)
+    dec.SetDeferral(True)
+    n = k1 - k0
+    cuts = [0, n // 3 + 5, 2 * n // 3 + 1, n]
+    d = C.c_void_p()
+    _lib.check(L.amr_dev_alloc(rank, n * bs2, C.byref(d)), "alloc")
+    part = np.ascontiguousarray(iq[k0 * bs2: k1 * bs2])
+    _lib.check(L.amr_dev_upload(rank, d, part.ctypes.data, part.size), "upload")
+    rows, seqs = [], []
+    for a, b in zip(cuts[:-1], cuts[1:]):
+        dec.submit_device(d.value + a * bs2, b - a)
+    for j in range(3):
+        dec.collect()
+        seqs.append(dec.gather_hits())
+        if rank == 1:
+            time.sleep(0.02 * (j + 1))
+        if rank == 0 and j >= 1:
+            for r in range(world):
+                rows.append(dist.rows_from_gathered(*dec.gather_fetch(r, seqs[j - 1])[1:]))
+    dec.flush()
+    seqs.append(dec.gather_hits())
     if rank == 0:
-        rows = []
-        for r in range(world):
-            n_true, off, blk, idx = dec.gather_fetch(r)
-            pid = np.zeros(len(blk), np.int64)
-            for q in range(len(off) - 1):
-                pid[int(off[q]):int(off[q + 1])] = q
-            rows.append(np.stack([pid, blk.astype(np.int64), idx.astype(np.int64)], axis=1))
+        for s in seqs[-2:]:
+            for r in range(world):
+                rows.append(dist.rows_from_gathered(*dec.gather_fetch(r, s)[1:]))
         np.save(out_path, np.concatenate(rows))
+    dec.gather_wait()
     dec.close()
 
 
@@ -104,3 +126,49 @@ def test_two_rank_hip_prime_gather_equals_single_decoder(tmp_path):
         dec.close()
     order = np.lexsort((got[:, 2], got[:, 1], got[:, 0]))
     assert len(want) > 0 and np.array_equal(got[order], want)
+
+
+def test_pipelined_gathers_carry_their_own_batch(tmp_path):
+    """World 1, five pipelined batches with DIFFERENT data, one gather each, the root consuming one gather behind (as
+    bench.py does): every gather's records are those of its own batch -- sequence numbers, the two buffer sets, the
+    pinned mirror and the ordering of the pack kernel against slot reuse all in play."""
+    import ctypes as C
+    from rtlamr_amd import _lib, dist
+    L = _lib.lib()
+    dec = util.make_decoder(["scm", "scm+"], 72)
+    d = C.c_void_p()
+    try:
+        sizes = [130, 64, 200, 65, 128]
+        bs2 = dec.Cfg.BlockSize2
+        iq, _ = util.synth_stream(["scm", "scm+"], 72, sum(sizes), dec.Cfg.BlockSize, seed=29, n_packets=14)
+        _lib.check(L.amr_dev_alloc(0, iq.size, C.byref(d)), "alloc")
+        _lib.check(L.amr_dev_upload(0, d, iq.ctypes.data, iq.size), "upload")
+        dec.comm_init(dist.comm_unique_id(), 0, 1, 0, cap_hits=1 << 16)
+        pos, want, got, seqs, inflight = 0, [], [], [], 0
+
+        def finish():
+            br = dec.collect()
+            want.append(dist.batch_hits_array(br, dec.n_preambles))
+            seqs.append(dec.gather_hits())
+            if len(seqs) >= 2:
+                got.append(dist.rows_from_gathered(*dec.gather_fetch(0, seqs[-2])[1:]))
+        for nb in sizes:
+            dec.submit_device(d.value + pos * bs2, nb)
+            pos += nb
+            inflight += 1
+            if inflight == 3:
+                finish()
+                inflight -= 1
+        while inflight:
+            finish()
+            inflight -= 1
+        got.append(dist.rows_from_gathered(*dec.gather_fetch(0, seqs[-1])[1:]))
+        assert seqs == list(range(5)) and sum(len(w) for w in want) > 0
+        for w, g in zip(want, got):
+            assert np.array_equal(w, g)
+        with pytest.raises(Exception):
+            dec.gather_fetch(0, seq=1)                  # overwritten two gathers later
+    finally:
+        if d.value:
+            L.amr_dev_free(0, d)
+        dec.close()

@@ -1,66 +1,50 @@
-"""The first-generation kernels (k1_demod for chip <= 72, k2_search_fast/dense for the stream kernel's geometries, the per-hit k3_slice) stay in
-the library as fallbacks (AMR_K1_IMPL=old, AMR_K2_IMPL=old, AMR_K3_IMPL=old) and as the A side of A/B measurements: keep them exact.
-The switch is read once per process, hence the child processes."""
-import os
-import subprocess
-import sys
+"""One pipeline mode, several search kernels.  The library has no run-time switches between kernel generations any more
+(round 2's AMR_K1_IMPL / AMR_K2_IMPL / AMR_K3_IMPL / AMR_TAIL_MODE / AMR_TAIL_OVERLAP / AMR_HIST_FOLD are gone); which
+kernel runs follows from the geometry alone:
+  K1   k1t_demod (register tile) for chip <= 72, k1_demod for chip 80 / 88 / 96
+  K2   k2_search_stream for rows of 64..256 words with up to four preambles of at least 10 / 12 symbols;
+       k2_search_fast for shorter rows (BlockSize 512: chip 8); k2_search_dense for more than four preambles, rows under
+       16 words, and as the overflow fallback (test hook AMR_DENSE_SEARCH, read at amr_create)
+and the state update rides inside whichever search kernel a pipelined batch uses.  Each combination, three batches in
+flight with ragged sizes, against the oracle."""
+import ctypes as C
 
+import numpy as np
 import pytest
+
+import rtlamr_amd as ra
+from oracle.oracle import OracleDecoder
+from rtlamr_amd import _lib, synth
+from tests import util
 
 pytestmark = pytest.mark.gpu
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-
-CHILD = r"""
-import numpy as np
-from tests import util
-for protos, chip, n_blocks, split in ((["scm"], 72, 200, [3, 64, 133]), (["scm"], 32, 150, [70, 80]),
-                                      (["idm"], 72, 140, [5, 135]), (["scm", "scm+", "idm"], 72, 150, [150])):
-    dec = util.make_decoder(protos, chip)
-    iq, _ = util.synth_stream(protos, chip, n_blocks, dec.Cfg.BlockSize, 77, 8)
-    want = util.oracle_run(protos, chip, iq)
-    got = util.gpu_run(dec, iq, split)
-    util.assert_same(want, got, dec.Cfg.PacketSymbols)
-    assert len(want[2]) > 0
-    dec.close()
-print("fallbacks exact")
-"""
+SIZES = [66, 64, 3, 129, 70, 1, 65]
 
 
-@pytest.mark.parametrize("env", [{"AMR_K1_IMPL": "old"}, {"AMR_K2_IMPL": "old"}, {"AMR_K3_IMPL": "old"},
-                                 {"AMR_K1_IMPL": "old", "AMR_K2_IMPL": "old", "AMR_K3_IMPL": "old"}],
-                         ids=["k1-old", "k2-old", "k3-old", "all-old"])
-def test_first_generation_kernels_stay_exact(env):
-    r = subprocess.run([sys.executable, "-c", CHILD], cwd=ROOT, env={**os.environ, **env}, capture_output=True, text=True,
-                       timeout=600)
-    assert r.returncode == 0 and "fallbacks exact" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
-
-
-PIPE_CHILD = r"""
-import ctypes as C
-import numpy as np
-from tests import util
-from rtlamr_amd import _lib
-L = _lib.lib()
-for protos, chip in ((["scm"], 72), (["scm", "scm+", "idm", "r900"], 72)):
-    dec = util.make_decoder(protos, chip)
+def _pipeline(dec, iq, sizes, depth=3):
+    L = _lib.lib()
     bs2 = dec.Cfg.BlockSize2
-    sizes = [66, 64, 3, 129, 70, 1, 65]
-    iq, _ = util.synth_stream(protos, chip, sum(sizes), dec.Cfg.BlockSize, 91, 10)
-    want = util.oracle_run(protos, chip, iq)
     bufs, got, pos, inflight = [], [], 0, 0
-    for nb in sizes:
-        part = np.ascontiguousarray(iq[pos * bs2:(pos + nb) * bs2])
-        d = C.c_void_p()
-        _lib.check(L.amr_dev_alloc(0, part.size, C.byref(d)), "alloc")
-        _lib.check(L.amr_dev_upload(0, d, part.ctypes.data, part.size), "upload")
-        bufs.append(d)
-        dec.submit_device(d.value, nb)
-        inflight += 1; pos += nb
-        if inflight == 3:
-            got.append(dec.collect()); inflight -= 1
-    while inflight:
-        got.append(dec.collect()); inflight -= 1
+    try:
+        for nb in sizes:
+            part = np.ascontiguousarray(iq[pos * bs2:(pos + nb) * bs2])
+            d = C.c_void_p()
+            _lib.check(L.amr_dev_alloc(0, part.size, C.byref(d)), "alloc")
+            _lib.check(L.amr_dev_upload(0, d, part.ctypes.data, part.size), "upload")
+            bufs.append(d)
+            dec.submit_device(d.value, nb)
+            inflight += 1
+            pos += nb
+            if inflight == depth:
+                got.append(dec.collect())
+                inflight -= 1
+        while inflight:
+            got.append(dec.collect())
+            inflight -= 1
+    finally:
+        for d in bufs:
+            L.amr_dev_free(0, d)
     hs, ps = [], []
     for br in got:
         for pid in range(dec.n_preambles):
@@ -69,23 +53,63 @@ for protos, chip in ((["scm"], 72), (["scm", "scm+", "idm", "r900"], 72)):
             ps.append(pk)
     h, p = np.concatenate(hs), np.concatenate(ps)
     o = np.lexsort((h[:, 2], h[:, 1], h[:, 0]))
-    h, p = h[o], p[o]
-    assert np.array_equal(h, want[2]), "hit lists differ"
-    nfull = dec.Cfg.PacketSymbols // 8
-    assert np.array_equal(p[:, :nfull], want[3][:, :nfull]), "packet bytes differ"
-    assert len(h) > 0
-    dec.close()
-    for d in bufs:
-        L.amr_dev_free(0, d)
-print("pipeline exact")
-"""
+    return h[o], p[o]
 
 
-@pytest.mark.parametrize("env", [{}, {"AMR_TAIL_MODE": "event"}, {"AMR_TAIL_OVERLAP": "0"}],
-                         ids=["host-launched-tail", "event-driven-tail", "single-stream"])
-def test_three_deep_pipeline_in_every_tail_mode(env):
-    """K3.. of a pipelined batch run on the second stream, launched by the host (default) or behind stream events, or on
-    the compute stream as before: same results as the oracle in all three."""
-    r = subprocess.run([sys.executable, "-c", PIPE_CHILD], cwd=ROOT, env={**os.environ, **env}, capture_output=True, text=True,
-                       timeout=600)
-    assert r.returncode == 0 and "pipeline exact" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
+@pytest.mark.parametrize("protos,chip,dense", [
+    (["scm"], 72, False),                            # k1t_demod + k2_search_stream<144, 10, 4>
+    (["scm", "scm+", "idm", "r900"], 72, False),     # four preambles, rows of 256 words
+    (["scm"], 8, False),                             # k2_search_fast (rows of 16 words)
+    (["scm"], 88, False),                            # k1_demod
+    (["scm", "idm"], 72, True),                      # k2_search_dense everywhere (AMR_DENSE_SEARCH)
+], ids=["stream", "stream-4pre", "fast-chip8", "k1-first-gen", "dense"])
+def test_three_deep_pipeline_with_every_search_kernel(protos, chip, dense, monkeypatch):
+    if dense:
+        monkeypatch.setenv("AMR_DENSE_SEARCH", "1")
+    dec = util.make_decoder(protos, chip)
+    try:
+        scale = 8 if chip == 8 else 1
+        sizes = [s * scale for s in SIZES]
+        iq, _ = util.synth_stream(protos, chip, sum(sizes), dec.Cfg.BlockSize, 91, 10)
+        want = util.oracle_run(protos, chip, iq)
+        h, p = _pipeline(dec, iq, sizes)
+        assert len(h) > 0 and np.array_equal(h, want[2]), f"hit lists differ: gpu {len(h)} oracle {len(want[2])}"
+        nfull = dec.Cfg.PacketSymbols // 8
+        assert np.array_equal(p[:, :nfull], want[3][:, :nfull]), "packet bytes differ"
+    finally:
+        dec.close()
+
+
+def test_more_than_four_preambles_go_through_the_dense_kernel():
+    """Five distinct preambles (custom protocol entries next to the rtlamr ones): the stream and list kernels hold four,
+    the dense kernel takes over -- pipelined, so the state update rides inside it."""
+    from rtlamr_amd.protocol import PacketConfig, Parser
+
+    class Custom(Parser):
+        def __init__(self, pre, chip):
+            self._c = PacketConfig(Protocol="x" + pre[:4], Preamble=pre, DataRate=32768, ChipLength=chip,
+                                   PreambleSymbols=len(pre), PacketSymbols=96)
+        def Cfg(self): return self._c
+        def Parse(self, pkts): return []
+
+    chip = 72
+    extra = ["1100110011110000", "101100111000111100001"]
+    dec = ra.new_decoder()
+    for name in ("scm", "scm+", "idm"):
+        dec.RegisterProtocol(ra.new_parser(name, chip))
+    for pre in extra:
+        dec.RegisterProtocol(Custom(pre, chip))
+    dec.Allocate()
+    try:
+        assert dec.n_preambles == 5
+        protos = ["scm", "scm+", "idm"] + [(pre, len(pre), 96) for pre in extra]
+        iq, _ = util.synth_stream(["scm", "scm+", "idm"], chip, sum(SIZES), dec.Cfg.BlockSize, 17, 8)
+        o = OracleDecoder(protos, chip)
+        _, hits, hb = o.decode_stream(iq, hits_cap=1 << 18)
+        order = np.lexsort((hits[:, 2], hits[:, 0], hits[:, 1]))
+        want = np.stack([hits[order, 1], hits[order, 0], hits[order, 2]], axis=1).astype(np.int64)
+        h, p = _pipeline(dec, iq, SIZES)
+        assert len(want) > 0 and np.array_equal(h, want)
+        assert np.array_equal(p, hb[order])
+    finally:
+        dec.close()

@@ -81,12 +81,15 @@ def test_random_pipeline_and_validation(seed):
     chip = int(rng.choice(CHIPS))
     validate = bool(rng.integers(2))
     host_input = bool(rng.integers(2))
+    defer = bool(rng.integers(2)) and "r900" not in protos      # wave-tile deferral (amr_set_deferral)
     dec = util.make_decoder(protos, chip)
     L = _lib.lib()
     bufs = []
     try:
         if validate:
             dec.EnableValidation()
+        if defer:
+            dec.SetDeferral(True)
         bs, bs2 = dec.Cfg.BlockSize, dec.Cfg.BlockSize2
         iq, n_blocks = _stream_for(rng, protos, chip, bs)
         split = _random_split(rng, n_blocks)
@@ -105,9 +108,13 @@ def test_random_pipeline_and_validation(seed):
             oh, op = np.concatenate([H[i] for i in order]), np.concatenate([P[i] for i in order])
         got_h, got_p = [], []
 
+        covered = []
+
         def take(br):
+            covered.append((br.first_block, br.n_blocks))
             for pid in range(dec.n_preambles):
                 blk, idx, pk = br.for_preamble(pid)
+                assert len(blk) == 0 or (blk.min() >= br.first_block and blk.max() < br.first_block + br.n_blocks)
                 got_h.append(np.stack([np.full(len(blk), pid, np.int64), blk.astype(np.int64), idx.astype(np.int64)], axis=1))
                 got_p.append(pk)
 
@@ -131,6 +138,13 @@ def test_random_pipeline_and_validation(seed):
                 take(dec.collect()); inflight -= 1
         while inflight:
             take(dec.collect()); inflight -= 1
+        if defer:
+            take(dec.flush())
+        # the results tile the stream: every call index is covered by exactly one of them, in order
+        edges = [c[0] for c in covered] + [covered[-1][0] + covered[-1][1]]
+        assert edges[0] == 0 and edges[-1] == n_blocks and all(a + n == b for (a, n), b in zip(covered, edges[1:]))
+        if not defer:
+            assert [c[1] for c in covered] == list(split)
         gh, gp = np.concatenate(got_h), np.concatenate(got_p)
         o = np.lexsort((gh[:, 2], gh[:, 1], gh[:, 0]))
         gh, gp = gh[o], gp[o]

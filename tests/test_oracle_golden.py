@@ -188,3 +188,62 @@ def test_c_and_numpy_restatements_agree_on_random_configurations(seed):
     if len(hits):
         nfull = pkt_sym // 8
         assert np.array_equal(npo.slice_packets(qq, hits, gg, pkt_sym)[:, :nfull], p[:, :nfull])
+
+
+# ---- full-size machinery: the C generator, the threaded sharded decode, the bench goldens ---------------------------
+
+def test_c_generator_equals_numpy_generator():
+    """oracle/synth_gen.c == rtlamr_amd.synth (the numpy twin of the device generator), noise and planted bursts,
+    at a stream offset, with packets clipped by both ends of the buffer."""
+    from oracle import oracle as orc
+    from rtlamr_amd import synth
+    n, first = 1 << 16, 777_000
+    pk = [synth.Packet(first - 3000, bytes(range(12)), 96, 30, -26),            # starts before the buffer
+          synth.Packet(first + 20_000, bytes(range(50, 62)), 96, -30, 26),
+          synth.Packet(first + 40_000, bytes(range(100, 192)), 736, 127, -128),   # saturates
+          synth.Packet(first + n - 3000, bytes(range(12)), 96, 22, 23)]         # runs past the end
+    for chip in (8, 72):
+        a = synth.noise(n, 5, first)
+        synth.plant(a, pk, chip, first_sample=first)
+        b = orc.synth_stream(n, 5, first, pk, chip, n_threads=3)
+        assert np.array_equal(a, b)
+
+
+@pytest.mark.parametrize("protos,chip,n_blocks", [(["scm"], 72, 700), (["idm"], 72, 320),
+                                                 (["scm", "scm+", "idm", "r900"], 72, 330), (["scm"], 8, 3000)])
+def test_sharded_oracle_equals_single_decoder(protos, chip, n_blocks):
+    """oracle.decode_sharded (what the full-size GPU tests and the bench goldens use): block ranges on threads, each
+    primed with ceil(PL/BS)+1 blocks, give exactly the single decoder's bitstream, hits and packets."""
+    from oracle import oracle as orc
+    o = OracleDecoder(protos, chip)
+    bs = o.geom.block_size
+    iq, _ = util.synth_stream(protos, chip, n_blocks, bs, seed=3, n_packets=24)
+    _, q1, h1, p1 = util.oracle_run(protos, chip, iq)
+    q2, h2, p2 = orc.decode_sharded(protos, chip, iq, n_threads=6)
+    assert len(h1) > 0 and np.array_equal(q1, q2) and np.array_equal(h1, h2) and np.array_equal(p1, p2)
+    q3, h3, p3 = orc.decode_sharded(protos, chip, iq, n_threads=6, first_block=9)
+    keep = h1[:, 1] >= 9
+    assert np.array_equal(q1[9 * bs // 8:], q3) and np.array_equal(h1[keep], h3) and np.array_equal(p1[keep], p3)
+
+
+def test_bench_goldens_come_from_the_oracle_and_reproduce():
+    """tests/golden/bench_golden.json: declared oracle-made, complete (every workload x shard 0..7 at full size), and
+    its small-size entries recompute to the same digests here (same schedule code, same oracle)."""
+    import bench
+    from tests.golden import make_bench_golden as mk
+    gold = json.load(open(os.path.join(HERE, "golden", "bench_golden.json")))
+    assert gold["source"].startswith("oracle")
+    for spec in mk.ALL:
+        wl = bench.workload(spec)
+        nb = wl["nbytes"] // OracleDecoder(wl["protos"], wl["chip"]).geom.block_size2
+        for shard in range(8):
+            for state in ("first", "steady"):
+                e = gold[mk.key(wl["name"], nb, shard)][state]
+                assert e["n_hits"] > 4096 and len(e["hits_sha256"]) == len(e["q_sha256"]) == len(e["pkt_sha256"]) == 64
+                assert 0 < e["validated"]["n_hits"] < e["n_hits"]
+    small = [k for k in gold if "|blocks=4096|" in k or "|blocks=2048|" in k]
+    assert len(small) >= 4
+    for k in small:
+        spec, nb, shard = k.split("|")
+        got = mk.golden_for(spec, int(shard.split("=")[1]), int(nb.split("=")[1]), threads=4)
+        assert got == gold[k], k
