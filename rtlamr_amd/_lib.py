@@ -71,12 +71,12 @@ class AmrTiming(C.Structure):
 
 def build(force: bool = False) -> str:
     """Compile libamrdemod.so in-tree with hipcc for gfx950 (cross-compiles without a GPU)."""
-    srcs = [os.path.join(CSRC, f) for f in ("amrdemod.hip", "k1_demod.h", "k1_tile.h", "k2_search.h", "k2_stream.h", "k2_walk.h", "k4_r900.h",
-                                            "k5_validate.h", "synth.h")]
+    srcs = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".hip", ".h", ".inc")) or f == "Makefile"]
     srcs.append(os.path.join(_HERE, "..", "include", "amrdemod.h"))
     stale = (not os.path.exists(SO_PATH)) or any(os.path.getmtime(s) > os.path.getmtime(SO_PATH) for s in srcs)
     if force or stale:
-        subprocess.check_call(["make", "-C", CSRC, "-s", "libamrdemod.so"] + (["-B"] if force else []))
+        jobs = str(min(8, os.cpu_count() or 1))     # one object per kernel family (csrc/launch.h)
+        subprocess.check_call(["make", "-C", CSRC, "-s", "-j", jobs, "libamrdemod.so"] + (["-B"] if force else []))
     return SO_PATH
 
 

@@ -21,11 +21,8 @@
 #include <vector>
 
 #include "amrdemod.h"
-#include "k1_demod.h"
-#include "k1_tile.h"
-#include "k2_search.h"
-#include "k2_stream.h"
-#include "k2_walk.h"
+#include "launch.h"
+#include "k3_slice.h"
 #include "k4_r900.h"
 #include "k5_validate.h"
 #include "synth.h"
@@ -215,29 +212,7 @@ amr_status host_realloc(T *&p, size_t count)
 
 // Timing events ride on the kernel dispatches themselves (hipExtLaunchKernelGGL start/stop events): a separate
 // hipEventRecord costs a ~6 us bubble on the stream each, four of them per batch were 6 % of a 1 GiB step.
-// K1 comes in two generations: k1t_demod (k1_tile.h: register-resident staging tile, static super-body) for every chip
-// length whose csum rings leave room for it, k1_demod (k1_demod.h) for the rest (chip 80/88/96).
-
-template <int CL, bool TAIL>
-void launch_k1_cl(dim3 grid, hipStream_t st, const amr::K1Args &a, hipEvent_t start, hipEvent_t stop)
-{
-    if constexpr (amr::K1TGeom<CL>::supported)
-        hipExtLaunchKernelGGL((amr::k1t_demod<CL, TAIL, amr::K1TDefault>), grid, dim3(64), amr::K1TDefault::kLds, st, start, stop, 0, a);
-    else
-        hipExtLaunchKernelGGL((amr::k1_demod<CL, TAIL>), grid, dim3(64), 0, st, start, stop, 0, a);
-}
-
-template <bool TAIL>
-void launch_k1(int cl, dim3 grid, hipStream_t st, const amr::K1Args &a, hipEvent_t start, hipEvent_t stop)
-{
-    switch (cl) {
-#define AMR_K1_CASE(N) case N: launch_k1_cl<N, TAIL>(grid, st, a, start, stop); break;
-        AMR_K1_CASE(8) AMR_K1_CASE(32) AMR_K1_CASE(40) AMR_K1_CASE(48) AMR_K1_CASE(56)
-        AMR_K1_CASE(64) AMR_K1_CASE(72) AMR_K1_CASE(80) AMR_K1_CASE(88) AMR_K1_CASE(96)
-#undef AMR_K1_CASE
-    default: break;
-    }
-}
+// The kernels are launched through launch.h: one translation unit per kernel family.
 
 // Wait for the compute stream.  With K3.. of some batches still unlaunched (pipelined callers), a k_hist_update on the
 // stream may be waiting for one of them: launch them first (each as soon as its own search has finished), or the wait
@@ -356,12 +331,6 @@ amr_status enqueue_k2(amr_handle *h, Slot &s, hipStream_t st, bool rerun, bool d
         HIP_TRY(hipMemsetAsync(s.d_overflow, 0, 4, st));
         HIP_TRY(hipMemsetAsync(s.d_gcnt, 0, (size_t)s.gcnt_words * 4, st));
     }
-    // second-generation search (k2_stream.h): rows of 64..256 words, every preamble at least D symbols long, D = taps
-    // applied to every position before the candidate lists take over: 10 for one preamble (2^-10 of the positions
-    // survive: ~20 list entries per wave in noise), 12 when several preambles share the sweep and the lists
-    const int k2d = n_pre == 1 ? AMR_K2S_D1 : AMR_K2S_DN;
-    bool stream_ok = !h->dense_search && !dense && n_pre <= 4 && h->sg.wpb >= 64 && h->sg.wpb <= 256;
-    for (uint32_t q = 0; q < n_pre; ++q) stream_ok = stream_ok && (int)h->sg.pre_len[q] >= k2d;
     // the batch's state update as workgroup number n_tiles of the search launch, the copies of deferred blocks as the
     // workgroups behind it (see K2Args::do_hist)
     uint32_t extra = 0;
@@ -374,93 +343,34 @@ amr_status enqueue_k2(amr_handle *h, Slot &s, hipStream_t st, bool rerun, bool d
         if (folded) *folded = true;
     }
     const uint32_t wgs = s.n_tiles + extra;
-    // third-generation search (k2_walk.h): one wave walks a whole tile out of global memory; every rtlamr parser set
-    // (at most four preambles of at least 16 symbols) at every BlockSize from 512 to 8192
+    hipEvent_t k2start = t2 ? s.ev_s : nullptr;
+    hipError_t le = hipSuccess;
+    // the walk search (k2_walk.h): one wave walks a whole tile out of global memory; every set of rtlamr's own preambles
+    // (scm, scm+, idm / netidm, r900: their first sixteen symbols are compile-time constants there) at every BlockSize
+    // from 512 to 8192
     bool walk_ok = !h->dense_search && !dense && n_pre <= 4 && h->sg.wpb >= 16 && h->sg.wpb <= 256;
-    for (uint32_t q = 0; q < n_pre; ++q) walk_ok = walk_ok && (int)h->sg.pre_len[q] >= amr::kK2WTaps;
-    {   // TEMPORARY (A/B on the GPU box): AMR_K2_IMPL=stream keeps the second generation
-        static const bool use_stream = [] { const char *e = getenv("AMR_K2_IMPL"); return e && strcmp(e, "stream") == 0; }();
-        if (use_stream) walk_ok = false;
+    uint32_t walk_set = 0;
+    for (uint32_t q = 0; q < n_pre && walk_ok; ++q) {
+        const int kind = amr::k2_walk_kind_of(h->sg.pre_len[q], h->sg.pre_bits[q]);
+        walk_ok = kind >= 0;
+        if (kind >= 0) { walk_set |= 1u << kind; k2.walk_pids |= q << (8 * kind); }
     }
     if (walk_ok) {
-        const size_t lds2 = amr::k2_walk_lds_bytes(h->hist_rows * h->sg.wpb);
         const uint32_t n_wg = (s.n_tiles + amr::kK2WWaves - 1) / amr::kK2WWaves + extra;
-        const uint32_t grid = 8u * ((n_wg + 7u) / 8u);   // XCD-contiguous tile order: 8 equal runs
-#define AMR_K2W_LAUNCH(S, N)                                                                                           \
-    do {                                                                                                             \
-        HIP_TRY(hipFuncSetAttribute((const void *)amr::k2_search_walk<S, N>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2)); \
-        hipExtLaunchKernelGGL((amr::k2_search_walk<S, N>), dim3(grid), dim3(64 * amr::kK2WWaves), lds2, st, t2 ? s.ev_s : nullptr, k2stop, 0, k2); \
-    } while (0)
-#define AMR_K2W_CASE(S)                                                                                               \
-    case S:                                                                                                          \
-        if (n_pre == 1) AMR_K2W_LAUNCH(S, 1); else if (n_pre == 2) AMR_K2W_LAUNCH(S, 2);                              \
-        else if (n_pre == 3) AMR_K2W_LAUNCH(S, 3); else AMR_K2W_LAUNCH(S, 4);                                         \
-        break;
-        switch (h->sg.symbol_length) {
-            AMR_K2W_CASE(16) AMR_K2W_CASE(64) AMR_K2W_CASE(80) AMR_K2W_CASE(96) AMR_K2W_CASE(112) AMR_K2W_CASE(128)
-            AMR_K2W_CASE(144) AMR_K2W_CASE(160) AMR_K2W_CASE(176) AMR_K2W_CASE(192)
-        default: walk_ok = false; break;
-        }
-#undef AMR_K2W_CASE
-#undef AMR_K2W_LAUNCH
+        walk_ok = amr::launch_k2_walk(h->sg.symbol_length, walk_set, 8u * ((n_wg + 7u) / 8u) /* XCD-contiguous tile order: 8 equal runs */,
+                                      amr::k2_walk_lds_bytes(h->hist_rows * h->sg.wpb), st, k2start, k2stop, k2, &le);
     }
-    if (walk_ok) stream_ok = false;
+    // fallbacks: the list-based kernel splits a row's words over 4 or 8 waves, 4 or 8 words per step: rows of fewer
+    // than 16 words (BlockSize 256: scm+ alone at chip length 8) and more than four preambles go through the dense kernel
     if (walk_ok) {
-    } else if (stream_ok) {
-        const int nwv = amr::k2_stream_waves(h->sg.wpb);
-        const size_t lds2 = amr::k2_stream_lds_bytes(h->sg.wpb, n_pre);
-        const uint32_t grid = 8u * ((wgs + 7u) / 8u);   // XCD-contiguous tile order: 8 equal runs
-        bool launched = true;
-#define AMR_K2S_LAUNCH(S, DD, W)                                                                                       \
-    do {                                                                                                             \
-        HIP_TRY(hipFuncSetAttribute((const void *)amr::k2_search_stream<S, DD, W>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2)); \
-        hipExtLaunchKernelGGL((amr::k2_search_stream<S, DD, W>), dim3(grid), dim3(64 * W), lds2, st, t2 ? s.ev_s : nullptr, k2stop, 0, k2); \
-    } while (0)
-#define AMR_K2S_W(S, DD)                                                                                             \
-    do {                                                                                                             \
-        if (nwv == 2) AMR_K2S_LAUNCH(S, DD, 2); else if (nwv == 4) AMR_K2S_LAUNCH(S, DD, 4); else AMR_K2S_LAUNCH(S, DD, 8); \
-    } while (0)
-#define AMR_K2S_CASE(S)                                                                                               \
-    case S:                                                                                                          \
-        if (n_pre == 1) AMR_K2S_W(S, AMR_K2S_D1); else AMR_K2S_W(S, AMR_K2S_DN);                                      \
-        break;
-        switch (h->sg.symbol_length) {
-            AMR_K2S_CASE(64) AMR_K2S_CASE(80) AMR_K2S_CASE(96) AMR_K2S_CASE(112) AMR_K2S_CASE(128)
-            AMR_K2S_CASE(144) AMR_K2S_CASE(160) AMR_K2S_CASE(176) AMR_K2S_CASE(192)
-        default: launched = false; break;
-        }
-#undef AMR_K2S_CASE
-#undef AMR_K2S_W
-#undef AMR_K2S_LAUNCH
-        stream_ok = launched;
-    }
-    // the list-based kernel splits a row's words over 4 or 8 waves, 4 or 8 words per step: rows of fewer than 16 words
-    // (BlockSize 256: scm+ alone at chip length 8) go through the dense kernel
-    if (stream_ok || walk_ok) {
     } else if (!h->dense_search && !dense && n_pre <= 4 && h->sg.wpb >= 16) {
         const int nwv = h->sg.wpb >= 64 ? 8 : 4;   // a wave needs at least JW words of a row: 8 x 8 or 4 x 4
-        const size_t lds2 = amr::k2_fast_lds_bytes(h->sg.wpb, (int)n_pre, nwv);
-#define AMR_K2_LAUNCH(N, W, J)                                                                                        \
-    do {                                                                                                             \
-        HIP_TRY(hipFuncSetAttribute((const void *)amr::k2_search_fast<N, W, J>, hipFuncAttributeMaxDynamicSharedMemorySize, \
-                                    (int)lds2));                                                                     \
-        hipExtLaunchKernelGGL((amr::k2_search_fast<N, W, J>), dim3(wgs), dim3(64 * W), lds2, st, t2 ? s.ev_s : nullptr, \
-                              k2stop, 0, k2);                                                                       \
-    } while (0)
-#define AMR_K2_CASE(N)                                                                                              \
-    case N:                                                                                                          \
-        if (nwv == 8) AMR_K2_LAUNCH(N, 8, 8);   /* 16 words per step measured slower (51 vs 47 us) */               \
-        else AMR_K2_LAUNCH(N, 4, 4);                                                                                 \
-        break;
-        switch (n_pre) { AMR_K2_CASE(1) AMR_K2_CASE(2) AMR_K2_CASE(3) AMR_K2_CASE(4) }
-#undef AMR_K2_CASE
-#undef AMR_K2_LAUNCH
+        (void)amr::launch_k2_fast(n_pre, nwv, wgs, amr::k2_fast_lds_bytes(h->sg.wpb, (int)n_pre, nwv), st, k2start, k2stop, k2, &le);
     } else {
-        const size_t lds2 = ((size_t)h->sg.wpb * 65 + 8) * 4;
-        HIP_TRY(hipFuncSetAttribute((const void *)amr::k2_search_dense, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                    (int)lds2));
-        hipExtLaunchKernelGGL(amr::k2_search_dense, dim3(wgs), dim3(256), lds2, st, t2 ? s.ev_s : nullptr, k2stop, 0, k2);
+        amr::launch_k2_dense(wgs, ((size_t)h->sg.wpb * 65 + 8) * 4, st, k2start, k2stop, k2, &le);
     }
+    HIP_TRY(le);
+    HIP_TRY(hipGetLastError());
     AMR_DBG(st, "k2_search");
     return AMR_OK;
 }
@@ -480,7 +390,11 @@ amr_status enqueue_tail(amr_handle *h, Slot &s, hipStream_t st, bool split)
     k3.out_cap = s.out_cap; k3.overflow = s.d_overflow;
     k3.block_base = s.calls_base; k3.n_tiles = s.n_tiles; k3.cap = s.stage_cap; k3.g = h->sg;
     hipEvent_t k3e0 = (t2 && split) ? s.ev_t : nullptr, k3e1 = t2 ? s.ev2 : nullptr;
-    hipExtLaunchKernelGGL(amr::k3_slice_words, dim3(s.n_tiles, n_pre), dim3(256), 0, st, k3e0, k3e1, 0, k3);
+    const size_t k3lds = amr::k3_lds_bytes(h->sg);
+    HIP_TRY(hipFuncSetAttribute((const void *)amr::k3_slice_words, hipFuncAttributeMaxDynamicSharedMemorySize, (int)k3lds));
+    // one workgroup per (tile, preamble) list; the kernel also takes a grid of (n_tiles, 1) = every list of a tile in one
+    // workgroup with shared row staging, which measured slower on the four-preamble decoder (188 against 173 us per 4 GiB)
+    hipExtLaunchKernelGGL(amr::k3_slice_words, dim3(s.n_tiles, n_pre), dim3(256), k3lds, st, k3e0, k3e1, 0, k3);
     HIP_TRY(hipGetLastError());
     AMR_DBG(st, "k3_slice");
     if (h->r900_pid >= 0) {
@@ -594,11 +508,11 @@ amr_status submit(amr_handle *h, const uint8_t *d_iq, size_t n_blocks, bool sear
     for (uint32_t w0 = 0; w0 < full; w0 += round) {
         const uint32_t n = std::min(round, full - w0);
         k1.wg_first = w0;
-        launch_k1<false>(h->geom.chip_length, dim3(n), st, k1, w0 == 0 ? e0 : nullptr, (w0 + n == full && !rem) ? e1 : nullptr);
+        amr::launch_k1(h->geom.chip_length, false, dim3(n), st, k1, w0 == 0 ? e0 : nullptr, (w0 + n == full && !rem) ? e1 : nullptr);
     }
     if (rem) {   // the partial wave-tile: one wave (sync callers, flush, batches under 64 blocks)
         k1.wg_first = full;
-        launch_k1<true>(h->geom.chip_length, dim3(1), st, k1, full ? nullptr : e0, e1);
+        amr::launch_k1(h->geom.chip_length, true, dim3(1), st, k1, full ? nullptr : e0, e1);
     }
     HIP_TRY(hipGetLastError());
     AMR_DBG(st, "k1_demod");

@@ -1,209 +1,10 @@
-// K2 / K2s / K3 -- preamble search, hit compaction and packet slicing on the
-// tiled bitstream K1 wrote.
-//
-// Reference semantics (protocol/decode.go:255-328, Decoder.Search): call k
-// reports every idx in [0, BlockSize) with
-//     Quantized[idx + p*SymbolLength] == preamble[p]   for all p,
-// ascending.  With pos = k*BlockSize + idx (counted from the first call of the
-// batch) the bit tested for tap p is q[pos - PacketLength + p*SymbolLength],
-// q = the stream of bit decisions, q[n] = 0 before the stream starts
-// (decode.go:145).  For every legal -symbollength the byte prefilter of
-// decode.go:268-294 selects exactly this set, so the
-// search below evaluates the set directly, 32 positions per lane at a time:
-//     M &= preamble[p] ? W_p : ~W_p,    W_p = the 32 stream bits starting at
-//                                       n + p*SymbolLength (one funnel shift).
-// All preambles share the windows W_p (every parser uses the same
-// SymbolLength), so one pass serves scm, scm+, idm/netidm and r900 together.
-//
-// Work decomposition: one workgroup = one tile = 64 consecutive rows (reference
-// blocks) of the tiled bitstream, staged in LDS together with row 0 of the
-// next tile (a window never reaches further: (L-1)*SL < PreambleLength <=
-// BlockSize).  Threads walk the tile in stream order, so hits leave the tile
-// already sorted; the per-tile counts (and their sums over groups of 64 tiles)
-// give every tile its slot in the final per-preamble arrays, which K3 fills
-// (hit position + the sliced packet, decode.go:353-375).
+// K2 fallbacks -- k2_search_fast (list-based, first generation) and k2_search_dense, for what k2_walk.h does not take:
+// preambles shorter than 16 symbols, more than four preambles, rows under 16 words, and the re-run after a candidate
+// list overflowed.  Same reference semantics, arguments and output as the walk kernel (k2_common.h).
 #pragma once
-#include <hip/hip_runtime.h>
-#include <stdint.h>
+#include "k2_common.h"
 
 namespace amr {
-
-constexpr int kMaxPre = 8;
-
-struct SearchGeom {
-    uint32_t block_size;     // BS
-    uint32_t lg_block_size;
-    uint32_t wpb;            // BS/32 words per row
-    uint32_t lg_wpb;
-    uint32_t symbol_length;  // SL (multiple of 16)
-    uint32_t packet_length;  // PL (multiple of 64)
-    uint32_t packet_symbols;
-    uint32_t pkt_bytes;
-    uint32_t n_pre;
-    uint32_t max_pre_len;
-    uint32_t pre_len[kMaxPre];
-    uint64_t pre_bits[kMaxPre];  // bit p = preamble[p]
-};
-
-// After a batch: the last `hr` rows (reference blocks) become the history rows 64-hr..63 of tile 0 of the next slot, the
-// last HBA IQ bytes the carry, and the next slot's search words are reset -- the state the Go Decoder carries from call
-// to call (decode.go:165-166).  One workgroup; reads everything before writing anything.
-struct HistArgs {
-    const uint32_t *qt;     // bitstream of the batch just processed (its tile 0 = the old history)
-    uint32_t *qt_next;      // bitstream buffer the next batch will use: receives the new history tile
-    uint32_t n_blocks;  // rows in the batch just processed
-    uint32_t hr;        // history rows kept = ceil(PL/BS) (<= 63)
-    uint32_t wpb, lg_wpb;
-    // the other per-batch state, folded into this launch: the IQ halo of the next batch's block 0 (last HBA stream
-    // bytes, decode.go:165) and the reset of the overflow word the next batch's search will use
-    const uint8_t *carry_src;
-    uint8_t *carry_dst;
-    uint32_t carry_bytes;   // multiple of 16
-    // blocks deferred to the next launch (amr_set_deferral): they follow the carry bytes in the stream and in the head
-    // buffer (carry_src + carry_bytes -> carry_dst + carry_bytes), copied by `defer_wgs` extra workgroups of the launch
-    uint32_t defer_bytes;   // multiple of 16
-    uint32_t defer_wgs;
-    uint32_t *ovf_next;
-    uint32_t *gcnt_next;    // the group sums the next batch's K2 adds into
-    uint32_t gcnt_words;
-    // completion ticket of the batch, stored to pinned host memory by the last thread of this last kernel
-    uint64_t *done_flag;
-    uint64_t done_value;
-    // ticket of the stream-A part of the batch (K1, search, this kernel), always published; done_flag may be null
-    // when K3 and what follows it run later on the second stream and publish the batch ticket themselves
-    uint64_t *adone_flag;
-    // Pipelined callers: K3.. of the PREVIOUS batch run on the second stream next to this batch's search.  When they
-    // take longer than the search, the next K1 launch (which needs every wave slot of the chip) has to wait for them:
-    // this kernel, the last one in front of it, spins until the device word `wait_flag` reaches `wait_value`
-    // (k_done of that batch) -- for at most ~2 ms, in case the host never launches them.
-    const uint64_t *wait_flag;
-    uint64_t wait_value;
-};
-
-__device__ __forceinline__ size_t qt_index_fwd(uint64_t R, uint32_t w, uint32_t lg_wpb)   // = qt_index, defined below
-{
-    return ((R >> 6) << (6 + lg_wpb)) + ((size_t)(w >> 2) << 8) + ((R & 63) << 2) + (w & 3);
-}
-
-// the work, by a workgroup of `nt` threads with hr * wpb words of LDS at tmp
-__device__ __forceinline__ void hist_body(const HistArgs &a, uint32_t *tmp, uint32_t nt)
-{
-    const uint32_t tid = threadIdx.x;
-    for (uint32_t i = tid; i < a.carry_bytes / 16; i += nt)
-        reinterpret_cast<uint4 *>(a.carry_dst)[i] = reinterpret_cast<const uint4 *>(a.carry_src)[i];
-    if (tid == nt - 1) *a.ovf_next = 0;
-    for (uint32_t i = tid; i < a.gcnt_words; i += nt) a.gcnt_next[i] = 0;
-    const uint32_t n = a.hr << a.lg_wpb;
-    for (uint32_t i = tid; i < n; i += nt) {
-        const uint32_t j = i >> a.lg_wpb, w = i & (a.wpb - 1);
-        // new history row j = stream row (n_blocks - hr + j) of the batch; negative -> old history
-        const int64_t srow = (int64_t)64 + a.n_blocks - a.hr + j;  // tiled row index (tile 0 rows 0..63 = old history)
-        tmp[i] = a.qt[qt_index_fwd((uint64_t)srow, w, a.lg_wpb)];
-    }
-    __syncthreads();
-    for (uint32_t i = tid; i < n; i += nt) {
-        const uint32_t j = i >> a.lg_wpb, w = i & (a.wpb - 1);
-        a.qt_next[qt_index_fwd(64 - a.hr + j, w, a.lg_wpb)] = tmp[i];
-    }
-    __syncthreads();
-}
-
-// slice `part` of `parts` of the deferred blocks, by a workgroup of `nt` threads
-__device__ __forceinline__ void defer_copy_body(const HistArgs &a, uint32_t part, uint32_t nt)
-{
-    const uint32_t n16 = a.defer_bytes / 16, per = (n16 + a.defer_wgs - 1) / a.defer_wgs;
-    const uint32_t lo = part * per, hi = lo + per < n16 ? lo + per : n16;
-    const uint4 *src = reinterpret_cast<const uint4 *>(a.carry_src + a.carry_bytes);
-    uint4 *dst = reinterpret_cast<uint4 *>(a.carry_dst + a.carry_bytes);
-    for (uint32_t i = lo + threadIdx.x; i < hi; i += nt) dst[i] = src[i];
-}
-
-// the tickets, by one thread, once everything of the batch on this stream has completed
-__device__ __forceinline__ void hist_publish(const HistArgs &a)
-{
-    if (a.adone_flag) __hip_atomic_store(a.adone_flag, a.done_value, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-    if (a.done_flag) __hip_atomic_store(a.done_flag, a.done_value, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-    if (a.wait_flag) {
-        const uint64_t t0 = __builtin_amdgcn_s_memrealtime();   // 100 MHz
-        while (__hip_atomic_load(a.wait_flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < a.wait_value &&
-               __builtin_amdgcn_s_memrealtime() - t0 < 200000ull)
-            __builtin_amdgcn_s_sleep(32);
-    }
-}
-
-__global__ __launch_bounds__(1024) void k_hist_update(const HistArgs a)
-{
-    extern __shared__ uint32_t hist_tmp[];  // hr*wpb words
-    if (blockIdx.x) { defer_copy_body(a, blockIdx.x - 1, 1024); return; }
-    hist_body(a, hist_tmp, 1024);
-    // every earlier kernel of the batch has completed (same stream); the host polls these words
-    if (threadIdx.x == 0) hist_publish(a);
-}
-
-struct K2Args {
-    const uint32_t *qt;    // tiled bitstream, tile 0 = history tile
-    uint32_t *counts;      // [n_pre][n_tiles]
-    uint32_t *gcnt;        // [n_pre][n_groups] sums of counts over groups of 64 tiles (atomicAdd; zero before K2 runs)
-    uint32_t *staging;     // [n_tiles][n_pre][cap] tile-local positions (row*BS + bit), ascending
-    uint32_t *overflow;    // set to 1 when a tile found more than cap hits for a preamble
-    uint32_t n_tiles;      // tiles searched: ceil(n_blocks/64) + 1 (history tile first)
-    uint32_t cap;
-    int64_t n_lo, n_hi;    // valid positions: n_lo <= n < n_hi, n relative to batch sample 0
-    unsigned long long *dbg;   // harness builds only (AMR_K2S_DBG): 16 words of timestamps per workgroup, or null
-    // pinned host word that receives `started_value` when the search starts, i.e. when everything before it on the
-    // stream (this batch's K1) has finished: the host then launches the previous batch's K3 on the second stream
-    uint64_t *started;
-    uint64_t started_value;
-    // pipelined callers: the state update rides along as one more workgroup (tile index n_tiles; the hist.defer_wgs
-    // workgroups behind it copy the deferred blocks) instead of a 5 us kernel of its own behind the search.  It carries
-    // no completion ticket (the search is still running
-    // when it is done; a ticket from inside the kernel would also need every workgroup to release its writes, an L2
-    // write-back each): the host takes "the next search has started" or "the stream is idle" as the signal instead.
-    uint32_t do_hist;
-    HistArgs hist;
-    SearchGeom g;
-};
-
-// Workgroups behind the last tile of a search launch: the folded state update and the deferred-block copies.
-// Returns true when this workgroup was one of them (and is done).
-__device__ __forceinline__ bool k2_extra_workgroup(const K2Args &a, uint32_t T, uint32_t *lds, uint32_t nt)
-{
-    if (T < a.n_tiles) return false;
-    if (a.do_hist) {
-        if (T == a.n_tiles) {
-            hist_body(a.hist, lds, nt);
-            if (threadIdx.x == 0) hist_publish(a.hist);   // no tickets here (the search is still running): only the wait
-        } else if (T - a.n_tiles - 1 < a.hist.defer_wgs) {
-            defer_copy_body(a.hist, T - a.n_tiles - 1, nt);
-        }
-    }
-    return true;
-}
-
-__device__ __forceinline__ void k2_announce(const K2Args &a)
-{
-    if (a.started && blockIdx.x == 0 && threadIdx.x == 0)
-        __hip_atomic_store(a.started, a.started_value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-}
-
-// Index of word w (32 decisions) of tiled row R (row 64 + b = batch block b; rows 0..63 = history tile) in the
-// "tiled4" bitstream K1 writes: per 64-row tile, 4-word chunks, a row's chunk = 16 contiguous bytes.
-__device__ __forceinline__ size_t qt_index(uint64_t R, uint32_t w, uint32_t lg_wpb)
-{
-    return ((R >> 6) << (6 + lg_wpb)) + ((size_t)(w >> 2) << 8) + ((R & 63) << 2) + (w & 3);
-}
-
-// 32 stream bits starting at bit `o` (word x = o>>5, shift sh = o&31) of row `l`; LDS tile is
-// [word][65]: column 64 holds row 0 of the next tile, so a row overrun is "same word index in
-// the next column".
-__device__ __forceinline__ uint32_t k2_word(const uint32_t *lds, uint32_t x, uint32_t l, uint32_t wpb_mask, uint32_t lg_wpb)
-{
-    return lds[(x & wpb_mask) * 65 + l + (x >> lg_wpb)];
-}
-
-// The per-(preamble, tile) hit counts are also summed per group of 64 tiles, so that K3 finds the slot of a list in
-// the packed result from <= n_pre * n_groups + 63 values instead of a scan over all of them.
-__host__ __device__ __forceinline__ uint32_t k2_groups(uint32_t n_tiles) { return (n_tiles + 63) >> 6; }
 
 __global__ __launch_bounds__(256) void k2_search_dense(const K2Args a)
 {
@@ -317,7 +118,6 @@ __global__ __launch_bounds__(256) void k2_search_dense(const K2Args a)
 //     and each entry is emitted by 32 lanes at once (lane b = bit b), in stream order.
 // If a wave's list overflows (pathological input), bit 1 of *overflow is set and the host re-runs the
 // tile set with k2_search_dense.
-constexpr int kListCap = 448;  // (key, mask) entries per wave
 
 #ifndef AMR_K2_DEPTH
 #define AMR_K2_DEPTH 9
@@ -557,209 +357,5 @@ __global__ __launch_bounds__(64 * NWV) void k2_search_fast(const K2Args a)
     if (lane == 0 && list_n > (uint32_t)LCAP) atomicOr(a.overflow, 2u);
 }
 
-inline size_t k2_fast_lds_bytes(uint32_t wpb, int npre, int nwv)
-{
-    return ((size_t)wpb * 65 + 4 * kListCap * 2 + 2 * (size_t)npre * 64 * nwv + 8) * 4;
-}
-
-// K3: move each tile's hits to their final slot and slice the packets.
-struct K3Args {
-    const uint32_t *qt;
-    const uint32_t *counts;     // [n_pre][n_tiles] from K2
-    const uint32_t *gcnt;       // [n_pre][n_groups] from K2
-    const uint32_t *staging;
-    // packed result [hit_block u64 x n | hit_idx u32 x n | pkt x n], n = total hits:
-    //   hit_block = block_base + (pos >> lg BS), pos = n + PacketLength;  hit_idx = pos & (BS-1)  (Data.Idx, decode.go:371)
-    uint8_t *out;
-    uint64_t *offs_pre;         // [n_pre+1] per-preamble bases, written here (K4/K5 and device-side consumers read them)
-    // what the host needs to size / accept the result, written straight into pinned host memory (no D2H copy on
-    // the compute stream): the per-preamble bases and K2's overflow word
-    uint64_t *h_offs_pre;       // [n_pre+1]
-    uint32_t *h_overflow;
-    uint64_t block_base;        // call index of the first block of the batch
-    uint64_t out_cap;           // hits the buffer holds
-    const uint32_t *overflow;   // K2's overflow word: non-zero = the host will grow a capacity and search again
-    uint32_t n_tiles;
-    uint32_t cap;
-    SearchGeom g;
-};
-
-// K3 slices by bitstream word, not by hit.  The hits of a real packet (and most noise hits' neighbours) come in runs of
-// adjacent positions, so slicing hit by hit (round 1: one lane = 32 symbols of one hit) read every bitstream word ~20
-// times and spent ~13 VALU operations per (hit, symbol).  Here the unit of work is a bitstream WORD that holds hits: for symbol p the 32 positions of the word
-// need the 32 stream bits starting at word*32 + p*SL -- one window, one or two word loads (SL is a multiple of 16) --
-// and the packets of all 32 positions are the columns of the bit matrix [symbol][position].  A wave takes 64 symbols
-// at a time, lane = symbol (two 32 x 32 blocks), transposes the blocks in five exchange steps (ds_swizzle, no LDS
-// memory), after which lane c of a block holds 32 consecutive packet bits of position 31-c: one dword of that packet,
-// already in the byte order of Decoder.Slice (decode.go:363-366) because the symbols were dealt to the lanes
-// bit-reversed inside every byte.  Positions that are hits store their dword, the others are dropped.
-// Input: positions in the staging slots, ascending; output: the packed result (K3Args).
-// (Tried and dropped: one workgroup per tile that first stages the tile's 64 rows in LDS -- LDS-DMA, rows XOR-swizzled
-// against bank conflicts -- and takes the windows from there: 64 vs 54 us of search per 1 GiB with scm, 1.05 vs 0.67 ms
-// per 4 GiB with four preambles.  The preambles of a tile run one after the other, half as many workgroups fit a CU,
-// and the staging is one more latency in front of a kernel that is made of latencies.)
-__device__ __forceinline__ uint32_t k3_transpose32(uint32_t x, uint32_t lane)
-{
-#define K3_TSTEP(S, M)                                                                                                \
-    {                                                                                                                 \
-        const uint32_t y = (uint32_t)__builtin_amdgcn_ds_swizzle((int)x, ((S) << 10) | 0x1f);   /* lane ^ S */       \
-        x = (lane & (S)) ? ((x & ~(M)) | ((y >> (S)) & (M))) : ((x & (M)) | ((y << (S)) & ~(M)));                     \
-    }
-    K3_TSTEP(16, 0x0000ffffu) K3_TSTEP(8, 0x00ff00ffu) K3_TSTEP(4, 0x0f0f0f0fu) K3_TSTEP(2, 0x33333333u) K3_TSTEP(1, 0x55555555u)
-#undef K3_TSTEP
-    return x;
-}
-
-constexpr int kK3Batch = 4;    // words (entries) a wave works on together: their bitstream loads are in flight at once
-
-__global__ __launch_bounds__(256) void k3_slice_words(const K3Args a)
-{
-    const SearchGeom &g = a.g;
-    const uint32_t T = blockIdx.x, q = blockIdx.y;
-    __shared__ uint64_t red[2][4];
-    __shared__ uint32_t tab[4][kK3Batch][32];   // per wave and entry: staging index of the hit at bit b of the word, or ~0
-    // Slot of this (tile, preamble) list in the packed result = the hits of all lists before it (preamble-major), and the
-    // layout needs the grand total.  No scan kernel between K2 and K3 (a dispatch costs the stream ~5 us): K2 left sums
-    // over groups of 64 tiles, so a workgroup adds up the group sums before its group, the <= 63 counts before it inside
-    // the group, and all group sums for the total -- one load per lane, all in flight before the first use.  The
-    // workgroups of tile 0 publish the per-preamble bases, (0,0) also the total and K2's overflow word.
-    const uint32_t n_groups = k2_groups(a.n_tiles), my_g = q * n_groups + (T >> 6);
-    const uint32_t cnt = a.counts[q * a.n_tiles + T];
-    uint64_t before = 0, all = 0;
-    for (uint32_t i = threadIdx.x; i < g.n_pre * n_groups; i += 256) {
-        const uint32_t c = a.gcnt[i];
-        all += c;
-        before += i < my_g ? c : 0u;
-    }
-    if (threadIdx.x < (T & 63)) before += a.counts[q * a.n_tiles + (T & ~63u) + threadIdx.x];
-    const uint32_t ovf = *a.overflow;
-    if (cnt == 0 && T != 0) return;
-    for (int d = 32; d; d >>= 1) {
-        before += __shfl_down((unsigned long long)before, d);
-        all += __shfl_down((unsigned long long)all, d);
-    }
-    if ((threadIdx.x & 63) == 0) { red[0][threadIdx.x >> 6] = before; red[1][threadIdx.x >> 6] = all; }
-    __syncthreads();
-    const uint64_t off = red[0][0] + red[0][1] + red[0][2] + red[0][3];
-    const uint64_t total = red[1][0] + red[1][1] + red[1][2] + red[1][3];
-    if (T == 0 && threadIdx.x == 0) {
-        a.offs_pre[q] = off;
-        a.h_offs_pre[q] = off;
-        if (q == 0) { a.offs_pre[g.n_pre] = total; a.h_offs_pre[g.n_pre] = total; *a.h_overflow = ovf; }
-    }
-    if (ovf || cnt == 0) return;
-    if (total > a.out_cap) return;   // the host grows the buffer and searches again
-    uint64_t *hit_block = reinterpret_cast<uint64_t *>(a.out);
-    uint32_t *hit_idx = reinterpret_cast<uint32_t *>(a.out + total * 8);
-    uint8_t *pkt = a.out + total * 12;
-    const uint32_t *src = a.staging + ((size_t)T * g.n_pre + q) * a.cap;
-    const uint32_t *__restrict__ tbase = a.qt + ((size_t)T << (6 + g.lg_wpb));
-    const uint32_t lg_bs = g.lg_block_size, bs_mask = g.block_size - 1, lg_tw = 6 + g.lg_wpb;
-    const uint32_t lane = threadIdx.x & 63, wv = threadIdx.x >> 6, l32 = lane & 31, half = lane >> 5;
-    const uint32_t PS = g.packet_symbols, SL = g.symbol_length, PB = g.pkt_bytes;
-    const bool dword_ok = (PB & 3) == 0 && (PS & 7) == 0;
-    // symbol offset of this lane inside a 64-symbol step: the 32 lanes of a block take the symbols bit-reversed
-    // within every byte, so that bit i of the transposed dword is the symbol Decoder.Slice puts into bit i
-    const uint32_t sym_lane = half * 32 + ((l32 & ~7u) | (7u - (l32 & 7u)));
-    const uint32_t bad = 64u << lg_bs;                 // defensive: never index the bitstream with a bad position
-    auto word_at = [&](uint32_t v) {                   // bitstream word holding bit v (counted from row 0 of tile T)
-        const uint32_t row = v >> lg_bs, w = (v & bs_mask) >> 5;
-        return tbase[((row >> 6) << lg_tw) + ((w >> 2) << 8) + ((row & 63) << 2) + (w & 3)];
-    };
-    for (uint32_t i0 = wv * 64; i0 < cnt; i0 += 256) {
-        const uint32_t i = i0 + lane;
-        const bool have = i < cnt;
-        const uint32_t local = have ? src[i] : 0xffffffffu;
-        const bool ok = have && local < bad;
-        if (ok) {
-            const int64_t n = ((int64_t)T * 64 - 64) * (int64_t)g.block_size + local;
-            const uint64_t pos = (uint64_t)(n + g.packet_length);
-            hit_block[off + i] = a.block_base + (pos >> lg_bs);
-            hit_idx[off + i] = (uint32_t)pos & bs_mask;
-        }
-        const uint32_t key = ok ? local >> 5 : 0xffffffffu;
-        const uint32_t prev = __shfl_up(key, 1);
-        uint64_t leaders = __ballot(ok && (lane == 0 || key != prev));
-        while (leaders) {
-            uint32_t v0[kK3Batch], slot[kK3Batch];
-            int nb = 0;
-#pragma unroll
-            for (int e = 0; e < kK3Batch; ++e) {
-                v0[e] = 0; slot[e] = 0xffffffffu;
-                if (leaders) {                                         // wave-uniform
-                    const uint32_t L = (uint32_t)__ffsll((unsigned long long)leaders) - 1;
-                    leaders &= leaders - 1;
-                    const uint32_t key_s = __builtin_amdgcn_readlane(key, L);
-                    if (lane < 32) tab[wv][e][lane] = 0xffffffffu;
-                    if (ok && key == key_s) tab[wv][e][local & 31] = i;   // same wave: LDS operations execute in order
-                    slot[e] = tab[wv][e][31 - l32];                    // lane c of a block ends up with position 31-c
-                    v0[e] = key_s << 5;
-                    nb = e + 1;
-                }
-            }
-            for (uint32_t p0 = 0; p0 < PS; p0 += 128) {               // two 64-symbol steps of up to four words per round
-                uint32_t A[kK3Batch][2], B[kK3Batch][2];
-#pragma unroll
-                for (int e = 0; e < kK3Batch; ++e)
-#pragma unroll
-                    for (int k = 0; k < 2; ++k) {
-                        A[e][k] = 0; B[e][k] = 0;
-                        if (e < nb && p0 + 64 * k < PS) {
-                            const uint32_t sy = p0 + 64 * k + sym_lane;
-                            const uint32_t v = v0[e] + (sy < PS ? sy : PS - 1) * SL;
-                            A[e][k] = word_at(v);
-                            B[e][k] = word_at(v + 32);
-                        }
-                    }
-#pragma unroll
-                for (int e = 0; e < kK3Batch; ++e)
-#pragma unroll
-                    for (int k = 0; k < 2; ++k) {
-                        if (e >= nb || p0 + 64 * k >= PS) continue;
-                        const uint32_t sy = p0 + 64 * k + sym_lane;
-                        const uint32_t W = ((sy < PS ? sy : PS - 1) * SL & 16) ? __builtin_amdgcn_alignbit(A[e][k], B[e][k], 16) : A[e][k];
-                        const uint32_t Y = k3_transpose32(W, lane);
-                        const uint32_t b0 = (p0 + 64 * k) / 8 + half * 4;   // first packet byte of this lane's dword
-                        if (slot[e] != 0xffffffffu && b0 < PB) {
-                            uint8_t *out = pkt + (off + slot[e]) * (uint64_t)PB;
-                            if (b0 + 4 <= PB && dword_ok) {
-                                *reinterpret_cast<uint32_t *>(out + b0) = Y;
-                            } else {
-#pragma unroll
-                                for (uint32_t j = 0; j < 4; ++j) {
-                                    const uint32_t bj = b0 + j;
-                                    if (bj < PB) {
-                                        uint32_t byte = (Y >> (8 * j)) & 0xffu;
-                                        const uint32_t valid = PS - bj * 8;
-                                        if (valid < 8) byte >>= (8 - valid);   // PacketSymbols % 8 != 0: right-aligned like Go's shift-in
-                                        out[bj] = (uint8_t)byte;
-                                    }
-                                }
-                            }
-                        }
-                    }
-            }
-        }
-    }
-}
-
-// last kernel of a batch whose K3 (K4, K5) ran on the second stream: publishes the batch ticket
-__global__ void k_done(uint64_t *flag, uint64_t value, uint64_t *dev_flag)
-{
-    __hip_atomic_store(dev_flag, value, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);   // k_hist_update of the next batch waits here
-    __hip_atomic_store(flag, value, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-}
-
-// Tests: tiled rows 64.. -> linear MSB-first byte stream (decode.go:259-265 packing).
-__global__ void k_untile(const uint32_t *qt, uint32_t *out, uint32_t n_blocks, uint32_t lg_wpb)
-{
-    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const uint64_t n = (uint64_t)n_blocks << lg_wpb;
-    if (i >= n) return;
-    const uint64_t R = 64 + (i >> lg_wpb);
-    const uint32_t w = (uint32_t)i & ((1u << lg_wpb) - 1);
-    const uint32_t v = qt[qt_index(R, w, lg_wpb)];
-    out[i] = __builtin_bswap32(v);
-}
 
 }  // namespace amr

@@ -3,7 +3,7 @@
 // lane = row = one reference block, every lane walks ITS row from the first word to the last, straight out of global
 // memory into a register ring.
 //
-// Why.  The second generation (k2_stream.h) staged a tile in LDS, split a row's words over 2 / 4 / 8 waves and met three
+// Why.  The second generation (round 2's k2_stream.h) staged a tile in LDS, split a row's words over 2 / 4 / 8 waves and met three
 // barriers per tile; with rows of 256 words (BlockSize 8192: idm, "all") a workgroup held 79 KB of LDS, two fitted a CU, and
 // the kernel took 0.22 ms (one preamble) to 0.54 ms (four) per 4 GiB of IQ for ~30 us of VALU work and 256 MiB of
 // reads -- a chain of exposed latencies.  Here nothing is staged and nothing is shared:
@@ -13,9 +13,10 @@
 //     their use (ordinary loads: the compiler counts the vmcnt);
 //   * the stream of a row continues in the next row: past the row end a lane's loads simply go on at row l+1 (lane 63:
 //     row 0 of the next tile) -- the look-ahead is re-read (LOOK words per row), not exchanged;
-//   * all preambles share the window words (one SymbolLength), so the taps are outermost and the preambles innermost:
-//     per word and tap one v_alignbit (odd multiples of 16 bits only) and ONE v_bitop3 per preamble (M & (W ^ inv), the
-//     preamble bit as a scalar 0 / ~0);
+//   * all preambles share the window words (one SymbolLength); the sixteen tap polarities of rtlamr's four preambles are
+//     compile-time constants, so two taps fold into ONE v_bitop3 (k2w_sweep below): 8 instructions per word and
+//     preamble, plus one v_perm per window at an odd multiple of 16 bits; several preambles run one after the other on
+//     the same ring registers;
 //   * D = 16 taps run on every position: 2^-16 of them survive in noise (8 per preamble and wave at BlockSize 8192), so
 //     the remaining taps of the longer preambles (scm 21, idm / netidm / r900 32) are rare enough to fetch their words
 //     from memory one candidate per lane;
@@ -23,20 +24,16 @@
 //     the staging slot need no barrier.  Four waves (four consecutive tiles) make a workgroup only so that the folded
 //     state update (K2Args::do_hist) has 256 threads.
 // Output (counts, group sums, staging slots, overflow protocol) is that of the other search kernels: K3 and the host see
-// no difference.  Used when every preamble has at least 16 symbols (all of rtlamr's: scm+ 16, scm 21, idm / netidm /
-// r900 32), there are at most four of them and a row has 16..256 words; otherwise k2_search_fast / k2_search_dense run.
+// no difference.  Used when every registered preamble is one of rtlamr's own (at most four distinct ones exist) and a row
+// has 16..256 words; otherwise k2_search_fast / k2_search_dense run.
 #pragma once
-#include "k2_search.h"
+#include "k2_common.h"
 
 #ifndef AMR_K2W_DBG
 #define AMR_K2W_DBG 0     // harness builds: phase stamps per wave in K2Args::dbg
 #endif
 
 namespace amr {
-
-constexpr int kK2WTaps = 16;              // taps applied to every position
-constexpr int kK2WList = 192;             // (key, mask) entries per wave
-constexpr int kK2WWaves = 4;              // waves (tiles) per workgroup
 
 template <int SL, int PF>
 struct K2WGeom {
@@ -47,15 +44,8 @@ struct K2WGeom {
     static constexpr int RW = RC * 4;                               // ring size in words
 };
 
-// prefetch depth by window length: a group of a short-symbol geometry is little work, its loads need more lead
-template <int SL, int NPRE> struct K2WPf { static constexpr int value = NPRE >= 3 ? 3 : NPRE == 2 ? 4 : 6; };
+constexpr int kK2WPrefetch = 5;           // chunks loaded ahead of their use
 
-inline size_t k2_walk_lds_bytes(uint32_t hist_words)
-{
-    const size_t per_wave = (size_t)kK2WList * 2 + 2 * 4 * 64;      // list + counts + bases (four preambles)
-    const size_t need = per_wave * kK2WWaves;
-    return (need > hist_words ? need : hist_words) * 4;
-}
 
 typedef uint32_t k2w_v4u __attribute__((ext_vector_type(4)));
 
@@ -81,56 +71,142 @@ __device__ __forceinline__ void k2w_load(K2WRing<RC> &R, const K2WCtx &cx, int s
 
 // one group of four words (ring slot GG of the current ring turn), all taps, all preambles; then the group's chunk is
 // dead and its slot takes the chunk RC further on.  Template recursion: every ring index has to be a constant.
-template <int SL, int NPRE, int PF, int GG>
+// ---- the sweep, specialised at COMPILE time on the preamble --------------------------------------------------------------
+// rtlamr's parsers bring four preambles, fixed in their NewParser functions: scm/scm.go:45, scmplus/scmplus.go:52,
+// idm/idm.go:52 (netidm/netidm.go:63 the same string), r900/r900.go:60.  With the first sixteen symbols known at compile
+// time the tap polarities move from a scalar operand into v_bitop3's truth table, which leaves the operand slots for
+// window words: M & f(W_p) & g(W_p+1) is ONE instruction instead of two (the first one takes three taps, having no M to
+// carry): 8 per word and preamble instead of 16.  The multi-preamble search is bound by exactly this count (a wave64
+// VALU instruction holds its SIMD for 4 cycles: "all" at 4 GiB is 7.5 G lane-operations = 0.19 ms of the chip's VALU).
+// Any other preamble (a custom protocol entry) sends the whole set to the fallback kernels of k2_search.h.
+constexpr uint32_t k2w_bits(const char *s)                                    // bit p = s[p] == '1', first sixteen symbols
+{
+    uint32_t v = 0;
+    for (int p = 0; p < kK2WTaps && s[p]; ++p) v |= (uint32_t)(s[p] == '1') << p;
+    return v;
+}
+constexpr uint32_t kK2WKnown[4] = {k2w_bits("111110010101001100000"),             // scm
+                                   k2w_bits("0001011010100011"),                  // scm+
+                                   k2w_bits("01010101010101010001011010100011"),  // idm, netidm
+                                   k2w_bits("00000000000000001110010101100100")};  // r900
+constexpr uint32_t kK2WKnownLen[4] = {21, 16, 32, 32};
+constexpr uint64_t k2w_bits64(const char *s)
+{
+    uint64_t v = 0;
+    for (int p = 0; p < 64 && s[p]; ++p) v |= (uint64_t)(s[p] == '1') << p;
+    return v;
+}
+constexpr uint64_t kK2WKnownAll[4] = {k2w_bits64("111110010101001100000"), k2w_bits64("0001011010100011"),
+                                      k2w_bits64("01010101010101010001011010100011"), k2w_bits64("00000000000000001110010101100100")};
+
+// which of the four a registered preamble is (-1: none of them)
+inline int k2_walk_kind(uint32_t len, uint64_t bits)
+{
+    for (int k = 0; k < 4; ++k)
+        if (len == kK2WKnownLen[k] && bits == kK2WKnownAll[k]) return k;
+    return -1;
+}
+
+// window word of tap P for word j of ring group GG
+template <int SL, int PF, int GG, int P>
+__device__ __forceinline__ uint32_t k2w_win(const K2WRing<K2WGeom<SL, PF>::RC> &R, int j)
+{
+    using G = K2WGeom<SL, PF>;
+    constexpr int x = (P * SL) >> 5;
+    constexpr bool half = ((P * SL) & 31) != 0;                        // SL is a multiple of 16: the shift is 0 or 16
+    const int i0 = (GG * 4 + j + x) % G::RW, i1 = (i0 + 1) % G::RW;
+    return half ? __builtin_amdgcn_alignbit(R.c[i0 >> 2][i0 & 3], R.c[i1 >> 2][i1 & 3], 16) : R.c[i0 >> 2][i0 & 3];
+}
+
+// taps P, P+1 folded into M: truth table of  x & (y == b_P) & (z == b_P+1)  over index 4x + 2y + z
+template <int SL, int PF, int GG, uint32_t BITS, int P>
+__device__ __forceinline__ void k2w_pairs(const K2WRing<K2WGeom<SL, PF>::RC> &R, uint32_t (&M)[4])
+{
+    if constexpr (P + 1 < kK2WTaps) {
+        constexpr uint32_t tt = 1u << (4 + 2 * ((BITS >> P) & 1u) + ((BITS >> (P + 1)) & 1u));
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            M[j] = __builtin_amdgcn_bitop3_b32(M[j], k2w_win<SL, PF, GG, P>(R, j), k2w_win<SL, PF, GG, P + 1>(R, j), tt);
+        k2w_pairs<SL, PF, GG, BITS, P + 2>(R, M);
+    } else if constexpr (P < kK2WTaps) {                               // the odd tap out: x & (y == b_P), z ignored
+        constexpr uint32_t b = (BITS >> P) & 1u;
+        constexpr uint32_t tt = (1u << (4 + 2 * b)) | (1u << (4 + 2 * b + 1));
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const uint32_t W = k2w_win<SL, PF, GG, P>(R, j);
+            M[j] = __builtin_amdgcn_bitop3_b32(M[j], W, W, tt);
+        }
+    }
+}
+
+// all sixteen taps of one preamble on the four words of group GG: 8 instructions per word
+template <int SL, int PF, int GG, uint32_t BITS>
+__device__ __forceinline__ void k2w_sweep(const K2WRing<K2WGeom<SL, PF>::RC> &R, uint32_t (&M)[4])
+{
+    constexpr uint32_t tt = 1u << (4 * (BITS & 1u) + 2 * ((BITS >> 1) & 1u) + ((BITS >> 2) & 1u));   // (x == b0) & (y == b1) & (z == b2)
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+        M[j] = __builtin_amdgcn_bitop3_b32(k2w_win<SL, PF, GG, 0>(R, j), k2w_win<SL, PF, GG, 1>(R, j), k2w_win<SL, PF, GG, 2>(R, j), tt);
+    k2w_pairs<SL, PF, GG, BITS, 3>(R, M);
+}
+
+// record the non-zero masks of one group and preamble (rare path)
+__device__ __forceinline__ void k2w_record(const uint32_t (&M)[4], uint32_t q, uint32_t g, uint32_t w_lo, uint32_t w_hi, uint32_t lane,
+                                           uint32_t *mylist, uint32_t &list_n)
+{
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const uint32_t w = g * 4 + j;
+        const uint32_t m = (w >= w_lo && w < w_hi) ? M[j] : 0u;
+        const uint64_t b = __ballot(m != 0);
+        if (b) {
+            const uint32_t idx = list_n + __builtin_amdgcn_mbcnt_hi((uint32_t)(b >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)b, 0));
+            if (m != 0 && idx < (uint32_t)kK2WList) {
+                mylist[idx * 2] = (q << 16) | (lane << 8) | w;
+                mylist[idx * 2 + 1] = m;
+            }
+            list_n += __popcll(b);
+        }
+    }
+}
+
+// one known preamble (KIND, present in the launch's SET) on the four words of group GG
+template <int SL, int PF, int GG, int SET, int KIND>
+__device__ __forceinline__ void k2w_kind(const K2WRing<K2WGeom<SL, PF>::RC> &R, uint32_t pids, uint32_t g, uint32_t w_lo, uint32_t w_hi,
+                                         uint32_t lane, uint32_t *mylist, uint32_t &list_n)
+{
+    if constexpr ((SET >> KIND) & 1) {
+        uint32_t M[4];
+        k2w_sweep<SL, PF, GG, kK2WKnown[KIND]>(R, M);
+        if (__ballot((M[0] | M[1] | M[2] | M[3]) != 0))                 // rare
+            k2w_record(M, (pids >> (8 * KIND)) & 0xffu, g, w_lo, w_hi, lane, mylist, list_n);
+    }
+}
+
+// one group of four words (ring slot GG of the current ring turn), all taps, all preambles of the SET; then the group's
+// chunk is dead and its slot takes the chunk RC further on.  Template recursion: every ring index has to be a constant.
+// SET: which of rtlamr's four preambles the launch searches, a compile-time mask -- a launch's code holds the sweeps it
+// runs and no others.  (One kernel for all sets with a run-time choice per preamble was 75 KB of loop body; the
+// instruction cache two CUs share holds 64 KB and every wave walks the whole body: 0.18 ms for what takes 0.08.)
+// pids: the preamble id (K2Args order) of each kind, 8 bits each.
+template <int SL, int PF, int SET, int GG>
 __device__ __forceinline__ void k2w_groups(K2WRing<K2WGeom<SL, PF>::RC> &R, const K2WCtx &cx, uint32_t g0, uint32_t n_groups,
-                                           uint32_t n_chunks, const uint32_t (&inv)[NPRE][kK2WTaps], uint32_t w_lo, uint32_t w_hi,
+                                           uint32_t pids, uint32_t w_lo, uint32_t w_hi,
                                            uint32_t lane, uint32_t *mylist, uint32_t &list_n)
 {
     using G = K2WGeom<SL, PF>;
     if constexpr (GG < G::RC) {
         const uint32_t g = g0 + GG;
         if (g >= n_groups) return;                                  // wave-uniform
-        uint32_t M[NPRE][4];
-#pragma unroll
-        for (int q = 0; q < NPRE; ++q)
-#pragma unroll
-            for (int j = 0; j < 4; ++j) M[q][j] = 0xffffffffu;
-#pragma unroll
-        for (int p = 0; p < G::D; ++p) {
-            const int x = (p * SL) >> 5;
-            const bool half = ((p * SL) & 31) != 0;                 // SL is a multiple of 16: the shift is 0 or 16
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const int i0 = (GG * 4 + j + x) % G::RW, i1 = (i0 + 1) % G::RW;
-                const uint32_t W = half ? __builtin_amdgcn_alignbit(R.c[i0 >> 2][i0 & 3], R.c[i1 >> 2][i1 & 3], 16) : R.c[i0 >> 2][i0 & 3];
-#pragma unroll
-                for (int q = 0; q < NPRE; ++q) M[q][j] = __builtin_amdgcn_bitop3_b32(M[q][j], W, inv[q][p], 0x60);   // M & (W ^ inv)
-            }
-        }
-        uint32_t any = 0;
-#pragma unroll
-        for (int q = 0; q < NPRE; ++q) any |= M[q][0] | M[q][1] | M[q][2] | M[q][3];
-        if (__ballot(any != 0)) {                                   // rare: record the non-zero masks of valid words
-#pragma unroll
-            for (int q = 0; q < NPRE; ++q) {
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const uint32_t w = g * 4 + j;
-                    const uint32_t m = (w >= w_lo && w < w_hi) ? M[q][j] : 0u;
-                    const uint64_t b = __ballot(m != 0);
-                    if (b) {
-                        const uint32_t idx = list_n + __builtin_amdgcn_mbcnt_hi((uint32_t)(b >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)b, 0));
-                        if (m != 0 && idx < (uint32_t)kK2WList) {
-                            mylist[idx * 2] = ((uint32_t)q << 16) | (lane << 8) | w;
-                            mylist[idx * 2 + 1] = m;
-                        }
-                        list_n += __popcll(b);
-                    }
-                }
-            }
-        }
-        if (g + G::RC < n_chunks) k2w_load<G::RC>(R, cx, GG, g + G::RC);
-        k2w_groups<SL, NPRE, PF, GG + 1>(R, cx, g0, n_groups, n_chunks, inv, w_lo, w_hi, lane, mylist, list_n);
+        k2w_kind<SL, PF, GG, SET, 0>(R, pids, g, w_lo, w_hi, lane, mylist, list_n);
+        k2w_kind<SL, PF, GG, SET, 1>(R, pids, g, w_lo, w_hi, lane, mylist, list_n);
+        k2w_kind<SL, PF, GG, SET, 2>(R, pids, g, w_lo, w_hi, lane, mylist, list_n);
+        k2w_kind<SL, PF, GG, SET, 3>(R, pids, g, w_lo, w_hi, lane, mylist, list_n);
+        // unconditionally, also past the last chunk the walk needs (PF + 1 chunks of the following row, harmless): a load
+        // inside a branch makes the compiler's waitcnt pass give up counting and wait for ALL loads in flight at every
+        // group (vmcnt(0): 64 exposed memory latencies per row walk)
+        k2w_load<G::RC>(R, cx, GG, g + G::RC);
+        k2w_groups<SL, PF, SET, GG + 1>(R, cx, g0, n_groups, pids, w_lo, w_hi, lane, mylist, list_n);
     }
 }
 
@@ -138,8 +214,7 @@ template <int RC, int K>
 __device__ __forceinline__ void k2w_fill(K2WRing<RC> &R, const K2WCtx &cx, uint32_t n_chunks)
 {
     if constexpr (K < RC) {
-        if ((uint32_t)K < n_chunks) k2w_load<RC>(R, cx, K, K);
-        else R.c[K] = k2w_v4u{0, 0, 0, 0};
+        k2w_load<RC>(R, cx, K, K);
         k2w_fill<RC, K + 1>(R, cx, n_chunks);
     }
 }
@@ -156,10 +231,10 @@ __device__ __forceinline__ uint32_t k2w_wave_scan(uint32_t x)
     return x;
 }
 
-template <int SL, int NPRE>
+template <int SL, int SET>
 __global__ __launch_bounds__(64 * kK2WWaves) void k2_search_walk(const K2Args a)
 {
-    constexpr int PF = K2WPf<SL, NPRE>::value;
+    constexpr int PF = kK2WPrefetch;
     using G = K2WGeom<SL, PF>;
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
 #if AMR_K2W_DBG
@@ -193,16 +268,15 @@ __global__ __launch_bounds__(64 * kK2WWaves) void k2_search_walk(const K2Args a)
 #pragma unroll
     for (int q = 0; q < 4; ++q) cnts[q * 64 + lane] = 0;
 
-    // ---- preamble bits as scalars: inv[q][p] = ~0 where preamble q has a 0 at tap p (and at taps it does not have) ----
-    uint32_t inv[NPRE][kK2WTaps];
-    uint64_t pbits[NPRE];
-    uint32_t plen[NPRE];
+    // ---- the preambles (up to four; the taps behind the sixteenth, stage 2, take their bits from the geometry) ----
+    constexpr int NP = 4;
+    const uint32_t n_pre = a.g.n_pre;
+    uint64_t pbits[NP];
+    uint32_t plen[NP];
 #pragma unroll
-    for (int q = 0; q < NPRE; ++q) {
-        pbits[q] = a.g.pre_bits[q];
-        plen[q] = a.g.pre_len[q];
-#pragma unroll
-        for (int p = 0; p < kK2WTaps; ++p) inv[q][p] = ((pbits[q] >> p) & 1) ? 0u : 0xffffffffu;
+    for (int q = 0; q < NP; ++q) {
+        pbits[q] = q < (int)n_pre ? a.g.pre_bits[q] : 0;
+        plen[q] = q < (int)n_pre ? a.g.pre_len[q] : 0;
     }
 
     // ---- valid word range of this lane's row: n_lo <= R*BS + 32w < n_hi ----
@@ -223,7 +297,7 @@ __global__ __launch_bounds__(64 * kK2WWaves) void k2_search_walk(const K2Args a)
     k2w_fill<G::RC, 0>(R, cx, n_chunks);
     uint32_t list_n = 0;                                             // wave-uniform
     for (uint32_t g0 = 0; g0 < cpr; g0 += G::RC)
-        k2w_groups<SL, NPRE, PF, 0>(R, cx, g0, cpr, n_chunks, inv, w_lo, w_hi, lane, mylist, list_n);
+        k2w_groups<SL, PF, SET, 0>(R, cx, g0, cpr, a.walk_pids, w_lo, w_hi, lane, mylist, list_n);
     K2W_STAMP(1);
 
     // ---- stage 2: the taps behind the first 16 on the list entries (one per lane), words from memory; compaction in place ----
@@ -239,7 +313,7 @@ __global__ __launch_bounds__(64 * kK2WWaves) void k2_search_walk(const K2Args a)
         uint64_t pb = pbits[0];
         uint32_t pl = plen[0];
 #pragma unroll
-        for (int qq = 1; qq < NPRE; ++qq)
+        for (int qq = 1; qq < NP; ++qq)
             if (q == (uint32_t)qq) { pb = pbits[qq]; pl = plen[qq]; }
         for (uint32_t p = kK2WTaps; p < maxL; p += 4) {              // four taps per round: their eight loads are in flight together
             if (!__any(m != 0)) break;
@@ -270,9 +344,9 @@ __global__ __launch_bounds__(64 * kK2WWaves) void k2_search_walk(const K2Args a)
     K2W_STAMP(2);
 
     // ---- ranks: exclusive scan over the rows in stream order (row-major: all of row l before row l+1) ----
-    uint32_t total[NPRE];
+    uint32_t total[NP];
 #pragma unroll
-    for (int q = 0; q < NPRE; ++q) {
+    for (int q = 0; q < NP; ++q) {
         const uint32_t val = cnts[q * 64 + lane];
         const uint32_t inc = k2w_wave_scan(val);
         total[q] = __builtin_amdgcn_readlane(inc, 63);
@@ -281,26 +355,26 @@ __global__ __launch_bounds__(64 * kK2WWaves) void k2_search_walk(const K2Args a)
 
     // ---- emit: every surviving entry by 32 lanes at once, lane b = bit b (MSB first = stream order).  The list is in
     // walk order: word-major across the rows, ascending words inside a row -- which is all the ranks need ----
-    uint32_t run[NPRE];
+    uint32_t run[NP];
 #pragma unroll
-    for (int q = 0; q < NPRE; ++q) run[q] = 0;
+    for (int q = 0; q < NP; ++q) run[q] = 0;
     for (uint32_t e = 0; e < n_keep; ++e) {
         const uint32_t key = __builtin_amdgcn_readfirstlane(mylist[e * 2]);
         const uint32_t m = __builtin_amdgcn_readfirstlane(mylist[e * 2 + 1]);
         const uint32_t q = key >> 16, l = (key >> 8) & 63, w = key & 0xff;
         uint32_t r = 0;
 #pragma unroll
-        for (int qq = 0; qq < NPRE; ++qq)
+        for (int qq = 0; qq < NP; ++qq)
             if (q == (uint32_t)qq) r = __builtin_amdgcn_readlane(run[qq], l);
         const uint32_t base = bases[q * 64 + l] + r;
         if (lane < 32 && ((m >> (31 - lane)) & 1)) {
             const uint32_t before = lane ? __popc(m >> (32 - lane)) : 0;
             const uint32_t rank = base + before;
-            if (rank < a.cap) a.staging[((size_t)T * NPRE + q) * a.cap + rank] = (l << lg_bs) + (w << 5) + lane;
+            if (rank < a.cap) a.staging[((size_t)T * n_pre + q) * a.cap + rank] = (l << lg_bs) + (w << 5) + lane;
         }
         const uint32_t add = (lane == l) ? __popc(m) : 0;
 #pragma unroll
-        for (int qq = 0; qq < NPRE; ++qq)
+        for (int qq = 0; qq < NP; ++qq)
             if (q == (uint32_t)qq) run[qq] += add;
     }
     K2W_STAMP(3);
@@ -312,7 +386,8 @@ __global__ __launch_bounds__(64 * kK2WWaves) void k2_search_walk(const K2Args a)
 #endif
     if (lane == 0) {
 #pragma unroll
-        for (int q = 0; q < NPRE; ++q) {
+        for (int q = 0; q < NP; ++q) {
+            if (q >= (int)n_pre) break;
             const uint32_t c = total[q] < a.cap ? total[q] : a.cap;
             a.counts[q * a.n_tiles + T] = c;
             if (c) atomicAdd(&a.gcnt[q * k2_groups(a.n_tiles) + (T >> 6)], c);

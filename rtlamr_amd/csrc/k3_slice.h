@@ -1,0 +1,312 @@
+// K3 (hit slots + Decoder.Slice, protocol/decode.go:353-375) and the small kernels around a batch: the state update
+// as a kernel of its own (callers that do not pipeline), the completion ticket, the test helper that untiles the bitstream.
+#pragma once
+#include "k2_common.h"
+
+namespace amr {
+
+__global__ __launch_bounds__(1024) void k_hist_update(const HistArgs a)
+{
+    extern __shared__ uint32_t hist_tmp[];  // hr*wpb words
+    if (blockIdx.x) { defer_copy_body(a, blockIdx.x - 1, 1024); return; }
+    hist_body(a, hist_tmp, 1024);
+    // every earlier kernel of the batch has completed (same stream); the host polls these words
+    if (threadIdx.x == 0) hist_publish(a);
+}
+
+// K3: move each tile's hits to their final slot and slice the packets.
+struct K3Args {
+    const uint32_t *qt;
+    const uint32_t *counts;     // [n_pre][n_tiles] from K2
+    const uint32_t *gcnt;       // [n_pre][n_groups] from K2
+    const uint32_t *staging;
+    // packed result [hit_block u64 x n | hit_idx u32 x n | pkt x n], n = total hits:
+    //   hit_block = block_base + (pos >> lg BS), pos = n + PacketLength;  hit_idx = pos & (BS-1)  (Data.Idx, decode.go:371)
+    uint8_t *out;
+    uint64_t *offs_pre;         // [n_pre+1] per-preamble bases, written here (K4/K5 and device-side consumers read them)
+    // what the host needs to size / accept the result, written straight into pinned host memory (no D2H copy on
+    // the compute stream): the per-preamble bases and K2's overflow word
+    uint64_t *h_offs_pre;       // [n_pre+1]
+    uint32_t *h_overflow;
+    uint64_t block_base;        // call index of the first block of the batch
+    uint64_t out_cap;           // hits the buffer holds
+    const uint32_t *overflow;   // K2's overflow word: non-zero = the host will grow a capacity and search again
+    uint32_t n_tiles;
+    uint32_t cap;
+    SearchGeom g;
+};
+
+// K3 slices by bitstream word, not by hit, out of LDS copies of the few rows a run of hits needs.
+//
+// By word: the hits of a real packet (and most noise hits' neighbours) come in runs of adjacent positions, so slicing hit
+// by hit (round 1: one lane = 32 symbols of one hit) read every bitstream word ~20 times and spent ~13 VALU operations
+// per (hit, symbol).  The unit of work is a bitstream WORD that holds hits: for symbol p the 32 positions of the word need
+// the 32 stream bits starting at word*32 + p*SL -- one window, one or two words (SL is a multiple of 16) -- and the
+// packets of all 32 positions are the columns of the bit matrix [symbol][position].  A wave takes 64 symbols at a time,
+// lane = symbol (two 32 x 32 blocks), transposes the blocks in five exchange steps (ds_swizzle, no LDS memory), after
+// which lane c of a block holds 32 consecutive packet bits of position 31-c: one dword of that packet, already in the
+// byte order of Decoder.Slice (decode.go:363-366) because the symbols were dealt to the lanes bit-reversed inside
+// every byte.  Positions that are hits store their dword, the others are dropped.
+//
+// Out of LDS: a packet is PacketSymbols bits at a stride of SymbolLength; IDM-length packets reach 13 rows of 8192 bits
+// past the hit.  Straight from the tiled bitstream every symbol's window is another 64-byte line (a row's words sit in
+// 16-byte pieces a KiB apart): 70 KB of line fetches per packet run for the 13 KB of stream they lie in -- round 2's K3
+// moved more bytes than the search itself (cfg3: 290 MB against 256 MiB).  So the rows [l, l + n_rows) are copied into
+// LDS ONCE, in stream order (16-byte pieces, neighbouring rows share their lines), and the windows of every hit that
+// starts in row l are taken from there.
+//
+// One workgroup per (tile, preamble) list (grid (n_tiles, n_pre); with a grid of (n_tiles, 1) a workgroup takes all lists
+// of its tile and stages a row once for all of them: measured slower, see enqueue_tail).  Its prologue: the slot of
+// a list in the packed result = the hits of all lists before it (preamble-major), and the layout needs the grand total.  No scan kernel between K2 and K3 (a dispatch costs the stream
+// ~5 us): K2 left sums over groups of 64 tiles; the workgroup scans them (32-bit DPP scan inside a wave -- a wave's 64
+// group sums stay below 2^31 -- the few wave totals in 64 bits) and adds the <= 63 counts before it inside its group.
+// Tile 0's workgroup publishes the per-preamble bases, the total and K2's overflow word.
+// Input: positions in the staging slots, ascending; output: the packed result (K3Args).  Dynamic LDS: k3_lds_bytes().
+__device__ __forceinline__ uint32_t k3_transpose32(uint32_t x, uint32_t lane)
+{
+#define K3_TSTEP(S, M)                                                                                                \
+    {                                                                                                                 \
+        const uint32_t y = (uint32_t)__builtin_amdgcn_ds_swizzle((int)x, ((S) << 10) | 0x1f);   /* lane ^ S */       \
+        x = (lane & (S)) ? ((x & ~(M)) | ((y >> (S)) & (M))) : ((x & (M)) | ((y << (S)) & ~(M)));                     \
+    }
+    K3_TSTEP(16, 0x0000ffffu) K3_TSTEP(8, 0x00ff00ffu) K3_TSTEP(4, 0x0f0f0f0fu) K3_TSTEP(2, 0x33333333u) K3_TSTEP(1, 0x55555555u)
+#undef K3_TSTEP
+    return x;
+}
+
+// inclusive 32-bit prefix sum over the 64 lanes of a wave (DPP)
+__device__ __forceinline__ uint32_t k3_wave_scan(uint32_t x)
+{
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x111, 0xf, 0xf, true);    // row_shr:1
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x112, 0xf, 0xf, true);    // row_shr:2
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x114, 0xf, 0xf, true);    // row_shr:4
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x118, 0xf, 0xf, true);    // row_shr:8
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x142, 0xa, 0xf, false);   // row_bcast:15 into rows 1 and 3
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x143, 0xc, 0xf, false);   // row_bcast:31 into rows 2 and 3
+    return x;
+}
+
+constexpr int kK3Batch = 4;    // words (entries) a wave works on together
+
+__global__ __launch_bounds__(256) void k3_slice_words(const K3Args a)
+{
+    const SearchGeom &g = a.g;
+    const uint32_t T = blockIdx.x;
+    const uint32_t n_pre = g.n_pre;
+    const uint32_t lane = threadIdx.x & 63, wv = threadIdx.x >> 6, l32 = lane & 31, half = lane >> 5;
+    __shared__ uint64_t s_off[kMaxPre + 1];     // slot of this tile's list per preamble; [n_pre] = the grand total
+    __shared__ uint32_t s_cnt[kMaxPre];
+    __shared__ uint32_t s_in[kMaxPre];          // hits of the tile's group in front of the tile, per preamble
+    __shared__ uint32_t tab[4][kK3Batch][32];   // per wave and entry: staging index of the hit at bit b of the word, or ~0
+    extern __shared__ __attribute__((aligned(16))) uint32_t rows_lds[];          // [n_rows][wpb] words, stream order
+
+    // ---- prologue ----
+    const uint32_t n_groups = k2_groups(a.n_tiles), n_sums = n_pre * n_groups;
+    const uint32_t ovf = *a.overflow;
+    for (uint32_t q = wv; q < n_pre; q += 4) {           // wave q: the counts of preamble q in this tile's group, up to the tile
+        const uint32_t t = lane;
+        const uint32_t c = t < (T & 63) ? a.counts[q * a.n_tiles + (T & ~63u) + t] : 0u;
+        const uint32_t mine = a.counts[q * a.n_tiles + T];
+        const uint32_t inc = k3_wave_scan(c);
+        if (lane == 63) { s_in[q] = inc; s_cnt[q] = mine; }
+    }
+    // exclusive scan over the flattened group sums [n_pre][n_groups] in rounds of 64, dealt to the four waves so that
+    // their loads are in flight together; round totals meet in LDS
+    constexpr uint32_t kRounds = 16;                     // rounds whose totals are kept in LDS at a time (1024 sums)
+    __shared__ uint32_t s_round[kRounds];
+    __shared__ uint32_t s_excl[kMaxPre], s_excl_round[kMaxPre];
+    const uint32_t n_rounds = (n_sums + 63) >> 6;
+    uint64_t carry = 0;                                  // workgroup-uniform: sums of the passes before this one
+    if (threadIdx.x < kMaxPre) s_excl_round[threadIdx.x] = 0xffffffffu;
+    for (uint32_t r0 = 0; r0 < n_rounds; r0 += kRounds) {          // one pass unless a batch has more than 1024 group sums
+        __syncthreads();
+        for (uint32_t r = r0 + wv; r < n_rounds && r < r0 + kRounds; r += 4) {
+            const uint32_t i = r * 64 + lane;
+            const uint32_t v = i < n_sums ? a.gcnt[i] : 0u;
+            const uint32_t inc = k3_wave_scan(v);
+            for (uint32_t q = 0; q < n_pre; ++q)         // the sums of this round before (q, this tile's group)
+                if (q * n_groups + (T >> 6) == i) { s_excl[q] = inc - v; s_excl_round[q] = r; }
+            if (lane == 63) s_round[r - r0] = inc;
+        }
+        __syncthreads();
+        if (threadIdx.x <= n_pre) {                      // thread q: the rounds in front of its round, 64 bits from here on
+            const uint32_t q = threadIdx.x;
+            const uint32_t my_r = q < n_pre ? s_excl_round[q] : 0xffffffffu;
+            uint64_t run = carry;
+            for (uint32_t r = r0; r < n_rounds && r < r0 + kRounds; ++r) {
+                if (r == my_r) s_off[q] = run + s_excl[q];
+                run += s_round[r - r0];
+            }
+            if (q == n_pre) s_off[n_pre] = run;          // the total so far
+        }
+        __syncthreads();
+        carry = s_off[n_pre];
+    }
+    __syncthreads();
+    const uint64_t total = s_off[n_pre];
+    if (T == 0 && blockIdx.y == 0 && threadIdx.x <= n_pre) {
+        const uint64_t v = threadIdx.x < n_pre ? s_off[threadIdx.x] : total;      // tile 0: nothing of its group in front of it
+        a.offs_pre[threadIdx.x] = v;
+        a.h_offs_pre[threadIdx.x] = v;
+        if (threadIdx.x == 0) *a.h_overflow = ovf;
+    }
+    // After an overflow the staging slots are incomplete (a wave whose sparse list overflowed counted hits it never
+    // emitted): their contents must not be used as positions; the host re-runs the search anyway.
+    if (ovf || total > a.out_cap) return;                // ... or grows the buffer and searches again
+    // gridDim.y == 1: this workgroup takes every preamble's list of the tile; == n_pre: one list per workgroup (A/B)
+    const uint32_t q_lo = gridDim.y > 1 ? blockIdx.y : 0u, q_hi = gridDim.y > 1 ? blockIdx.y + 1u : n_pre;
+    uint32_t any = 0;
+    for (uint32_t q = q_lo; q < q_hi; ++q) any |= s_cnt[q];
+    if (!any) return;
+
+    uint64_t *hit_block = reinterpret_cast<uint64_t *>(a.out);
+    uint32_t *hit_idx = reinterpret_cast<uint32_t *>(a.out + total * 8);
+    uint8_t *pkt = a.out + total * 12;
+    const uint32_t *__restrict__ tbase = a.qt + ((size_t)T << (6 + g.lg_wpb));
+    const uint32_t lg_bs = g.lg_block_size, bs_mask = g.block_size - 1, lg_tw = 6 + g.lg_wpb;
+    const uint32_t PS = g.packet_symbols, SL = g.symbol_length, PB = g.pkt_bytes;
+    const bool dword_ok = (PB & 3) == 0 && (PS & 7) == 0;
+    // symbol offset of this lane inside a 64-symbol step: the 32 lanes of a block take the symbols bit-reversed
+    // within every byte, so that bit i of the transposed dword is the symbol Decoder.Slice puts into bit i
+    const uint32_t sym_lane = half * 32 + ((l32 & ~7u) | (7u - (l32 & 7u)));
+    const uint32_t bad = 64u << lg_bs;                 // defensive: never index the bitstream with a bad position
+    const uint32_t wpb = g.wpb, cpr = wpb >> 2;
+    const uint32_t n_rows = 1 + ((PS * SL + 32 + g.block_size - 1) >> lg_bs);     // rows a hit-word's windows can touch
+    // The four waves share the work by hits (64 each) when a packet is short, by SYMBOLS when it is long: the hits of a
+    // packet are one run of ~70 positions, i.e. one wave's worth, and 736 symbols in one wave are six rounds one after
+    // the other while three waves watch.
+    const bool by_symbols = PS > 128;
+
+    // ---- row by row, all preambles: cur[q] = the first hit of list q not sliced yet (workgroup-uniform) ----
+    uint32_t cur[kMaxPre];
+#pragma unroll
+    for (int q = 0; q < kMaxPre; ++q) cur[q] = 0;
+    for (;;) {
+        uint32_t l0 = 0xffffffffu;                       // the lowest row any list still has a hit in
+#pragma unroll
+        for (int q = 0; q < kMaxPre; ++q) {
+            if (q >= (int)q_hi) break;
+            if (q < (int)q_lo) continue;
+            while (cur[q] < s_cnt[q] && a.staging[((size_t)T * n_pre + q) * a.cap + cur[q]] >= bad) cur[q] += 1;   // defensive
+            if (cur[q] < s_cnt[q]) {
+                const uint32_t r = a.staging[((size_t)T * n_pre + q) * a.cap + cur[q]] >> lg_bs;
+                l0 = r < l0 ? r : l0;
+            }
+        }
+        if (l0 == 0xffffffffu) break;
+        __syncthreads();                                                        // the previous row set has been consumed
+        for (uint32_t t = threadIdx.x; t < n_rows * cpr; t += 256) {
+            const uint32_t c = t / n_rows, r = t - c * n_rows, row = l0 + r;     // neighbouring threads: neighbouring rows of one chunk
+            const uint4 x = *reinterpret_cast<const uint4 *>(tbase + ((size_t)(row >> 6) << lg_tw) + ((size_t)c << 8) + ((row & 63) << 2));
+            *reinterpret_cast<uint4 *>(rows_lds + r * wpb + c * 4) = x;
+        }
+        __syncthreads();
+        const uint32_t base_bit = l0 << lg_bs;                                    // stream bit (tile-local) of rows_lds[0], bit 31
+        const uint32_t lim = (l0 + 1) << lg_bs;
+#pragma unroll 1
+        for (uint32_t q = q_lo; q < q_hi; ++q) {
+            const uint32_t cnt = s_cnt[q];
+            const uint32_t *src = a.staging + ((size_t)T * n_pre + q) * a.cap;
+            uint32_t i_lo = 0;
+#pragma unroll
+            for (int qq = 0; qq < kMaxPre; ++qq) i_lo = q == (uint32_t)qq ? cur[qq] : i_lo;
+            if (i_lo >= cnt || src[i_lo] >= lim) continue;
+            // end of this list's hits that start in row l0 (positions ascend): binary search, the same loads in every thread
+            uint32_t lo = i_lo + 1, hi = cnt;
+            while (lo < hi) {
+                const uint32_t mid = (lo + hi) >> 1;
+                if (src[mid] < lim) lo = mid + 1; else hi = mid;
+            }
+            const uint32_t i_hi = lo;
+#pragma unroll
+            for (int qq = 0; qq < kMaxPre; ++qq) cur[qq] = q == (uint32_t)qq ? i_hi : cur[qq];
+            const uint64_t off = s_off[q] + s_in[q];
+            for (uint32_t i0 = i_lo + (by_symbols ? 0u : wv * 64); i0 < i_hi; i0 += by_symbols ? 64u : 256u) {
+                const uint32_t i = i0 + lane;
+                const bool have = i < i_hi;
+                const uint32_t local = have ? src[i] : 0xffffffffu;
+                const bool ok = have && local < bad;
+                if (ok && (!by_symbols || wv == (((i0 - i_lo) >> 6) & 3u))) {
+                    const int64_t n = ((int64_t)T * 64 - 64) * (int64_t)g.block_size + local;
+                    const uint64_t pos = (uint64_t)(n + g.packet_length);
+                    hit_block[off + i] = a.block_base + (pos >> lg_bs);
+                    hit_idx[off + i] = (uint32_t)pos & bs_mask;
+                }
+                const uint32_t key = ok ? local >> 5 : 0xffffffffu;
+                const uint32_t prev = __shfl_up(key, 1);
+                uint64_t leaders = __ballot(ok && (lane == 0 || key != prev));
+                while (leaders) {
+                    uint32_t v0[kK3Batch], slot[kK3Batch];
+                    int nb = 0;
+#pragma unroll
+                    for (int e = 0; e < kK3Batch; ++e) {
+                        v0[e] = 0; slot[e] = 0xffffffffu;
+                        if (leaders) {                                         // wave-uniform
+                            const uint32_t L = (uint32_t)__ffsll((unsigned long long)leaders) - 1;
+                            leaders &= leaders - 1;
+                            const uint32_t key_s = __builtin_amdgcn_readlane(key, L);
+                            if (lane < 32) tab[wv][e][lane] = 0xffffffffu;
+                            if (ok && key == key_s) tab[wv][e][local & 31] = i;   // same wave: LDS operations execute in order
+                            slot[e] = tab[wv][e][31 - l32];                    // lane c of a block ends up with position 31-c
+                            v0[e] = (key_s << 5) - base_bit;                   // first bit of the word, counted from the staged rows
+                            nb = e + 1;
+                        }
+                    }
+                    // two 64-symbol steps of up to four words per round; long packets: the rounds are dealt to the four waves
+                    for (uint32_t p0 = by_symbols ? wv * 128 : 0u; p0 < PS; p0 += by_symbols ? 512u : 128u) {
+#pragma unroll
+                        for (int e = 0; e < kK3Batch; ++e)
+#pragma unroll
+                            for (int k = 0; k < 2; ++k) {
+                                if (e >= nb || p0 + 64 * k >= PS) continue;
+                                const uint32_t sy = p0 + 64 * k + sym_lane;
+                                const uint32_t v = v0[e] + (sy < PS ? sy : PS - 1) * SL;   // window = 32 stream bits from bit v
+                                const uint32_t A = rows_lds[v >> 5], B = rows_lds[(v >> 5) + 1];
+                                const uint32_t W = (v & 16) ? __builtin_amdgcn_alignbit(A, B, 16) : A;
+                                const uint32_t Y = k3_transpose32(W, lane);
+                                const uint32_t b0 = (p0 + 64 * k) / 8 + half * 4;   // first packet byte of this lane's dword
+                                if (slot[e] != 0xffffffffu && b0 < PB) {
+                                    uint8_t *out = pkt + (off + slot[e]) * (uint64_t)PB;
+                                    if (b0 + 4 <= PB && dword_ok) {
+                                        *reinterpret_cast<uint32_t *>(out + b0) = Y;
+                                    } else {
+#pragma unroll
+                                        for (uint32_t j = 0; j < 4; ++j) {
+                                            const uint32_t bj = b0 + j;
+                                            if (bj < PB) {
+                                                uint32_t byte = (Y >> (8 * j)) & 0xffu;
+                                                const uint32_t valid = PS - bj * 8;
+                                                if (valid < 8) byte >>= (8 - valid);   // PacketSymbols % 8 != 0: right-aligned like Go's shift-in
+                                                out[bj] = (uint8_t)byte;
+                                            }
+                                        }
+                                    }
+                                }
+                            }
+                    }
+                }
+            }
+        }
+    }
+}
+
+// last kernel of a batch whose K3 (K4, K5) ran on the second stream: publishes the batch ticket
+__global__ void k_done(uint64_t *flag, uint64_t value, uint64_t *dev_flag)
+{
+    __hip_atomic_store(dev_flag, value, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);   // k_hist_update of the next batch waits here
+    __hip_atomic_store(flag, value, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
+// Tests: tiled rows 64.. -> linear MSB-first byte stream (decode.go:259-265 packing).
+__global__ void k_untile(const uint32_t *qt, uint32_t *out, uint32_t n_blocks, uint32_t lg_wpb)
+{
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const uint64_t n = (uint64_t)n_blocks << lg_wpb;
+    if (i >= n) return;
+    const uint64_t R = 64 + (i >> lg_wpb);
+    const uint32_t w = (uint32_t)i & ((1u << lg_wpb) - 1);
+    const uint32_t v = qt[qt_index(R, w, lg_wpb)];
+    out[i] = __builtin_bswap32(v);
+}
+
+}  // namespace amr

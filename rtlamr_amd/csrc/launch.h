@@ -1,0 +1,27 @@
+// Kernel launchers, one translation unit per kernel family so that the library builds in parallel (make -j): the
+// template instantiations (ten chip lengths of K1, 40 variants of the walk search) are what takes the compile time.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
+
+#include "k1_demod.h"
+#include "k2_common.h"
+
+namespace amr {
+
+// K1 for one chip length (flags.go:127-132); false: not a legal chip length
+bool launch_k1(int chip_length, bool tail, dim3 grid, hipStream_t st, const K1Args &a, hipEvent_t start, hipEvent_t stop);
+
+// K2, the walk search (k2_walk.h) for the set of rtlamr's preambles given as a mask (bit k = kind k of k2_walk_kind_of).
+// false: no kernel for this SymbolLength (nothing launched)
+bool launch_k2_walk(uint32_t symbol_length, uint32_t set, uint32_t grid, size_t lds_bytes, hipStream_t st, hipEvent_t start, hipEvent_t stop,
+                    const K2Args &a, hipError_t *err);
+// which of rtlamr's four preambles (k2_walk.h) a registered preamble is, -1: none
+int k2_walk_kind_of(uint32_t len, uint64_t bits);
+// K2 fallbacks (k2_search.h): list-based for up to four short preambles / short rows, dense for everything else
+bool launch_k2_fast(uint32_t n_pre, int nwv, uint32_t grid, size_t lds_bytes, hipStream_t st, hipEvent_t start, hipEvent_t stop,
+                    const K2Args &a, hipError_t *err);
+void launch_k2_dense(uint32_t grid, size_t lds_bytes, hipStream_t st, hipEvent_t start, hipEvent_t stop, const K2Args &a,
+                     hipError_t *err);
+
+}  // namespace amr

@@ -2,9 +2,10 @@
 (round 2's AMR_K1_IMPL / AMR_K2_IMPL / AMR_K3_IMPL / AMR_TAIL_MODE / AMR_TAIL_OVERLAP / AMR_HIST_FOLD are gone); which
 kernel runs follows from the geometry alone:
   K1   k1t_demod (register tile) for chip <= 72, k1_demod for chip 80 / 88 / 96
-  K2   k2_search_stream for rows of 64..256 words with up to four preambles of at least 10 / 12 symbols;
-       k2_search_fast for shorter rows (BlockSize 512: chip 8); k2_search_dense for more than four preambles, rows under
-       16 words, and as the overflow fallback (test hook AMR_DENSE_SEARCH, read at amr_create)
+  K2   k2_search_walk<SymbolLength, set> for every set of rtlamr's own preambles (scm, scm+, idm / netidm, r900) at every
+       BlockSize from 512 to 8192; k2_search_fast when a set holds any other preamble (a custom protocol entry), up to
+       four; k2_search_dense for more than four preambles, rows under 16 words, and as the overflow fallback (test hook
+       AMR_DENSE_SEARCH, read at amr_create)
 and the state update rides inside whichever search kernel a pipelined batch uses.  Each combination, three batches in
 flight with ragged sizes, against the oracle."""
 import ctypes as C
@@ -57,12 +58,13 @@ def _pipeline(dec, iq, sizes, depth=3):
 
 
 @pytest.mark.parametrize("protos,chip,dense", [
-    (["scm"], 72, False),                            # k1t_demod + k2_search_stream<144, 10, 4>
-    (["scm", "scm+", "idm", "r900"], 72, False),     # four preambles, rows of 256 words
-    (["scm"], 8, False),                             # k2_search_fast (rows of 16 words)
+    (["scm"], 72, False),                            # k1t_demod + k2_search_walk<144, scm>
+    (["scm", "scm+", "idm", "r900"], 72, False),     # all four preambles, rows of 256 words
+    (["r900", "scm+"], 56, False),                   # a two-preamble set, registration order != the kernel's kind order
+    (["scm"], 8, False),                             # rows of 16 words
     (["scm"], 88, False),                            # k1_demod
     (["scm", "idm"], 72, True),                      # k2_search_dense everywhere (AMR_DENSE_SEARCH)
-], ids=["stream", "stream-4pre", "fast-chip8", "k1-first-gen", "dense"])
+], ids=["walk", "walk-4pre", "walk-2pre-order", "walk-chip8", "k1-first-gen", "dense"])
 def test_three_deep_pipeline_with_every_search_kernel(protos, chip, dense, monkeypatch):
     if dense:
         monkeypatch.setenv("AMR_DENSE_SEARCH", "1")
@@ -80,9 +82,11 @@ def test_three_deep_pipeline_with_every_search_kernel(protos, chip, dense, monke
         dec.close()
 
 
-def test_more_than_four_preambles_go_through_the_dense_kernel():
-    """Five distinct preambles (custom protocol entries next to the rtlamr ones): the stream and list kernels hold four,
-    the dense kernel takes over -- pipelined, so the state update rides inside it."""
+@pytest.mark.parametrize("extra", [["1100110011110000"], ["1100110011110000", "101100111000111100001"]], ids=["fast", "dense"])
+def test_custom_preambles_go_through_the_fallback_kernels(extra):
+    """Custom protocol entries next to the rtlamr ones: the walk kernel knows rtlamr's four preambles only.  One custom
+    preamble (four in all) -> the list kernel k2_search_fast; two (five in all) -> k2_search_dense.  Pipelined, so the
+    state update rides inside either."""
     from rtlamr_amd.protocol import PacketConfig, Parser
 
     class Custom(Parser):
@@ -93,7 +97,6 @@ def test_more_than_four_preambles_go_through_the_dense_kernel():
         def Parse(self, pkts): return []
 
     chip = 72
-    extra = ["1100110011110000", "101100111000111100001"]
     dec = ra.new_decoder()
     for name in ("scm", "scm+", "idm"):
         dec.RegisterProtocol(ra.new_parser(name, chip))
@@ -101,7 +104,7 @@ def test_more_than_four_preambles_go_through_the_dense_kernel():
         dec.RegisterProtocol(Custom(pre, chip))
     dec.Allocate()
     try:
-        assert dec.n_preambles == 5
+        assert dec.n_preambles == 3 + len(extra)
         protos = ["scm", "scm+", "idm"] + [(pre, len(pre), 96) for pre in extra]
         iq, _ = util.synth_stream(["scm", "scm+", "idm"], chip, sum(SIZES), dec.Cfg.BlockSize, 17, 8)
         o = OracleDecoder(protos, chip)
