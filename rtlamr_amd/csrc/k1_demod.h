@@ -191,6 +191,9 @@ __device__ __forceinline__ void k1_prefetch(const K1Args &a, uint32_t lds_base, 
     if (!TAIL && !carry_tile) {
         const uint8_t *base = sb;                                   // uniform
         uint32_t m0v = lds_base + buf_off;
+        // (Tried: when the first half of tile 0's line holds none of the 4 * CL halo bytes -- chip 8: 32 needed of 128 --
+        // let the lanes of that half sit the DMA out.  Bit-exact, and not a microsecond faster at any chip length: a miss
+        // brings the whole 128-byte line whatever part of it is asked for.)
 #pragma unroll 1
         for (int q = 0; q < 4; ++q) {                               // a rolled loop: this code sits in every group
             asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1 " AMR_K1_LDFLAGS

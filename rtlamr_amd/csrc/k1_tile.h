@@ -53,16 +53,27 @@ __device__ unsigned long long k1t_timeline[2 * 8192];   // harness only: 100 MHz
 //        priority 0 / 1 every tile / 4 tiles / 16 tiles (the wave in the odd slot starts high).  5: priority 2 from the
 //        wait for the next tile to the issue of the following DMA (the memory-critical stretch), 0 otherwise; 6 = 5 on
 //        top of the per-tile swap of 2 (levels 0 / 1, boundary 3).  10 + k: swap every 2^k tiles.
-template <int SCHED_, int DEPTH_, int XCD_, int NW_, int DIAG_ = 0, int STPOL_ = 0, int STORE_AFTER_ = 0, int NLC_ = 0, int PRIO_ = 0>
+// HDL    slots of the hd ring that live in LDS instead of registers (chip length 80 / 88: rings of 96 slots do not fit
+//        256 VGPRs next to the register tile; a value of the ring is written once and read once, chip-length steps
+//        later, so a third of the ring -- the slots at the ring's upper end -- goes through LDS: two ds_write_b128 when
+//        a group of 8 is produced, two ds_read_b128 one ring turn minus a chip later, fetched next to the LUT gathers).
+//        Costs parking space: 8 KiB of hd leave 3 KiB for output chunks, i.e. four store bursts per 4096-sample block.
+template <int SCHED_, int DEPTH_, int XCD_, int NW_, int DIAG_ = 0, int STPOL_ = 0, int STORE_AFTER_ = 0, int NLC_ = 0, int PRIO_ = 0, int HDL_ = 0>
 struct K1TCfg {
-    static constexpr int SCHED = SCHED_, DEPTH = DEPTH_, XCD = XCD_, NW = NW_, DIAG = DIAG_, STPOL = STPOL_, STORE_AFTER = STORE_AFTER_, NLC = NLC_, PRIO = PRIO_;
+    static constexpr int SCHED = SCHED_, DEPTH = DEPTH_, XCD = XCD_, NW = NW_, DIAG = DIAG_, STPOL = STPOL_, STORE_AFTER = STORE_AFTER_, NLC = NLC_, PRIO = PRIO_, HDL = HDL_;
     static constexpr int CAP = NLC_ + NW_ / 4 + 1;               // chunks per full burst (LDS, registers, staging)
     static constexpr uint32_t kLut = DEPTH_ * kTileBuf;          // LDS byte offset of the LUT behind the tile buffer(s)
     static constexpr uint32_t kPark = DEPTH_ * kTileBuf + 1024;  // parked output chunks: chunk c of lane l at kPark + c * 1024 + l * 16
-    static constexpr uint32_t kLds = DEPTH_ * kTileBuf + 1024 + NLC_ * 1024;   // dynamic LDS bytes per workgroup
+    static constexpr uint32_t kHd = kPark + NLC_ * 1024;         // hd slots in LDS: slots 4j..4j+3 of lane l at kHd + j * 1024 + l * 16
+    static constexpr uint32_t kLds = kHd + HDL_ * 256;           // dynamic LDS bytes per workgroup
     static constexpr uint32_t kFlip = DEPTH_ == 2 ? kTileBuf : 0; // toggles U.par between the buffers
+    static_assert(HDL_ % 8 == 0 && kLds <= 20 * 1024, "20 KiB of LDS per wave at 8 waves per CU");
 };
-typedef K1TCfg<0, 1, 1, 16, 0, 1, 1, 11, 13> K1TDefault;
+typedef K1TCfg<0, 1, 1, 16, 0, 1, 1, 11, 13> K1TDefault;            // chip length <= 72
+typedef K1TCfg<0, 1, 1, 16, 0, 1, 1, 3, 13, 32> K1TLongChip;        // chip length 80 / 88: rings of 96, 32 hd slots in LDS
+template <int CL> struct K1TCfgFor { typedef K1TDefault type; };
+template <> struct K1TCfgFor<80> { typedef K1TLongChip type; };
+template <> struct K1TCfgFor<88> { typedef K1TLongChip type; };
 
 constexpr int k1t_gcd(int a, int b) { return b == 0 ? a : k1t_gcd(b, a % b); }
 
@@ -76,10 +87,11 @@ struct K1TGeom {
     static constexpr int NPT = HBA / kTileBytes;       // halo tiles
     // csum rings: slot t % RING is written at step t and holds c[t] / d[t] until step t + CL reads it.  RING is the
     // smallest multiple of 8 above CL whose super-body stays small (chip 64: 80, not 72 -> 5 tiles instead of 9).
-    static constexpr int RING = (CL == 64) ? 80 : CL + 8;
+    static constexpr int RING = (CL == 64) ? 80 : (CL == 80) ? 96 : CL + 8;
     static constexpr int SPB = RING / k1t_gcd(RING, 64) * 64;   // samples per super-body
     static constexpr int TPS = SPB / 64;                         // tiles per super-body
-    static constexpr bool supported = (TPS <= 7) && (2 * RING <= 160);
+    static constexpr int HDL = K1TCfgFor<CL>::type::HDL;        // hd slots in LDS (the ring's upper end)
+    static constexpr bool supported = (TPS <= 7) && (2 * RING - HDL <= 160);
 };
 
 typedef const __attribute__((address_space(3))) float *k1t_lds_f;
@@ -90,7 +102,8 @@ template <int CL, class C>
 struct K1TLane {
     using G = K1TGeom<CL>;
     float hc[G::RING];   // hc[t % RING] = c[t], running sum after sample t (decode.go:234)
-    float hd[G::RING];   // hd[t % RING] = c[t] - c[t-CL]
+    float hd[G::RING - C::HDL > 0 ? G::RING - C::HDL : 1];   // hd[t % RING] = c[t] - c[t-CL]; slots >= RING - HDL live in LDS
+    float hdt[C::HDL ? 8 : 1];   // the eight hd values of the current group when they come from LDS
     uint32_t tl[32];     // the staging tile of this lane's row: 128 B = 64 IQ samples
     float lv[16];        // LUT values of 8 samples (lut[I], lut[Q] interleaved)
     uint32_t acc, prev;  // sign bits of f, newest in bit 0 (inverted decisions); acc at the last word boundary
@@ -142,6 +155,8 @@ __device__ __forceinline__ void k1t_arith(K1TLane<CL, C> &L, int rb, int n, int 
         for (int j = 0; j < 2 * n; ++j) L.acc ^= __float_as_uint(L.lv[lv0 + j]);
         return;
     }
+    constexpr int RR = R - C::HDL;                                     // hd slots below RR are registers, the rest LDS
+    float dn[8];                                                       // the group's new d values bound for LDS
 #pragma unroll
     for (int j = 0; j < n; ++j) {
         const int r = (rb + j) % R, rp = (r + R - 1) % R, ro = (r + R - CL) % R;
@@ -149,10 +164,40 @@ __device__ __forceinline__ void k1t_arith(K1TLane<CL, C> &L, int rb, int n, int 
         if (PRED) m = (sidx + j < zlim) ? 0.0f : m;
         const float c = L.hc[rp] + m;                                  // decode.go:234
         const float d = c - L.hc[ro];                                  // csum[i+SL]-csum[i+CL]   (decode.go:242)
-        const float f = L.hd[ro] - d;                                  // (csum[i+CL]-csum[i]) - d
+        const float dold = (C::HDL && ro >= RR) ? L.hdt[j] : L.hd[ro < RR ? ro : 0];   // csum[i+CL]-csum[i], one ring turn old
+        const float f = dold - d;                                      // (csum[i+CL]-csum[i]) - d
         L.acc = __builtin_amdgcn_alignbit(L.acc, __float_as_uint(f), 31);   // decode.go:243, inverted
         L.hc[r] = c;
-        L.hd[r] = d;
+        if (C::HDL && r >= RR) dn[j] = d; else L.hd[r < RR ? r : 0] = d;
+    }
+    if constexpr (C::HDL > 0) {
+        // groups are 8-aligned and so is the LDS part of the ring: a group's eight new values go out together
+        if (n == 8 && rb % R >= RR) {
+            typedef float v4f __attribute__((ext_vector_type(4)));
+            typedef __attribute__((address_space(3))) v4f *lds_v4f;
+            const uint32_t base = C::kHd + (uint32_t)((rb % R - RR) / 4) * 1024 + threadIdx.x * 16;
+            *(lds_v4f)(uintptr_t)base = v4f{dn[0], dn[1], dn[2], dn[3]};
+            *(lds_v4f)(uintptr_t)(base + 1024) = v4f{dn[4], dn[5], dn[6], dn[7]};
+        }
+    }
+}
+
+// the eight hd values the group at ring slot rb will read (slots rb - CL ...), when they live in LDS: issued next to the
+// group's LUT gathers, consumed by k1t_arith
+template <int CL, class C>
+__device__ __forceinline__ void k1t_hd_fetch(K1TLane<CL, C> &L, int rb)
+{
+    if constexpr (C::HDL > 0) {
+        constexpr int R = K1TGeom<CL>::RING, RR = R - C::HDL;
+        const int ro = (rb % R + R - CL) % R;
+        if (ro >= RR) {
+            typedef float v4f __attribute__((ext_vector_type(4)));
+            typedef const __attribute__((address_space(3))) v4f *lds_v4f;
+            const uint32_t base = C::kHd + (uint32_t)((ro - RR) / 4) * 1024 + threadIdx.x * 16;
+            const v4f a = *(lds_v4f)(uintptr_t)base, b = *(lds_v4f)(uintptr_t)(base + 1024);
+            L.hdt[0] = a.x; L.hdt[1] = a.y; L.hdt[2] = a.z; L.hdt[3] = a.w;
+            L.hdt[4] = b.x; L.hdt[5] = b.y; L.hdt[6] = b.z; L.hdt[7] = b.w;
+        }
     }
 }
 
@@ -313,6 +358,7 @@ __device__ __forceinline__ bool k1t_tile(K1TLane<CL, C> &L, K1TUni &U, const K1A
     for (int g = 0; g < 8; ++g) {
         const bool skip = WARMUP && (TI * 64 + g * 8 + 8 <= G::SKIP);     // static: samples before the reference's window
         if (!skip) k1t_gather<CL, C>(L, g * 8, 8, 0);
+        if (!skip) k1t_hd_fetch<CL, C>(L, (RB0 + g * 8) % R);
         if (g == 7 && more) {
             // every tile register is dead now.  Outstanding VMEM in issue order: DMA(t+1), the store burst of the
             // previous boundary, DMA(t+2): vmcnt(8) leaves at most DMA(t+2)'s eight pieces in flight.
@@ -442,7 +488,15 @@ __global__ __launch_bounds__(64, 2) void k1t_demod(const K1Args a)
 
     K1TLane<CL, C> L;
 #pragma unroll
-    for (int r = 0; r < G::RING; ++r) { L.hc[r] = 0.0f; L.hd[r] = 0.0f; }
+    for (int r = 0; r < G::RING; ++r) L.hc[r] = 0.0f;
+#pragma unroll
+    for (int r = 0; r < G::RING - C::HDL; ++r) L.hd[r] = 0.0f;
+    if constexpr (C::HDL > 0) {                       // the ring starts from zeros, its LDS part too
+        typedef float v4f __attribute__((ext_vector_type(4)));
+        typedef __attribute__((address_space(3))) v4f *lds_v4f;
+#pragma unroll
+        for (int j = 0; j < C::HDL / 4; ++j) *(lds_v4f)(uintptr_t)(C::kHd + j * 1024 + lane * 16) = v4f{0.f, 0.f, 0.f, 0.f};
+    }
     L.acc = 0; L.prev = 0; L.xs = 0;
 
     K1TUni U;

@@ -69,7 +69,11 @@ static const Variant kVariants[] = {
 #define W(S, P, X, N, POL, AFT) {"s" #S "p" #P "x" #X "n" #N "w" #POL "a" #AFT, launch_tile<amr::K1TCfg<S, P, X, N, 0, POL, AFT>>},
 #define L(S, P, X, N, POL, AFT, NLC) {"s" #S "p" #P "x" #X "n" #N "w" #POL "a" #AFT "l" #NLC, launch_tile<amr::K1TCfg<S, P, X, N, 0, POL, AFT, NLC>>},
 #define P(S, P_, X, N, POL, AFT, NLC, PR) {"s" #S "p" #P_ "x" #X "n" #N "w" #POL "a" #AFT "l" #NLC "r" #PR, launch_tile<amr::K1TCfg<S, P_, X, N, 0, POL, AFT, NLC, PR>>},
+#define H(S, P_, X, N, POL, AFT, NLC, PR, HD) {"s" #S "p" #P_ "x" #X "n" #N "w" #POL "a" #AFT "l" #NLC "r" #PR "h" #HD, launch_tile<amr::K1TCfg<S, P_, X, N, 0, POL, AFT, NLC, PR, HD>>},
+#define T(NAME, ...) {#NAME, launch_tile<amr::K1TCfg<__VA_ARGS__>>},     /* any configuration, named freely */
     K1B_VARIANTS
+#undef T
+#undef H
 #undef P
 #undef V
 #undef D
