@@ -88,12 +88,112 @@ __device__ __forceinline__ uint32_t k3_wave_scan(uint32_t x)
 
 constexpr int kK3Batch = 4;    // words (entries) a wave works on together
 
+// 64 hits of one list (src[i0 .. i0 + 64) below i_hi) by one wave: their (call, idx) records and the packets of every word
+// that holds some of them.  STAGED: the windows come from rows_lds (stream order, bit 31 of word 0 = tile-local bit
+// base_bit), else from the tiled bitstream at tbase.  Symbols [p_first, PS) in steps of 128 (p_step).
+template <bool STAGED>
+__device__ __forceinline__ void k3_chunk(const K3Args &a, const SearchGeom &g, uint32_t T, const uint32_t *src, uint32_t i0, uint32_t i_hi,
+                                         uint32_t i_lo, uint32_t wv, uint64_t off, uint64_t total, uint32_t (&tab)[kK3Batch][32],
+                                         const uint32_t *rows_lds, const uint32_t *__restrict__ tbase, uint32_t base_bit,
+                                         uint32_t p_first, bool by_symbols)
+{
+    const uint32_t lane = threadIdx.x & 63, l32 = lane & 31, half = lane >> 5;
+    const uint32_t lg_bs = g.lg_block_size, bs_mask = g.block_size - 1, lg_tw = 6 + g.lg_wpb;
+    const uint32_t PS = g.packet_symbols, SL = g.symbol_length, PB = g.pkt_bytes;
+    const bool dword_ok = (PB & 3) == 0 && (PS & 7) == 0;
+    // symbol offset of this lane inside a 64-symbol step: the 32 lanes of a block take the symbols bit-reversed
+    // within every byte, so that bit i of the transposed dword is the symbol Decoder.Slice puts into bit i
+    const uint32_t sym_lane = half * 32 + ((l32 & ~7u) | (7u - (l32 & 7u)));
+    const uint32_t bad = 64u << lg_bs;                 // defensive: never index the bitstream with a bad position
+    uint64_t *hit_block = reinterpret_cast<uint64_t *>(a.out);
+    uint32_t *hit_idx = reinterpret_cast<uint32_t *>(a.out + total * 8);
+    uint8_t *pkt = a.out + total * 12;
+    auto word_at = [&](uint32_t v) {                   // bitstream word holding bit v (counted from row 0 of tile T)
+        const uint32_t row = v >> lg_bs, w = (v & bs_mask) >> 5;
+        return tbase[((row >> 6) << lg_tw) + ((w >> 2) << 8) + ((row & 63) << 2) + (w & 3)];
+    };
+    const uint32_t i = i0 + lane;
+    const bool have = i < i_hi;
+    const uint32_t local = have ? src[i] : 0xffffffffu;
+    const bool ok = have && local < bad;
+    if (ok && (!by_symbols || wv == (((i0 - i_lo) >> 6) & 3u))) {      // by symbols: four waves see the chunk, one writes
+        const int64_t n = ((int64_t)T * 64 - 64) * (int64_t)g.block_size + local;
+        const uint64_t pos = (uint64_t)(n + g.packet_length);
+        hit_block[off + i] = a.block_base + (pos >> lg_bs);
+        hit_idx[off + i] = (uint32_t)pos & bs_mask;
+    }
+    const uint32_t key = ok ? local >> 5 : 0xffffffffu;
+    const uint32_t prev = __shfl_up(key, 1);
+    uint64_t leaders = __ballot(ok && (lane == 0 || key != prev));
+    while (leaders) {
+        uint32_t v0[kK3Batch], slot[kK3Batch];
+        int nb = 0;
+#pragma unroll
+        for (int e = 0; e < kK3Batch; ++e) {
+            v0[e] = 0; slot[e] = 0xffffffffu;
+            if (leaders) {                                         // wave-uniform
+                const uint32_t L = (uint32_t)__ffsll((unsigned long long)leaders) - 1;
+                leaders &= leaders - 1;
+                const uint32_t key_s = __builtin_amdgcn_readlane(key, L);
+                if (lane < 32) tab[e][lane] = 0xffffffffu;
+                if (ok && key == key_s) tab[e][local & 31] = i;    // same wave: LDS operations execute in order
+                slot[e] = tab[e][31 - l32];                        // lane c of a block ends up with position 31-c
+                v0[e] = (key_s << 5) - base_bit;                   // first bit of the word (STAGED: counted from the staged rows)
+                nb = e + 1;
+            }
+        }
+        // two 64-symbol steps of up to four words per round (their loads are in flight together)
+        for (uint32_t p0 = p_first; p0 < PS; p0 += by_symbols ? 512u : 128u) {
+            uint32_t A[kK3Batch][2], B[kK3Batch][2];
+#pragma unroll
+            for (int e = 0; e < kK3Batch; ++e)
+#pragma unroll
+                for (int k = 0; k < 2; ++k) {
+                    A[e][k] = 0; B[e][k] = 0;
+                    if (e < nb && p0 + 64 * k < PS) {
+                        const uint32_t sy = p0 + 64 * k + sym_lane;
+                        const uint32_t v = v0[e] + (sy < PS ? sy : PS - 1) * SL;   // window = 32 stream bits from bit v
+                        if (STAGED) { A[e][k] = rows_lds[v >> 5]; B[e][k] = rows_lds[(v >> 5) + 1]; }
+                        else { A[e][k] = word_at(v); B[e][k] = word_at(v + 32); }
+                    }
+                }
+#pragma unroll
+            for (int e = 0; e < kK3Batch; ++e)
+#pragma unroll
+                for (int k = 0; k < 2; ++k) {
+                    if (e >= nb || p0 + 64 * k >= PS) continue;
+                    const uint32_t sy = p0 + 64 * k + sym_lane;
+                    const uint32_t W = ((sy < PS ? sy : PS - 1) * SL & 16) ? __builtin_amdgcn_alignbit(A[e][k], B[e][k], 16) : A[e][k];
+                    const uint32_t Y = k3_transpose32(W, lane);
+                    const uint32_t b0 = (p0 + 64 * k) / 8 + half * 4;   // first packet byte of this lane's dword
+                    if (slot[e] != 0xffffffffu && b0 < PB) {
+                        uint8_t *out = pkt + (off + slot[e]) * (uint64_t)PB;
+                        if (b0 + 4 <= PB && dword_ok) {
+                            *reinterpret_cast<uint32_t *>(out + b0) = Y;
+                        } else {
+#pragma unroll
+                            for (uint32_t j = 0; j < 4; ++j) {
+                                const uint32_t bj = b0 + j;
+                                if (bj < PB) {
+                                    uint32_t byte = (Y >> (8 * j)) & 0xffu;
+                                    const uint32_t valid = PS - bj * 8;
+                                    if (valid < 8) byte >>= (8 - valid);   // PacketSymbols % 8 != 0: right-aligned like Go's shift-in
+                                    out[bj] = (uint8_t)byte;
+                                }
+                            }
+                        }
+                    }
+                }
+        }
+    }
+}
+
 __global__ __launch_bounds__(256) void k3_slice_words(const K3Args a)
 {
     const SearchGeom &g = a.g;
     const uint32_t T = blockIdx.x;
     const uint32_t n_pre = g.n_pre;
-    const uint32_t lane = threadIdx.x & 63, wv = threadIdx.x >> 6, l32 = lane & 31, half = lane >> 5;
+    const uint32_t lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     __shared__ uint64_t s_off[kMaxPre + 1];     // slot of this tile's list per preamble; [n_pre] = the grand total
     __shared__ uint32_t s_cnt[kMaxPre];
     __shared__ uint32_t s_in[kMaxPre];          // hits of the tile's group in front of the tile, per preamble
@@ -159,25 +259,30 @@ __global__ __launch_bounds__(256) void k3_slice_words(const K3Args a)
     for (uint32_t q = q_lo; q < q_hi; ++q) any |= s_cnt[q];
     if (!any) return;
 
-    uint64_t *hit_block = reinterpret_cast<uint64_t *>(a.out);
-    uint32_t *hit_idx = reinterpret_cast<uint32_t *>(a.out + total * 8);
-    uint8_t *pkt = a.out + total * 12;
     const uint32_t *__restrict__ tbase = a.qt + ((size_t)T << (6 + g.lg_wpb));
-    const uint32_t lg_bs = g.lg_block_size, bs_mask = g.block_size - 1, lg_tw = 6 + g.lg_wpb;
-    const uint32_t PS = g.packet_symbols, SL = g.symbol_length, PB = g.pkt_bytes;
-    const bool dword_ok = (PB & 3) == 0 && (PS & 7) == 0;
-    // symbol offset of this lane inside a 64-symbol step: the 32 lanes of a block take the symbols bit-reversed
-    // within every byte, so that bit i of the transposed dword is the symbol Decoder.Slice puts into bit i
-    const uint32_t sym_lane = half * 32 + ((l32 & ~7u) | (7u - (l32 & 7u)));
+    const uint32_t lg_bs = g.lg_block_size, lg_tw = 6 + g.lg_wpb;
+    const uint32_t PS = g.packet_symbols, SL = g.symbol_length;
     const uint32_t bad = 64u << lg_bs;                 // defensive: never index the bitstream with a bad position
     const uint32_t wpb = g.wpb, cpr = wpb >> 2;
     const uint32_t n_rows = 1 + ((PS * SL + 32 + g.block_size - 1) >> lg_bs);     // rows a hit-word's windows can touch
-    // The four waves share the work by hits (64 each) when a packet is short, by SYMBOLS when it is long: the hits of a
-    // packet are one run of ~70 positions, i.e. one wave's worth, and 736 symbols in one wave are six rounds one after
-    // the other while three waves watch.
-    const bool by_symbols = PS > 128;
+    const bool by_symbols = PS > 128;                  // long packets (idm, netidm, "all"): rows staged in LDS
 
-    // ---- row by row, all preambles: cur[q] = the first hit of list q not sliced yet (workgroup-uniform) ----
+    // ---- short packets (scm, scm+, r900 geometries: at most 128 symbols): the windows straight from the tiled bitstream.
+    // A packet's reach is a few KB of stream; staging rows for it costs more than the line fetches it saves (1 GiB of scm:
+    // 32 us staged against 16-25 us direct).
+    if (!by_symbols) {
+#pragma unroll 1
+        for (uint32_t q = q_lo; q < q_hi; ++q) {
+            const uint32_t cnt = s_cnt[q];
+            const uint32_t *src = a.staging + ((size_t)T * n_pre + q) * a.cap;
+            const uint64_t off = s_off[q] + s_in[q];
+            for (uint32_t i0 = wv * 64; i0 < cnt; i0 += 256)
+                k3_chunk<false>(a, g, T, src, i0, cnt, 0u, wv, off, total, tab[wv], nullptr, tbase, 0u, 0u, false);
+        }
+        return;
+    }
+
+    // ---- long packets, row by row: cur[q] = the first hit of list q not sliced yet (workgroup-uniform) ----
     uint32_t cur[kMaxPre];
 #pragma unroll
     for (int q = 0; q < kMaxPre; ++q) cur[q] = 0;
@@ -221,74 +326,14 @@ __global__ __launch_bounds__(256) void k3_slice_words(const K3Args a)
 #pragma unroll
             for (int qq = 0; qq < kMaxPre; ++qq) cur[qq] = q == (uint32_t)qq ? i_hi : cur[qq];
             const uint64_t off = s_off[q] + s_in[q];
-            for (uint32_t i0 = i_lo + (by_symbols ? 0u : wv * 64); i0 < i_hi; i0 += by_symbols ? 64u : 256u) {
-                const uint32_t i = i0 + lane;
-                const bool have = i < i_hi;
-                const uint32_t local = have ? src[i] : 0xffffffffu;
-                const bool ok = have && local < bad;
-                if (ok && (!by_symbols || wv == (((i0 - i_lo) >> 6) & 3u))) {
-                    const int64_t n = ((int64_t)T * 64 - 64) * (int64_t)g.block_size + local;
-                    const uint64_t pos = (uint64_t)(n + g.packet_length);
-                    hit_block[off + i] = a.block_base + (pos >> lg_bs);
-                    hit_idx[off + i] = (uint32_t)pos & bs_mask;
-                }
-                const uint32_t key = ok ? local >> 5 : 0xffffffffu;
-                const uint32_t prev = __shfl_up(key, 1);
-                uint64_t leaders = __ballot(ok && (lane == 0 || key != prev));
-                while (leaders) {
-                    uint32_t v0[kK3Batch], slot[kK3Batch];
-                    int nb = 0;
-#pragma unroll
-                    for (int e = 0; e < kK3Batch; ++e) {
-                        v0[e] = 0; slot[e] = 0xffffffffu;
-                        if (leaders) {                                         // wave-uniform
-                            const uint32_t L = (uint32_t)__ffsll((unsigned long long)leaders) - 1;
-                            leaders &= leaders - 1;
-                            const uint32_t key_s = __builtin_amdgcn_readlane(key, L);
-                            if (lane < 32) tab[wv][e][lane] = 0xffffffffu;
-                            if (ok && key == key_s) tab[wv][e][local & 31] = i;   // same wave: LDS operations execute in order
-                            slot[e] = tab[wv][e][31 - l32];                    // lane c of a block ends up with position 31-c
-                            v0[e] = (key_s << 5) - base_bit;                   // first bit of the word, counted from the staged rows
-                            nb = e + 1;
-                        }
-                    }
-                    // two 64-symbol steps of up to four words per round; long packets: the rounds are dealt to the four waves
-                    for (uint32_t p0 = by_symbols ? wv * 128 : 0u; p0 < PS; p0 += by_symbols ? 512u : 128u) {
-#pragma unroll
-                        for (int e = 0; e < kK3Batch; ++e)
-#pragma unroll
-                            for (int k = 0; k < 2; ++k) {
-                                if (e >= nb || p0 + 64 * k >= PS) continue;
-                                const uint32_t sy = p0 + 64 * k + sym_lane;
-                                const uint32_t v = v0[e] + (sy < PS ? sy : PS - 1) * SL;   // window = 32 stream bits from bit v
-                                const uint32_t A = rows_lds[v >> 5], B = rows_lds[(v >> 5) + 1];
-                                const uint32_t W = (v & 16) ? __builtin_amdgcn_alignbit(A, B, 16) : A;
-                                const uint32_t Y = k3_transpose32(W, lane);
-                                const uint32_t b0 = (p0 + 64 * k) / 8 + half * 4;   // first packet byte of this lane's dword
-                                if (slot[e] != 0xffffffffu && b0 < PB) {
-                                    uint8_t *out = pkt + (off + slot[e]) * (uint64_t)PB;
-                                    if (b0 + 4 <= PB && dword_ok) {
-                                        *reinterpret_cast<uint32_t *>(out + b0) = Y;
-                                    } else {
-#pragma unroll
-                                        for (uint32_t j = 0; j < 4; ++j) {
-                                            const uint32_t bj = b0 + j;
-                                            if (bj < PB) {
-                                                uint32_t byte = (Y >> (8 * j)) & 0xffu;
-                                                const uint32_t valid = PS - bj * 8;
-                                                if (valid < 8) byte >>= (8 - valid);   // PacketSymbols % 8 != 0: right-aligned like Go's shift-in
-                                                out[bj] = (uint8_t)byte;
-                                            }
-                                        }
-                                    }
-                                }
-                            }
-                    }
-                }
-            }
+            // the four waves share a 64-hit chunk by SYMBOLS: the hits of a packet are one run of ~70 positions, i.e. one
+            // wave's worth, and 736 symbols in one wave are six rounds one after the other while three waves watch
+            for (uint32_t i0 = i_lo; i0 < i_hi; i0 += 64)
+                k3_chunk<true>(a, g, T, src, i0, i_hi, i_lo, wv, off, total, tab[wv], rows_lds, tbase, base_bit, wv * 128, true);
         }
     }
 }
+
 
 // last kernel of a batch whose K3 (K4, K5) ran on the second stream: publishes the batch ticket
 __global__ void k_done(uint64_t *flag, uint64_t value, uint64_t *dev_flag)
