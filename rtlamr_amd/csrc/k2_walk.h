@@ -44,7 +44,11 @@ struct K2WGeom {
     static constexpr int RW = RC * 4;                               // ring size in words
 };
 
-constexpr int kK2WPrefetch = 5;           // chunks loaded ahead of their use
+#ifndef AMR_K2W_PF1
+#define AMR_K2W_PF1 5
+#endif
+constexpr int kK2WPrefetch = 5;           // chunks loaded ahead of their use (several preambles)
+constexpr int kK2WPrefetch1 = AMR_K2W_PF1; // ... one preamble: little arithmetic per group, the loads need more lead
 
 
 typedef uint32_t k2w_v4u __attribute__((ext_vector_type(4)));
@@ -234,7 +238,7 @@ __device__ __forceinline__ uint32_t k2w_wave_scan(uint32_t x)
 template <int SL, int SET>
 __global__ __launch_bounds__(64 * kK2WWaves) void k2_search_walk(const K2Args a)
 {
-    constexpr int PF = kK2WPrefetch;
+    constexpr int PF = (SET & (SET - 1)) == 0 ? kK2WPrefetch1 : kK2WPrefetch;
     using G = K2WGeom<SL, PF>;
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
 #if AMR_K2W_DBG
