@@ -10,7 +10,9 @@
 //	cp -r <this repo>/go/cmd/amdgolden  <rtlamr checkout>/cmd/amdgolden
 //	cd <rtlamr checkout> && go run ./cmd/amdgolden -repo <this repo>
 //
-// Output: <repo>/tests/golden/go_sample_bin.json and go_synth.json.  The
+// Output: <repo>/tests/golden/go_sample_bin.json and go_synth.json, and -- when
+// built with -tags amdgolden next to go/r900/amd_golden.go (see r900_golden.go)
+// -- go_r900_filter.json.  The
 // pytest suite picks them up when they exist (tests/test_go_golden.py):
 // oracle == Go on every hash, and, on the GPU box, HIP == Go.
 //
@@ -57,10 +59,12 @@ type refDecoder struct {
 	d   protocol.Decoder
 	lut protocol.MagLUT
 	pre [][]byte // distinct preambles as 0/1 bytes, in order of first registration = preamble id
+
+	parsers map[string]protocol.Parser // by protocol name (r900.go: the second-stage golden needs the parser itself)
 }
 
 func newRefDecoder(protos []string, chip int) *refDecoder {
-	r := &refDecoder{d: protocol.NewDecoder(), lut: protocol.NewMagLUT()}
+	r := &refDecoder{d: protocol.NewDecoder(), lut: protocol.NewMagLUT(), parsers: map[string]protocol.Parser{}}
 	seen := map[string]bool{}
 	for _, name := range protos {
 		p, err := protocol.NewParser(name, chip) // main.go:77
@@ -68,6 +72,7 @@ func newRefDecoder(protos []string, chip int) *refDecoder {
 			log.Fatal(err)
 		}
 		r.d.RegisterProtocol(p)
+		r.parsers[name] = p
 		s := p.Cfg().Preamble
 		if !seen[s] {
 			seen[s] = true
@@ -497,4 +502,7 @@ func main() {
 		fmt.Printf("%-24s hits %4d  q %s\n", c.name, len(sc.Hits), sc.QSha[:16])
 	}
 	writeJSON(filepath.Join(golden, "go_sample_bin.json"), sb)
+
+	// ---- the r900 parser's second stage (r900/r900.go:82-150), only with -tags amdgolden (r900_golden.go) ----
+	r900Golden(golden, capture)
 }

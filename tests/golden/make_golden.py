@@ -67,6 +67,43 @@ def synth_vectors():
     return {"cases": cases}
 
 
+def r900_filter_run(protos, chip, iq):
+    """The r900 parser's second stage over a stream: p.quantized after EVERY Decode call (r900/r900.go:160-172, 82-150),
+    all calls concatenated -> (sha256, histogram of the six symbol values, calls)."""
+    from oracle.oracle import R900Filter
+    d = OracleDecoder(protos, chip)
+    f = R900Filter(d)
+    bs2 = d.geom.block_size2
+    h = hashlib.sha256()
+    hist = np.zeros(6, np.int64)
+    n = iq.size // bs2
+    for k in range(n):
+        d.decode(iq[k * bs2:(k + 1) * bs2])
+        q = f.step()
+        h.update(q.tobytes())
+        hist += np.bincount(q, minlength=6)[:6]
+    return h.hexdigest(), hist.tolist(), n
+
+
+def r900_filter_vectors(raw):
+    """What go/cmd/amdgolden -tags amdgolden reproduces with the reference's own r900.Parser.filter (go/r900/amd_golden.go)."""
+    cases = []
+    for name, protos, chip in [("capture_r900_72", ["r900"], 72), ("capture_r900_32", ["r900"], 32),
+                               ("capture_all_72", ["scm", "scm+", "idm", "r900"], 72)]:
+        qsha, hist, n = r900_filter_run(protos, chip, raw)
+        cases.append({"name": name, "protocols": protos, "chip": chip, "input": "capture", "calls": n, "qsha": qsha, "hist": hist})
+    for c in json.load(open(os.path.join(HERE, "synth.json")))["cases"]:
+        if "r900" not in c["protocols"]:
+            continue
+        d = OracleDecoder(c["protocols"], c["chip"])
+        iq, _ = util.synth_stream(c["protocols"], c["chip"], c["blocks"], d.geom.block_size, c["seed"], c["packets"])
+        assert sha(iq) == c["iq_sha"]
+        qsha, hist, n = r900_filter_run(c["protocols"], c["chip"], iq)
+        cases.append({"name": c["name"], "protocols": c["protocols"], "chip": c["chip"], "input": "synth", "calls": n,
+                      "qsha": qsha, "hist": hist})
+    return {"cases": cases}
+
+
 def capture_fixture():
     """The reference's only real-signal input, assets/sample.bin (raw uint8 IQ -- data, not code), xz-compressed, so
     that the -m gpu tests can run BASELINE config 1 on the GPU box, where /root/reference does not exist."""
@@ -81,4 +118,5 @@ if __name__ == "__main__":
         json.dump(sample_bin_vectors(), open(os.path.join(HERE, "sample_bin.json"), "w"), indent=1)
         capture_fixture()
     json.dump(synth_vectors(), open(os.path.join(HERE, "synth.json"), "w"), indent=1)
+    json.dump(r900_filter_vectors(util.load_capture()), open(os.path.join(HERE, "r900_filter.json"), "w"), indent=1)
     print("golden vectors written")

@@ -21,6 +21,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 G = os.path.join(HERE, "golden")
 SYNTH_FIELDS = ("protocols", "chip", "blocks", "seed", "packets", "iq_sha", "qsha", "n_hits", "hits_sha", "pkt_sha")
 SAMPLE_FIELDS = ("protocols", "chip", "blocks", "block_size", "ones", "qsha", "hits", "pkt_sha")
+R900_FIELDS = ("protocols", "chip", "input", "calls", "qsha", "hist")      # r900.Parser.filter, r900/r900.go:82-150
 
 
 def _load(name):
@@ -49,7 +50,7 @@ def compare_goldens(ours: dict, go: dict, fields) -> list:
 def test_comparison_machinery_on_a_stand_in():
     """Schema round trip: a Go-shaped copy of the oracle's vectors compares equal; one flipped hash, one dropped hit
     and one missing case are each reported."""
-    for name, fields in (("synth.json", SYNTH_FIELDS), ("sample_bin.json", SAMPLE_FIELDS)):
+    for name, fields in (("synth.json", SYNTH_FIELDS), ("sample_bin.json", SAMPLE_FIELDS), ("r900_filter.json", R900_FIELDS)):
         ours = _load(name)
         fake = json.loads(json.dumps({"generator": "stand-in", **copy.deepcopy(ours)}))   # through JSON, like the real file
         assert compare_goldens(ours, fake, fields) == []
@@ -66,7 +67,35 @@ def test_comparison_machinery_on_a_stand_in():
     assert any(".hits" in d for d in compare_goldens(ours, bad, SAMPLE_FIELDS))
 
 
-@pytest.mark.parametrize("name,fields", [("synth.json", SYNTH_FIELDS), ("sample_bin.json", SAMPLE_FIELDS)])
+def test_r900_filter_vectors_reproduce_from_the_oracle():
+    """tests/golden/r900_filter.json (what go/cmd/amdgolden -tags amdgolden re-computes with the reference's own
+    r900.Parser.filter) is what the oracle's literal C restatement gives today, and the numpy restatement
+    (oracle/r900_oracle.py: the checker of the HIP digits) agrees with it at every position a hit could use."""
+    import importlib.util
+    from oracle import r900_oracle as r9
+    from oracle.oracle import OracleDecoder, R900Filter
+    spec = importlib.util.spec_from_file_location("make_golden", os.path.join(G, "make_golden.py"))
+    mg = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mg)
+    raw = util.load_capture()
+    gold = {c["name"]: c for c in _load("r900_filter.json")["cases"]}
+    c = gold["capture_r900_72"]
+    qsha, hist, n = mg.r900_filter_run(c["protocols"], c["chip"], raw)
+    assert (qsha, hist, n) == (c["qsha"], c["hist"], c["calls"])
+    # numpy twin == C restatement on the last call's buffer, wherever filter() writes (idx < BufferLength - 4*CL)
+    d = OracleDecoder(c["protocols"], c["chip"])
+    f = R900Filter(d)
+    bs2 = d.geom.block_size2
+    for k in range(3):
+        d.decode(raw[k * bs2:(k + 1) * bs2])
+        q = f.step().copy()
+    csum = np.concatenate([np.zeros(1, np.float32), np.cumsum(f.signal, dtype=np.float32)])
+    pos = np.arange(d.geom.buffer_length - 4 * d.geom.chip_length)
+    assert np.array_equal(r9.quantize_at(csum, pos, d.geom.chip_length), q[: len(pos)])
+
+
+@pytest.mark.parametrize("name,fields", [("synth.json", SYNTH_FIELDS), ("sample_bin.json", SAMPLE_FIELDS),
+                                         ("r900_filter.json", R900_FIELDS)])
 def test_oracle_equals_go_reference(name, fields):
     go = _load("go_" + name)
     if go is None:
