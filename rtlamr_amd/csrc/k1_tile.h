@@ -27,6 +27,9 @@
 #ifndef AMR_K1T_CLK
 #define AMR_K1T_CLK 0
 #endif
+#ifndef AMR_K1T_LUT_DMA
+#define AMR_K1T_LUT_DMA 1     // 0: the round-2 table fill (global load + ds_write in front of the first tile), for A/B builds
+#endif
 
 namespace amr {
 
@@ -464,11 +467,13 @@ __global__ __launch_bounds__(64, 2) void k1t_demod(const K1Args a)
     const uint32_t b = wg * kRows + lane;
     const uint32_t rows_valid = TAIL ? (a.n_blocks - wg * kRows) : kRows;
 
+#if !AMR_K1T_LUT_DMA
     {
         float *lut = reinterpret_cast<float *>(k1t_lds + C::kLut);
 #pragma unroll
         for (int i = 0; i < 4; ++i) lut[lane + 64 * i] = a.lut[lane + 64 * i];
     }
+#endif
 
     // loader role: lane (rl, c') of piece q fetches row 8q+rl, 16-byte column c'^((row>>1)&7)
     const uint32_t rl = lane >> 3;
@@ -507,6 +512,15 @@ __global__ __launch_bounds__(64, 2) void k1t_demod(const K1Args a)
 
     // prologue: tiles 0 and 1 go out, tile 0 is drained, tile 2 follows it into buffer 0
     k1_prefetch<CL, TAIL>(a, 0, wg, 0, 0, lane, voff_e, voff_o, rows_valid);
+#if AMR_K1T_LUT_DMA
+    // the LUT (NewMagLUT, 1 KiB) follows tile 0 as ONE LDS-DMA instruction, 16 bytes per lane, instead of a global load +
+    // ds_write pair in front of the first tile: one memory latency at the start of a wave instead of two.  Measured
+    // neutral (harness A/B in one call, chip 8 and 72: inside the run-to-run spread -- with 8 waves per CU out of step
+    // after the first round, another wave covers the start of this one); kept because it is less code.  No "nt": every
+    // wave of the launch reads the same KiB.
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1"
+                 :: "v"(lane * 16u), "s"(a.lut), "s"((uint32_t)C::kLut) : "memory");
+#endif
     if (C::DEPTH == 2) {
         k1_prefetch<CL, TAIL>(a, 0, wg, 1, kTileBuf, lane, voff_e, voff_o, rows_valid);
         asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
