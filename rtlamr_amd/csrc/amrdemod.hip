@@ -230,7 +230,7 @@ amr_status ensure_qt(amr_handle *h, Slot &s, Slot &other, size_t tiles)
     // hipMemset (asynchronous to the host for device memory) would race with the kernels enqueued right after
     if (tiles > s.qt_tiles) {
         uint32_t *nq = nullptr;
-        hipError_t e = hipMalloc((void **)&nq, tiles * tile_words * 4);
+        hipError_t e = hipMalloc((void **)&nq, tiles * tile_words * 4 + amr::kQtSlackBytes);   // slack: see kQtSlackBytes
         if (e != hipSuccess) return fail(AMR_ENOMEM, "hipMalloc(qt)", e);
         if (s.d_qt) {
             HIP_TRY(hipMemcpyAsync(nq, s.d_qt, tile_words * 4, hipMemcpyDeviceToDevice, h->stream));
@@ -243,7 +243,7 @@ amr_status ensure_qt(amr_handle *h, Slot &s, Slot &other, size_t tiles)
         s.qt_tiles = tiles;
     }
     if (!other.d_qt) {
-        hipError_t e = hipMalloc((void **)&other.d_qt, tiles * tile_words * 4);
+        hipError_t e = hipMalloc((void **)&other.d_qt, tiles * tile_words * 4 + amr::kQtSlackBytes);
         if (e != hipSuccess) { other.d_qt = nullptr; return fail(AMR_ENOMEM, "hipMalloc(qt)", e); }
         HIP_TRY(hipMemsetAsync(other.d_qt, 0, tile_words * 4, h->stream));
         other.qt_tiles = tiles;

@@ -201,6 +201,11 @@ __host__ __device__ __forceinline__ uint32_t k2_groups(uint32_t n_tiles) { retur
 constexpr int kK2WTaps = 16;              // taps applied to every position
 constexpr int kK2WList = 192;             // (key, mask) entries per wave
 constexpr int kK2WWaves = 4;              // waves (tiles) per workgroup
+// The walk loads its ring chunks unconditionally (k2_walk.h: a load inside a branch costs a vmcnt(0) per group), so at the
+// end of a row it fetches up to NEED + PF chunks of 1 KiB that nobody uses -- for the last row of the last searched tile
+// they lie behind the tile that follows it.  The bitstream allocation carries this many bytes of slack behind its
+// tiles (ensure_qt); k2_search_walk asserts that its over-read fits.
+constexpr size_t kQtSlackBytes = 64 * 1024;
 
 inline size_t k2_walk_lds_bytes(uint32_t hist_words)
 {

@@ -42,6 +42,8 @@ struct K2WGeom {
     static constexpr int NEED = (3 + LOOK) / 4 + 1;                 // chunks (4 words) a group of 4 words needs
     static constexpr int RC = NEED + PF;                            // ring size in chunks
     static constexpr int RW = RC * 4;                               // ring size in words
+    // bytes a lane may touch behind the end of the tile after its own: chunk index (NEED - 1) + RC past a row end
+    static_assert((size_t)(NEED + RC + 1) * 1024 <= kQtSlackBytes, "the bitstream allocation's slack (kQtSlackBytes) must cover the walk's over-read");
 };
 
 #ifndef AMR_K2W_PF1
