@@ -116,3 +116,31 @@ def test_custom_preambles_go_through_the_fallback_kernels(extra):
         assert np.array_equal(p, hb[order])
     finally:
         dec.close()
+
+
+@pytest.mark.parametrize("protos,chip", [(["scm+"], 72), (["scm", "scm+"], 32), (["scm+", "idm"], 72)])
+def test_walk_candidate_list_overflow_reruns_dense(protos, chip):
+    """A carrier that repeats scm+'s 16-symbol preamble without pause: every repetition is a run of adjacent hits three
+    bitstream words long, two runs per row -- several hundred candidate words per 64-row tile, more than the 192 entries
+    a wave of k2_search_walk keeps (K2Args::overflow bit 1).  The host must notice, re-run the batch's search with
+    k2_search_dense and return exactly the oracle's hits; the batches after it go back to the walk kernel."""
+    dec = util.make_decoder(protos, chip)
+    try:
+        bs = dec.Cfg.BlockSize
+        n_blocks = 200
+        iq = synth.noise(n_blocks * bs, 77)
+        rep = bytes([0x16, 0xA3] * 8)                                   # scmplus/scmplus.go:52, eight times = 128 symbols
+        span = 128 * 2 * chip                                            # samples one planted "packet" covers
+        first = 70 * bs                                                  # quiet blocks first: the walk kernel runs
+        pk = [synth.Packet(first + k * span, rep, 128, 34, -30) for k in range((60 * bs) // span)]
+        synth.plant(iq, pk, chip)
+        want = util.oracle_run(protos, chip, iq, hits_cap=1 << 20)
+        got = util.gpu_run(dec, iq, [64, 64, 72])
+        util.assert_same(want, got, dec.Cfg.PacketSymbols)
+        pid = dec._pid_of_preamble[ra.new_parser("scm+", chip).Cfg().Preamble]
+        hh = got[1][got[1][:, 0] == pid]
+        words = np.unique(np.stack([hh[:, 1], hh[:, 2] // 32], axis=1), axis=0)           # bitstream words that hold hits
+        per_tile = np.bincount(words[:, 0] // 64, minlength=4)
+        assert per_tile.max() > 192, f"vacuous: the carrier did not fill a wave's candidate list ({per_tile.tolist()})"
+    finally:
+        dec.close()

@@ -1,0 +1,117 @@
+// K2 harness: k2_search_walk<SL, SET> alone on a random bitstream, with the per-wave phase stamps of AMR_K2W_DBG
+// (developer tool, not product code).  Geometry: scm at chip length 72 by default (rows of 128 words), or "idm" / "all"
+// (rows of 256 words).
+//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -DAMR_K2W_DBG=1 -Irtlamr_amd/csrc -Iinclude -o build/k2b tools/k2_bench.hip
+// usage: k2b [scm|idm|all] [n_tiles incl. the history tile] [reps]
+// Note: the bitstream stays in the 256 MB Infinity Cache between launches here; in the product K1 has just streamed a GiB
+// through it and K2 reads a cold bitstream (scm: 20-25 us here, 34 us in the bench's --depth 1 profile).
+#include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
+#include <algorithm>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+#include "k2_walk.h"
+
+#ifndef K2B_PF1
+#define K2B_PF1 AMR_K2W_PF1
+#endif
+
+#define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { fprintf(stderr, "%s: %s\n", #x, hipGetErrorString(e_)); exit(1); } } while (0)
+
+static uint64_t bits_of(const char *s) { uint64_t v = 0; for (int p = 0; s[p]; ++p) v |= (uint64_t)(s[p] == '1') << p; return v; }
+
+template <int SL, int SET>
+static void run(const char *name, amr::K2Args a, uint32_t n_tiles, int reps, unsigned long long *d_dbg)
+{
+    using namespace amr;
+    const uint32_t n_wg = (n_tiles + kK2WWaves - 1) / kK2WWaves;
+    const uint32_t grid = 8u * ((n_wg + 7u) / 8u);
+    const size_t lds = k2_walk_lds_bytes(0);
+    CK(hipFuncSetAttribute((const void *)k2_search_walk<SL, SET>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipEvent_t e0, e1;
+    CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    std::vector<float> ms;
+    const uint32_t groups = k2_groups(n_tiles);
+    for (int r = 0; r < reps + 30; ++r) {
+        CK(hipMemsetAsync(a.gcnt, 0, (size_t)groups * a.g.n_pre * 4, 0));
+        CK(hipMemsetAsync(a.overflow, 0, 4, 0));
+        a.dbg = (r == reps + 29) ? d_dbg : nullptr;
+        hipExtLaunchKernelGGL((k2_search_walk<SL, SET>), dim3(grid), dim3(64 * kK2WWaves), lds, 0, e0, e1, 0, a);
+        CK(hipEventSynchronize(e1));
+        float t; CK(hipEventElapsedTime(&t, e0, e1));
+        if (r >= 30) ms.push_back(t);
+    }
+    std::sort(ms.begin(), ms.end());
+    uint32_t ovf = 0; CK(hipMemcpy(&ovf, a.overflow, 4, hipMemcpyDeviceToHost));
+    std::vector<uint32_t> cnt((size_t)n_tiles * a.g.n_pre);
+    CK(hipMemcpy(cnt.data(), a.counts, cnt.size() * 4, hipMemcpyDeviceToHost));
+    unsigned long long hits = 0; for (uint32_t c : cnt) hits += c;
+    printf("k2b %-4s SL=%d SET=%d tiles=%u grid=%u: min %.1f med %.1f p90 %.1f us   hits %llu overflow %u\n", name, SL, SET, n_tiles, grid,
+           ms[0] * 1e3, ms[ms.size() / 2] * 1e3, ms[ms.size() * 9 / 10] * 1e3, hits, ovf);
+    if (!AMR_K2W_DBG) return;
+    // phase stamps of the last launch: shader-clock deltas per wave, real-time start/end (100 MHz)
+    std::vector<unsigned long long> d((size_t)n_tiles * 16);
+    CK(hipMemcpy(d.data(), d_dbg, d.size() * 8, hipMemcpyDeviceToHost));
+    std::vector<double> walk, st2, emit, life, start, end;
+    unsigned long long t0 = ~0ull;
+    for (uint32_t T = 0; T < n_tiles; ++T) t0 = std::min(t0, d[(size_t)T * 16 + 8]);
+    unsigned long long cand = 0, keep = 0;
+    for (uint32_t T = 0; T < n_tiles; ++T) {
+        const unsigned long long *w = &d[(size_t)T * 16];
+        walk.push_back((double)(w[1] - w[0])); st2.push_back((double)(w[2] - w[1])); emit.push_back((double)(w[3] - w[2]));
+        life.push_back((w[9] - w[8]) * 0.01); start.push_back((w[8] - t0) * 0.01); end.push_back((w[9] - t0) * 0.01);
+        cand += w[7] >> 32; keep += w[7] & 0xffffffffu;
+    }
+    auto q = [](std::vector<double> v, double f) { std::sort(v.begin(), v.end()); return v[(size_t)(f * (v.size() - 1))]; };
+    printf("    cycles  walk %.0f / %.0f / %.0f   stage2 %.0f / %.0f / %.0f   ranks+emit %.0f / %.0f / %.0f   (p10 / med / p90)\n",
+           q(walk, .1), q(walk, .5), q(walk, .9), q(st2, .1), q(st2, .5), q(st2, .9), q(emit, .1), q(emit, .5), q(emit, .9));
+    printf("    us      wave life %.1f / %.1f / %.1f   start %.1f / %.1f / %.1f   end %.1f / %.1f / %.1f (max %.1f)   candidates %llu kept %llu\n",
+           q(life, .1), q(life, .5), q(life, .9), q(start, .1), q(start, .5), q(start, .9), q(end, .1), q(end, .5), q(end, .9), q(end, 1.0), cand, keep);
+    // per-XCD picture: tiles are dealt in 8 contiguous runs
+    const uint32_t per = (n_tiles + 7) / 8;
+    printf("    end of the last wave per XCD run (us):");
+    for (int x = 0; x < 8; ++x) { double m = 0; for (uint32_t T = x * per; T < std::min(n_tiles, (x + 1) * per); ++T) m = std::max(m, end[T]); printf(" %.1f", m); }
+    printf("\n");
+}
+
+int main(int argc, char **argv)
+{
+    using namespace amr;
+    const char *kind = argc > 1 ? argv[1] : "scm";
+    const bool wide = strcmp(kind, "scm") != 0;
+    const uint32_t n_tiles = argc > 2 ? (uint32_t)atoi(argv[2]) : (wide ? 4097u : 2049u);
+    const int reps = argc > 3 ? atoi(argv[3]) : 40;
+    K2Args a{};
+    SearchGeom &g = a.g;
+    g.block_size = wide ? 8192 : 4096; g.lg_block_size = wide ? 13 : 12; g.wpb = g.block_size / 32; g.lg_wpb = wide ? 8 : 7;
+    g.symbol_length = 144;
+    const char *pre[4] = {"111110010101001100000", "0001011010100011", "01010101010101010001011010100011", "00000000000000001110010101100100"};
+    if (!strcmp(kind, "scm")) { g.n_pre = 1; g.pre_len[0] = 21; g.pre_bits[0] = bits_of(pre[0]); g.packet_symbols = 96; a.walk_pids = 0; }
+    else if (!strcmp(kind, "idm")) { g.n_pre = 1; g.pre_len[0] = 32; g.pre_bits[0] = bits_of(pre[2]); g.packet_symbols = 736; a.walk_pids = 0; }
+    else { g.n_pre = 4; for (int q = 0; q < 4; ++q) { g.pre_len[q] = (uint32_t)strlen(pre[q]); g.pre_bits[q] = bits_of(pre[q]); }
+           g.packet_symbols = 736; a.walk_pids = 0u | (1u << 8) | (2u << 16) | (3u << 24); }
+    g.max_pre_len = 0; for (uint32_t q = 0; q < g.n_pre; ++q) g.max_pre_len = std::max(g.max_pre_len, g.pre_len[q]);
+    g.packet_length = g.packet_symbols * g.symbol_length; g.pkt_bytes = (g.packet_symbols + 7) / 8;
+    const size_t tile_words = (size_t)64 * g.wpb;
+    const size_t qt_bytes = (size_t)(n_tiles + 2) * tile_words * 4 + kQtSlackBytes;   // history tile + n_tiles + one more, as ensure_qt
+    uint32_t *d_qt; CK(hipMalloc((void **)&d_qt, qt_bytes));
+    {   // random bits (what noise quantizes to)
+        std::vector<uint32_t> h(qt_bytes / 4);
+        uint64_t s = 0x9e3779b97f4a7c15ull;
+        for (auto &w : h) { s ^= s << 13; s ^= s >> 7; s ^= s << 17; w = (uint32_t)(s >> 16); }
+        CK(hipMemcpy(d_qt, h.data(), qt_bytes, hipMemcpyHostToDevice));
+    }
+    a.qt = d_qt; a.n_tiles = n_tiles; a.cap = 1024;
+    CK(hipMalloc((void **)&a.counts, (size_t)n_tiles * g.n_pre * 4));
+    CK(hipMalloc((void **)&a.gcnt, (size_t)k2_groups(n_tiles) * g.n_pre * 4));
+    CK(hipMalloc((void **)&a.staging, (size_t)n_tiles * g.n_pre * a.cap * 4));
+    CK(hipMalloc((void **)&a.overflow, 4));
+    unsigned long long *d_dbg; CK(hipMalloc((void **)&d_dbg, (size_t)n_tiles * 16 * 8));
+    a.n_lo = -(int64_t)g.packet_length; a.n_hi = (int64_t)(n_tiles - 1) * 64 * g.block_size - g.packet_length;   // tile 0 = history tile
+    if (!strcmp(kind, "scm")) run<144, 1>("scm", a, n_tiles, reps, d_dbg);
+    else if (!strcmp(kind, "idm")) run<144, 4>("idm", a, n_tiles, reps, d_dbg);
+    else run<144, 15>("all", a, n_tiles, reps, d_dbg);
+    return 0;
+}
