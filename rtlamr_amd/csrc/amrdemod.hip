@@ -935,9 +935,6 @@ amr_status amr_create(const amr_protocol *protos, int32_t n_protos, int32_t devi
         amr_status ps = plan_geometry(protos, n_protos, h->geom, h->sg, h->proto_pid, h->halo_bytes, h->hist_rows);
         if (ps != AMR_OK) { delete h; return ps; }
     }
-    amr_geometry &g = h->geom;
-    amr::SearchGeom &sg = h->sg;
-    (void)g;
     // NewMagLUT, decode.go:209-216: float32 divide then float32 square, two roundings per entry.
     for (int i = 0; i < 256; ++i) {
         volatile float q = (127.5f - (float)i) / 127.5f;

@@ -87,6 +87,7 @@ __device__ __forceinline__ uint32_t k3_wave_scan(uint32_t x)
 }
 
 constexpr int kK3Batch = 4;    // words (entries) a wave works on together
+constexpr int kK3List = 1024;  // positions of a list held in LDS at a time (long packets)
 
 // 64 hits of one list (src[i0 .. i0 + 64) below i_hi) by one wave: their (call, idx) records and the packets of every word
 // that holds some of them.  STAGED: the windows come from rows_lds (stream order, bit 31 of word 0 = tile-local bit
@@ -95,7 +96,7 @@ template <bool STAGED>
 __device__ __forceinline__ void k3_chunk(const K3Args &a, const SearchGeom &g, uint32_t T, const uint32_t *src, uint32_t i0, uint32_t i_hi,
                                          uint32_t i_lo, uint32_t wv, uint64_t off, uint64_t total, uint32_t (&tab)[kK3Batch][32],
                                          const uint32_t *rows_lds, const uint32_t *__restrict__ tbase, uint32_t base_bit,
-                                         uint32_t p_first, bool by_symbols)
+                                         uint32_t p_first, bool by_symbols, uint32_t i_out0)
 {
     const uint32_t lane = threadIdx.x & 63, l32 = lane & 31, half = lane >> 5;
     const uint32_t lg_bs = g.lg_block_size, bs_mask = g.block_size - 1, lg_tw = 6 + g.lg_wpb;
@@ -119,8 +120,8 @@ __device__ __forceinline__ void k3_chunk(const K3Args &a, const SearchGeom &g, u
     if (ok && (!by_symbols || wv == (((i0 - i_lo) >> 6) & 3u))) {      // by symbols: four waves see the chunk, one writes
         const int64_t n = ((int64_t)T * 64 - 64) * (int64_t)g.block_size + local;
         const uint64_t pos = (uint64_t)(n + g.packet_length);
-        hit_block[off + i] = a.block_base + (pos >> lg_bs);
-        hit_idx[off + i] = (uint32_t)pos & bs_mask;
+        hit_block[off + i_out0 + i] = a.block_base + (pos >> lg_bs);
+        hit_idx[off + i_out0 + i] = (uint32_t)pos & bs_mask;
     }
     const uint32_t key = ok ? local >> 5 : 0xffffffffu;
     const uint32_t prev = __shfl_up(key, 1);
@@ -136,7 +137,7 @@ __device__ __forceinline__ void k3_chunk(const K3Args &a, const SearchGeom &g, u
                 leaders &= leaders - 1;
                 const uint32_t key_s = __builtin_amdgcn_readlane(key, L);
                 if (lane < 32) tab[e][lane] = 0xffffffffu;
-                if (ok && key == key_s) tab[e][local & 31] = i;    // same wave: LDS operations execute in order
+                if (ok && key == key_s) tab[e][local & 31] = i_out0 + i;   // same wave: LDS operations execute in order
                 slot[e] = tab[e][31 - l32];                        // lane c of a block ends up with position 31-c
                 v0[e] = (key_s << 5) - base_bit;                   // first bit of the word (STAGED: counted from the staged rows)
                 nb = e + 1;
@@ -198,6 +199,7 @@ __global__ __launch_bounds__(256) void k3_slice_words(const K3Args a)
     __shared__ uint32_t s_cnt[kMaxPre];
     __shared__ uint32_t s_in[kMaxPre];          // hits of the tile's group in front of the tile, per preamble
     __shared__ uint32_t tab[4][kK3Batch][32];   // per wave and entry: staging index of the hit at bit b of the word, or ~0
+    __shared__ uint32_t s_list[kK3List];        // long packets: the segment of the list being sliced
     extern __shared__ __attribute__((aligned(16))) uint32_t rows_lds[];          // [n_rows][wpb] words, stream order
 
     // ---- prologue ----
@@ -277,59 +279,51 @@ __global__ __launch_bounds__(256) void k3_slice_words(const K3Args a)
             const uint32_t *src = a.staging + ((size_t)T * n_pre + q) * a.cap;
             const uint64_t off = s_off[q] + s_in[q];
             for (uint32_t i0 = wv * 64; i0 < cnt; i0 += 256)
-                k3_chunk<false>(a, g, T, src, i0, cnt, 0u, wv, off, total, tab[wv], nullptr, tbase, 0u, 0u, false);
+                k3_chunk<false>(a, g, T, src, i0, cnt, 0u, wv, off, total, tab[wv], nullptr, tbase, 0u, 0u, false, 0u);
         }
         return;
     }
 
-    // ---- long packets, row by row: cur[q] = the first hit of list q not sliced yet (workgroup-uniform) ----
-    uint32_t cur[kMaxPre];
-#pragma unroll
-    for (int q = 0; q < kMaxPre; ++q) cur[q] = 0;
-    for (;;) {
-        uint32_t l0 = 0xffffffffu;                       // the lowest row any list still has a hit in
-#pragma unroll
-        for (int q = 0; q < kMaxPre; ++q) {
-            if (q >= (int)q_hi) break;
-            if (q < (int)q_lo) continue;
-            while (cur[q] < s_cnt[q] && a.staging[((size_t)T * n_pre + q) * a.cap + cur[q]] >= bad) cur[q] += 1;   // defensive
-            if (cur[q] < s_cnt[q]) {
-                const uint32_t r = a.staging[((size_t)T * n_pre + q) * a.cap + cur[q]] >> lg_bs;
-                l0 = r < l0 ? r : l0;
+    // ---- long packets, row by row.  The list comes into LDS first, a segment of kK3List positions at a time: what row
+    // to stage next and where the hits of that row end are then LDS reads.  (Taken from global memory, every such
+    // decision was a dependent load in front of the next row set -- the staging slot's first unsliced entry, then a
+    // binary search -- 4 to 5 us per row set next to 2 us of staging and 1 us of slicing; "all" has 8 lone scm+ noise
+    // hits per tile, each a row set of its own: K3 184 us per 4 GiB, most of it these loads.) ----
+    for (uint32_t q = q_lo; q < q_hi; ++q) {
+        const uint32_t cnt = s_cnt[q];
+        const uint32_t *src = a.staging + ((size_t)T * n_pre + q) * a.cap;
+        const uint64_t off = s_off[q] + s_in[q];
+        for (uint32_t seg0 = 0; seg0 < cnt; seg0 += kK3List) {
+            const uint32_t seg_n = cnt - seg0 < (uint32_t)kK3List ? cnt - seg0 : (uint32_t)kK3List;
+            __syncthreads();                                                    // the previous segment has been consumed
+            for (uint32_t t = threadIdx.x; t < seg_n; t += 256) s_list[t] = src[seg0 + t];
+            __syncthreads();
+            uint32_t cur = 0;                                                   // workgroup-uniform: first entry not sliced yet
+            while (cur < seg_n) {
+                const uint32_t first = s_list[cur];
+                if (first >= bad) { cur += 1; continue; }                       // defensive
+                const uint32_t l0 = first >> lg_bs;                             // the row this round stages from
+                const uint32_t lim = (l0 + 1) << lg_bs;
+                uint32_t lo = cur + 1, hi = seg_n;                              // end of the hits that start in row l0 (positions ascend)
+                while (lo < hi) {
+                    const uint32_t mid = (lo + hi) >> 1;
+                    if (s_list[mid] < lim) lo = mid + 1; else hi = mid;
+                }
+                const uint32_t i_hi = lo;
+                __syncthreads();                                                // the previous row set has been consumed
+                for (uint32_t t = threadIdx.x; t < n_rows * cpr; t += 256) {
+                    const uint32_t c = t / n_rows, r = t - c * n_rows, row = l0 + r;     // neighbouring threads: neighbouring rows of one chunk
+                    const uint4 x = *reinterpret_cast<const uint4 *>(tbase + ((size_t)(row >> 6) << lg_tw) + ((size_t)c << 8) + ((row & 63) << 2));
+                    *reinterpret_cast<uint4 *>(rows_lds + r * wpb + c * 4) = x;
+                }
+                __syncthreads();
+                const uint32_t base_bit = l0 << lg_bs;                          // stream bit (tile-local) of rows_lds[0], bit 31
+                // the four waves share a 64-hit chunk by SYMBOLS: the hits of a packet are one run of ~70 positions, i.e. one
+                // wave's worth, and 736 symbols in one wave are six rounds one after the other while three waves watch
+                for (uint32_t i0 = cur; i0 < i_hi; i0 += 64)
+                    k3_chunk<true>(a, g, T, s_list, i0, i_hi, cur, wv, off, total, tab[wv], rows_lds, tbase, base_bit, wv * 128, true, seg0);
+                cur = i_hi;
             }
-        }
-        if (l0 == 0xffffffffu) break;
-        __syncthreads();                                                        // the previous row set has been consumed
-        for (uint32_t t = threadIdx.x; t < n_rows * cpr; t += 256) {
-            const uint32_t c = t / n_rows, r = t - c * n_rows, row = l0 + r;     // neighbouring threads: neighbouring rows of one chunk
-            const uint4 x = *reinterpret_cast<const uint4 *>(tbase + ((size_t)(row >> 6) << lg_tw) + ((size_t)c << 8) + ((row & 63) << 2));
-            *reinterpret_cast<uint4 *>(rows_lds + r * wpb + c * 4) = x;
-        }
-        __syncthreads();
-        const uint32_t base_bit = l0 << lg_bs;                                    // stream bit (tile-local) of rows_lds[0], bit 31
-        const uint32_t lim = (l0 + 1) << lg_bs;
-#pragma unroll 1
-        for (uint32_t q = q_lo; q < q_hi; ++q) {
-            const uint32_t cnt = s_cnt[q];
-            const uint32_t *src = a.staging + ((size_t)T * n_pre + q) * a.cap;
-            uint32_t i_lo = 0;
-#pragma unroll
-            for (int qq = 0; qq < kMaxPre; ++qq) i_lo = q == (uint32_t)qq ? cur[qq] : i_lo;
-            if (i_lo >= cnt || src[i_lo] >= lim) continue;
-            // end of this list's hits that start in row l0 (positions ascend): binary search, the same loads in every thread
-            uint32_t lo = i_lo + 1, hi = cnt;
-            while (lo < hi) {
-                const uint32_t mid = (lo + hi) >> 1;
-                if (src[mid] < lim) lo = mid + 1; else hi = mid;
-            }
-            const uint32_t i_hi = lo;
-#pragma unroll
-            for (int qq = 0; qq < kMaxPre; ++qq) cur[qq] = q == (uint32_t)qq ? i_hi : cur[qq];
-            const uint64_t off = s_off[q] + s_in[q];
-            // the four waves share a 64-hit chunk by SYMBOLS: the hits of a packet are one run of ~70 positions, i.e. one
-            // wave's worth, and 736 symbols in one wave are six rounds one after the other while three waves watch
-            for (uint32_t i0 = i_lo; i0 < i_hi; i0 += 64)
-                k3_chunk<true>(a, g, T, src, i0, i_hi, i_lo, wv, off, total, tab[wv], rows_lds, tbase, base_bit, wv * 128, true);
         }
     }
 }
