@@ -87,7 +87,7 @@ __device__ __forceinline__ uint32_t k3_wave_scan(uint32_t x)
 }
 
 constexpr int kK3Batch = 4;    // words (entries) a wave works on together
-constexpr int kK3List = 1024;  // positions of a list held in LDS at a time (long packets)
+constexpr int kK3List = 512;   // positions of a list held in LDS at a time (long packets): 2 KiB, eight workgroups still fit a CU
 
 // 64 hits of one list (src[i0 .. i0 + 64) below i_hi) by one wave: their (call, idx) records and the packets of every word
 // that holds some of them.  STAGED: the windows come from rows_lds (stream order, bit 31 of word 0 = tile-local bit
@@ -189,7 +189,7 @@ __device__ __forceinline__ void k3_chunk(const K3Args &a, const SearchGeom &g, u
     }
 }
 
-__global__ __launch_bounds__(256) void k3_slice_words(const K3Args a)
+__global__ __launch_bounds__(256, 8) void k3_slice_words(const K3Args a)   // 8 workgroups per CU: 64 VGPRs (65 without the hint: 7)
 {
     const SearchGeom &g = a.g;
     const uint32_t T = blockIdx.x;
@@ -201,6 +201,11 @@ __global__ __launch_bounds__(256) void k3_slice_words(const K3Args a)
     __shared__ uint32_t tab[4][kK3Batch][32];   // per wave and entry: staging index of the hit at bit b of the word, or ~0
     __shared__ uint32_t s_list[kK3List];        // long packets: the segment of the list being sliced
     extern __shared__ __attribute__((aligned(16))) uint32_t rows_lds[];          // [n_rows][wpb] words, stream order
+
+    // one list per workgroup and the list is empty (three of four in "all", where only scm+ finds hits in noise): nothing to
+    // place, nothing to slice -- leave before the prologue's loads and barriers.  Tile 0's first workgroup stays: it
+    // publishes the bases, the total and the overflow word.
+    if (gridDim.y > 1 && a.counts[blockIdx.y * a.n_tiles + T] == 0 && !(T == 0 && blockIdx.y == 0)) return;
 
     // ---- prologue ----
     const uint32_t n_groups = k2_groups(a.n_tiles), n_sums = n_pre * n_groups;
