@@ -49,7 +49,11 @@ struct K2WGeom {
 #ifndef AMR_K2W_PF1
 #define AMR_K2W_PF1 5
 #endif
-constexpr int kK2WPrefetch = 5;           // chunks loaded ahead of their use (several preambles)
+#ifndef AMR_K2W_PFM
+#define AMR_K2W_PFM 2
+#endif
+constexpr int kK2WPrefetch = AMR_K2W_PFM;   // chunks loaded ahead of their use, several preambles: a group takes 2-4 x the time there,
+                                            // and 12 VGPRs fewer than with 5 bring the set of four under 168 (three waves per SIMD)
 constexpr int kK2WPrefetch1 = AMR_K2W_PF1; // ... one preamble: little arithmetic per group, the loads need more lead
 
 
@@ -156,6 +160,53 @@ __device__ __forceinline__ void k2w_sweep(const K2WRing<K2WGeom<SL, PF>::RC> &R,
     k2w_pairs<SL, PF, GG, BITS, 3>(R, M);
 }
 
+// ---- several preambles: tap-major.  Preamble after preamble, the compiler kept the funnel-shifted windows of the first
+// sweep alive for the next ones (they are common subexpressions): 186 VGPRs for the set of four, two waves per SIMD, and
+// a batch of 2^k + 1 tiles then needs a third round for its last tile.  Here a pair of windows is formed once, applied
+// to every preamble's masks and dropped: 16 masks + 8 windows live instead of 4 masks + up to 32 windows. ----
+template <int SL, int PF, int GG, int SET, int P, int KIND>
+__device__ __forceinline__ void k2w_apply(uint32_t (&M)[4][4], const uint32_t (&Wa)[4], const uint32_t (&Wb)[4], const uint32_t (&Wc)[4])
+{
+    if constexpr (KIND < 4) {
+        if constexpr ((SET >> KIND) & 1) {
+            constexpr uint32_t BITS = kK2WKnown[KIND];
+            if constexpr (P == 0) {                                     // (x == b0) & (y == b1) & (z == b2)
+                constexpr uint32_t tt = 1u << (4 * (BITS & 1u) + 2 * ((BITS >> 1) & 1u) + ((BITS >> 2) & 1u));
+#pragma unroll
+                for (int j = 0; j < 4; ++j) M[KIND][j] = __builtin_amdgcn_bitop3_b32(Wa[j], Wb[j], Wc[j], tt);
+            } else if constexpr (P + 1 < kK2WTaps) {                     // x & (y == b_P) & (z == b_P+1)
+                constexpr uint32_t tt = 1u << (4 + 2 * ((BITS >> P) & 1u) + ((BITS >> (P + 1)) & 1u));
+#pragma unroll
+                for (int j = 0; j < 4; ++j) M[KIND][j] = __builtin_amdgcn_bitop3_b32(M[KIND][j], Wa[j], Wb[j], tt);
+            } else {                                                    // the odd tap out: x & (y == b_P)
+                constexpr uint32_t b = (BITS >> P) & 1u;
+                constexpr uint32_t tt = (1u << (4 + 2 * b)) | (1u << (4 + 2 * b + 1));
+#pragma unroll
+                for (int j = 0; j < 4; ++j) M[KIND][j] = __builtin_amdgcn_bitop3_b32(M[KIND][j], Wa[j], Wa[j], tt);
+            }
+        }
+        k2w_apply<SL, PF, GG, SET, P, KIND + 1>(M, Wa, Wb, Wc);
+    }
+}
+
+template <int SL, int PF, int GG, int SET, int P>
+__device__ __forceinline__ void k2w_sweep_set(const K2WRing<K2WGeom<SL, PF>::RC> &R, uint32_t (&M)[4][4])
+{
+    if constexpr (P < kK2WTaps) {
+        uint32_t Wa[4], Wb[4], Wc[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            Wa[j] = k2w_win<SL, PF, GG, P>(R, j);
+            Wb[j] = P + 1 < kK2WTaps ? k2w_win<SL, PF, GG, (P + 1 < kK2WTaps ? P + 1 : P)>(R, j) : 0u;
+            Wc[j] = P == 0 ? k2w_win<SL, PF, GG, 2>(R, j) : 0u;
+        }
+        k2w_apply<SL, PF, GG, SET, P, 0>(M, Wa, Wb, Wc);
+        // pin the order: without it the scheduler hoists the next pairs' funnel shifts above this pair's bitops again
+        asm volatile("" : "+v"(M[0][0]), "+v"(M[1][0]), "+v"(M[2][0]), "+v"(M[3][0]));
+        k2w_sweep_set<SL, PF, GG, SET, (P == 0 ? 3 : P + 2)>(R, M);
+    }
+}
+
 // record the non-zero masks of one group and preamble (rare path)
 __device__ __forceinline__ void k2w_record(const uint32_t (&M)[4], uint32_t q, uint32_t g, uint32_t w_lo, uint32_t w_hi, uint32_t lane,
                                            uint32_t *mylist, uint32_t &list_n)
@@ -204,10 +255,23 @@ __device__ __forceinline__ void k2w_groups(K2WRing<K2WGeom<SL, PF>::RC> &R, cons
     if constexpr (GG < G::RC) {
         const uint32_t g = g0 + GG;
         if (g >= n_groups) return;                                  // wave-uniform
-        k2w_kind<SL, PF, GG, SET, 0>(R, pids, g, w_lo, w_hi, lane, mylist, list_n);
-        k2w_kind<SL, PF, GG, SET, 1>(R, pids, g, w_lo, w_hi, lane, mylist, list_n);
-        k2w_kind<SL, PF, GG, SET, 2>(R, pids, g, w_lo, w_hi, lane, mylist, list_n);
-        k2w_kind<SL, PF, GG, SET, 3>(R, pids, g, w_lo, w_hi, lane, mylist, list_n);
+        if constexpr ((SET & (SET - 1)) == 0) {                     // one preamble
+            k2w_kind<SL, PF, GG, SET, 0>(R, pids, g, w_lo, w_hi, lane, mylist, list_n);
+            k2w_kind<SL, PF, GG, SET, 1>(R, pids, g, w_lo, w_hi, lane, mylist, list_n);
+            k2w_kind<SL, PF, GG, SET, 2>(R, pids, g, w_lo, w_hi, lane, mylist, list_n);
+            k2w_kind<SL, PF, GG, SET, 3>(R, pids, g, w_lo, w_hi, lane, mylist, list_n);
+        } else {                                                    // several: tap-major (k2w_sweep_set)
+            uint32_t M[4][4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) M[k][j] = 0;
+            k2w_sweep_set<SL, PF, GG, SET, 0>(R, M);
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+                if (((SET >> k) & 1) && __ballot((M[k][0] | M[k][1] | M[k][2] | M[k][3]) != 0))   // rare
+                    k2w_record(M[k], (pids >> (8 * k)) & 0xffu, g, w_lo, w_hi, lane, mylist, list_n);
+        }
         // unconditionally, also past the last chunk the walk needs (PF + 1 chunks of the following row, harmless): a load
         // inside a branch makes the compiler's waitcnt pass give up counting and wait for ALL loads in flight at every
         // group (vmcnt(0): 64 exposed memory latencies per row walk)
