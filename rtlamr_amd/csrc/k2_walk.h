@@ -87,7 +87,7 @@ __device__ __forceinline__ void k2w_load(K2WRing<RC> &R, const K2WCtx &cx, int s
 // time the tap polarities move from a scalar operand into v_bitop3's truth table, which leaves the operand slots for
 // window words: M & f(W_p) & g(W_p+1) is ONE instruction instead of two (the first one takes three taps, having no M to
 // carry): 8 per word and preamble instead of 16.  The multi-preamble search is bound by exactly this count (a wave64
-// VALU instruction holds its SIMD for 4 cycles: "all" at 4 GiB is 7.5 G lane-operations = 0.19 ms of the chip's VALU).
+// VALU instruction holds its SIMD for 4 cycles: "all" at 4 GiB is 67 M words x 40 = 2.7 G lane-operations = 70 us of the chip's VALU).
 // Any other preamble (a custom protocol entry) sends the whole set to the fallback kernels of k2_search.h.
 constexpr uint32_t k2w_bits(const char *s)                                    // bit p = s[p] == '1', first sixteen symbols
 {
