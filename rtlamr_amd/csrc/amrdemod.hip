@@ -508,12 +508,10 @@ amr_status submit(amr_handle *h, const uint8_t *d_iq, size_t n_blocks, bool sear
     for (uint32_t w0 = 0; w0 < full; w0 += round) {
         const uint32_t n = std::min(round, full - w0);
         k1.wg_first = w0;
-        amr::launch_k1(h->geom.chip_length, false, dim3(n), st, k1, w0 == 0 ? e0 : nullptr, (w0 + n == full && !rem) ? e1 : nullptr);
+        amr::launch_k1(h->geom.chip_length, dim3(n), st, k1, w0 == 0 ? e0 : nullptr, (w0 + n == full && !rem) ? e1 : nullptr);
     }
-    if (rem) {   // the partial wave-tile: one wave (sync callers, flush, batches under 64 blocks)
-        k1.wg_first = full;
-        amr::launch_k1(h->geom.chip_length, true, dim3(1), st, k1, full ? nullptr : e0, e1);
-    }
+    if (rem)     // the blocks behind the last whole wave-tile (sync callers, flush, batches under 64 blocks): a wave each
+        amr::launch_k1_coop(h->geom.chip_length, full * 64u, rem, st, k1, full ? nullptr : e0, e1);
     HIP_TRY(hipGetLastError());
     AMR_DBG(st, "k1_demod");
     s.dense = h->dense_hold > 0;
