@@ -121,6 +121,11 @@ struct Comm;
 // Up to three batches in flight over four slots: the state update of batch i writes the history rows into the slot
 // batch i+1 will use, which must not belong to a batch that is still in flight.
 constexpr int kSlots = 4;
+// Batches of up to this many samples (and at most 8192 blocks: the waves then sit on the chip side by side) run K1 as one
+// wave per block throughout.  BlockSize 4096 on an idle MI355X: 49 us up to 512 blocks, 57 at 2048, 75 at 4096, 125 at 8192,
+// against 100 us for any number of wave-tiles up to a chip-filling 2048 (tools/coop_sweep.py).
+constexpr uint64_t kK1CoopMaxSamples = 1ull << 24;
+constexpr uint64_t kK1CoopMaxBlocks = 8192;
 constexpr int kMaxPending = 3;
 constexpr int kIqHist = 5;   // r900 IQ history buffers, rotating: a batch in flight keeps its own until it is collected
 
@@ -155,6 +160,9 @@ struct amr_handle {
     uint32_t n_head = 0;         // deferred blocks waiting in the head buffer
     bool zero_halo = true;
     bool dense_search = false;   // test hook (AMR_DENSE_SEARCH): always use the fallback search kernel
+    uint64_t k1_coop_max = 0;    // batches of up to this many blocks run K1 as one wave per block throughout (k1_coop.h):
+                                 // from kK1CoopMaxSamples / kK1CoopMaxBlocks; test hook AMR_K1_COOP_MAX (0: only the blocks
+                                 // behind the last whole wave-tile -- keeps the tile kernels under the small-batch tests)
     uint64_t init_hit_cap = 1 << 16;   // hits the result buffers hold at first (test hook AMR_HIT_CAP: exercise the growth)
     int dense_streak = 0;        // consecutive batches whose sparse lists overflowed; >= 4: stay dense for a while
     int dense_hold = 0;          // batches left in which the dense kernel is used straight away
@@ -505,13 +513,20 @@ amr_status submit(amr_handle *h, const uint8_t *d_iq, size_t n_blocks, bool sear
     // under 0.1 ms) lose more at the extra launch boundaries than they gain: BlockSize 2048 0.182 -> 0.256 ms, so they
     // keep the single launch.
     const uint32_t round = bs >= 4096 ? (uint32_t)h->n_cus * 8u : full;
-    for (uint32_t w0 = 0; w0 < full; w0 += round) {
-        const uint32_t n = std::min(round, full - w0);
-        k1.wg_first = w0;
-        amr::launch_k1(h->geom.chip_length, dim3(n), st, k1, w0 == 0 ? e0 : nullptr, (w0 + n == full && !rem) ? e1 : nullptr);
+    // Small batches entirely as one wave per block (k1_coop.h): a wave-tile costs a whole wave life (150-175 us) however few
+    // tiles there are; a wave per block finishes in ~50 us as long as the waves fit the chip side by side.
+    const bool all_coop = rows > 0 && rows <= h->k1_coop_max;
+    if (all_coop) {
+        amr::launch_k1_coop(h->geom.chip_length, 0u, (uint32_t)rows, st, k1, e0, e1);
+    } else {
+        for (uint32_t w0 = 0; w0 < full; w0 += round) {
+            const uint32_t n = std::min(round, full - w0);
+            k1.wg_first = w0;
+            amr::launch_k1(h->geom.chip_length, dim3(n), st, k1, w0 == 0 ? e0 : nullptr, (w0 + n == full && !rem) ? e1 : nullptr);
+        }
+        if (rem)     // the blocks behind the last whole wave-tile (sync callers, flush): a wave each
+            amr::launch_k1_coop(h->geom.chip_length, full * 64u, rem, st, k1, full ? nullptr : e0, e1);
     }
-    if (rem)     // the blocks behind the last whole wave-tile (sync callers, flush, batches under 64 blocks): a wave each
-        amr::launch_k1_coop(h->geom.chip_length, full * 64u, rem, st, k1, full ? nullptr : e0, e1);
     HIP_TRY(hipGetLastError());
     AMR_DBG(st, "k1_demod");
     s.dense = h->dense_hold > 0;
@@ -933,6 +948,8 @@ amr_status amr_create(const amr_protocol *protos, int32_t n_protos, int32_t devi
         amr_status ps = plan_geometry(protos, n_protos, h->geom, h->sg, h->proto_pid, h->halo_bytes, h->hist_rows);
         if (ps != AMR_OK) { delete h; return ps; }
     }
+    h->k1_coop_max = std::min<uint64_t>(kK1CoopMaxBlocks, kK1CoopMaxSamples / (uint64_t)h->geom.block_size);
+    if (const char *cm = getenv("AMR_K1_COOP_MAX")) h->k1_coop_max = strtoull(cm, nullptr, 10);   // test hook / A-B
     // NewMagLUT, decode.go:209-216: float32 divide then float32 square, two roundings per entry.
     for (int i = 0; i < 256; ++i) {
         volatile float q = (127.5f - (float)i) / 127.5f;

@@ -14,6 +14,17 @@ from tests import util
 pytestmark = pytest.mark.gpu
 
 
+@pytest.fixture(autouse=True, params=["wave-per-block", "wave-tiles"])
+def _k1_policy(request, monkeypatch):
+    """Small batches run K1 as one wave per block throughout (k1_coop.h); deferral is about wave-tiles.  Every test here runs
+    under both policies (test hook AMR_K1_COOP_MAX, read at amr_create: 0 = wave-tiles + one wave per block for the
+    remainder only)."""
+    if request.param == "wave-tiles":
+        monkeypatch.setenv("AMR_K1_COOP_MAX", "0")
+    else:
+        monkeypatch.delenv("AMR_K1_COOP_MAX", raising=False)
+
+
 def _rows(dec, br):
     rows, pk = [], []
     for pid in range(dec.n_preambles):

@@ -1,7 +1,8 @@
 """One pipeline mode, several search kernels.  The library has no run-time switches between kernel generations any more
 (round 2's AMR_K1_IMPL / AMR_K2_IMPL / AMR_K3_IMPL / AMR_TAIL_MODE / AMR_TAIL_OVERLAP / AMR_HIST_FOLD are gone); which
 kernel runs follows from the geometry alone:
-  K1   k1t_demod (register tile) for chip <= 72, k1_demod for chip 80 / 88 / 96
+  K1   whole wave-tiles: k1t_demod (register tile) for chip <= 88, k1_demod for chip 96; the blocks behind the last whole
+       wave-tile, and small batches throughout: k1c_demod (one wave per block)
   K2   k2_search_walk<SymbolLength, set> for every set of rtlamr's own preambles (scm, scm+, idm / netidm, r900) at every
        BlockSize from 512 to 8192; k2_search_fast when a set holds any other preamble (a custom protocol entry), up to
        four; k2_search_dense for more than four preambles, rows under 16 words, and as the overflow fallback (test hook
@@ -19,6 +20,13 @@ from rtlamr_amd import _lib, synth
 from tests import util
 
 pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(autouse=True)
+def _tile_kernels(monkeypatch):
+    """This file is about which kernel family runs: keep K1 on the tile kernels for whole wave-tiles (small batches would
+    otherwise run one wave per block throughout, k1_coop.h; test hook AMR_K1_COOP_MAX, read at amr_create)."""
+    monkeypatch.setenv("AMR_K1_COOP_MAX", "0")
 
 SIZES = [66, 64, 3, 129, 70, 1, 65]
 
