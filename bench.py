@@ -23,9 +23,11 @@ decoder must turn the batch into exactly the planted messages; a mismatch makes 
 N > 1: every rank's hits that pass the parsers' checksum tests on the GPU (K5; --gather raw: every hit) travel to rank 0
 each step through the library's RCCL gather, and rank 0 reads every step's records inside the timed loop.
 
-Launch:  python bench.py [--gpus 1] [--steps K] [--warmup W] [--workload cfg2]
+Launch:  python bench.py [--gpus N] [--steps K] [--warmup W] [--workload cfg2]
          python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
-Prints ONE JSON line on rank 0.
+Without a launcher `--gpus N` (N > 1) starts the N ranks itself, one per device (rtlamr_amd/launch.py); `--gpus` that
+disagrees with the launcher's WORLD_SIZE, or asks for more ranks than there are gfx950 devices, exits non-zero with a
+one-line reason -- a request for N ranks never turns into a run of one.  Prints ONE JSON line on rank 0.
 """
 from __future__ import annotations
 
@@ -272,13 +274,34 @@ def main():
     args = ap.parse_args()
     wl = workload(args.workload)
 
+    # ---- who am I: a rank of a launcher's job, the only rank, or the process that has to start the ranks ----
+    from rtlamr_amd import launch
+    launched = "WORLD_SIZE" in os.environ
+    torch = None
+    if launched or os.environ.get("AMR_BENCH_FORCE_DIST") == "1":
+        import torch  # noqa: F811  (first, so its HIP runtime is the one in the process)
+        n_devices = torch.cuda.device_count()
+    else:
+        from rtlamr_amd import _lib as _l0
+        n_devices = _l0.device_count()
+    try:
+        mode, envs = launch.rank_plan(args.gpus, os.environ, n_devices)
+    except launch.LaunchError as e:
+        print(f"bench.py: {e}", file=sys.stderr)
+        return 2
+    if mode == "spawn":
+        return launch.spawn_ranks([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], envs)
+    if args.gather == "raw" and args.gpus > 2:
+        print("bench.py: --gather raw is refused above 2 ranks: every step's raw hit list of every rank (3.5 MB each at cfg2) "
+              "would pass through rank 0's host inside the timed loop; the validated records (K5) are what a deployment gathers",
+              file=sys.stderr)
+        return 2
+
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     distributed = world > 1 or os.environ.get("AMR_BENCH_FORCE_DIST") == "1"   # the env: exercise the RCCL path with one rank
-    torch = None
     if distributed:
-        import torch  # noqa: F811  (first, so its HIP runtime is the one in the process)
         import torch.distributed as dist
         torch.cuda.set_device(local_rank)
         if "MASTER_ADDR" not in os.environ:
@@ -551,8 +574,9 @@ def main():
                 traffic_src = f"profiles/k1_hbm_traffic.json (static: rocprofv3 --pmc passes of this command, {tj.get('tag', 'see profiles/README.md')}); not measured in this run"
             except Exception:
                 traffic = None
-        # chip lengths up to 72 run the second-generation kernel (k1_tile.h), 80/88/96 the first (k1_demod.h)
-        k1_name = f"k1t_demod<{chip}>" if chip <= 72 else f"k1_demod<{chip}>"
+        # every chip length up to 88 runs the tile kernel (k1_tile.h; 80 / 88 with part of the csum ring in LDS), 96 the
+        # first-generation one (k1_demod.h)
+        k1_name = f"k1t_demod<{chip}>" if chip <= 88 else f"k1_demod<{chip}>"
         ms_step = dt / args.steps * 1e3
         out = {
             "metric": "IQ Msamples/s through Decoder.Decode (SCM, 72 sym/len)" if wl["name"] == "cfg2" else
@@ -587,10 +611,15 @@ def main():
                          "algorithmic_bytes_per_launch": alg_bytes},
         }
         if distributed:
-            slot = int(gatherer.slot_bytes)
-            out["config"].update({"rccl_ranks": dec.comm_ranks(),
-                                  "gather_bytes_per_step": {"sent_per_rank": slot, "payload_per_rank": 128 + 12 * n_hits,
-                                                            "into_root": slot * world},
+            sent = 128 + dec.gather_wire_bytes(n_hits)      # header + records of the last step, as amr_gather_hits sends them
+            ranks = dec.comm_ranks()
+            if not (ranks == world == args.gpus or os.environ.get("AMR_BENCH_FORCE_DIST") == "1"):
+                check["ranks"] = f"MISMATCH: --gpus {args.gpus}, WORLD_SIZE {world}, RCCL communicator spans {ranks}"
+                rc = rc or 7
+            out["config"].update({"rccl_ranks": ranks,
+                                  "gather_bytes_per_step": {"sent_per_rank": sent, "payload_per_rank": 128 + 12 * n_hits,
+                                                            "slot_capacity_bytes": int(gatherer.slot_bytes),
+                                                            "into_root": sent * world, "rule": "128-byte header + 12 B per record rounded up to 4 KiB (amr_gather_wire_bytes)"},
                                   "gather_records": "validated hits (K5)" if validating else "raw hits (--gather raw)"})
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(wl, dec, d_iq.value, bs2)

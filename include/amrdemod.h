@@ -122,6 +122,9 @@ typedef struct amr_timing {
  */
 amr_status amr_create(const amr_protocol *protos, int32_t n_protos, int32_t device_id, amr_handle **out);
 amr_status amr_destroy(amr_handle *h);
+/* gfx950 devices visible to this process (0 is an answer, not an error): what a host that starts one process per GPU
+ *  asks before it spawns its ranks; main.go has no counterpart (one rtl_tcp stream, one Decoder). */
+amr_status amr_device_count(int32_t *n_devices);
 
 /*
  * The arithmetic of RegisterProtocol + Allocate alone (decode.go:100-141), without a device: the geometry amr_create
@@ -321,10 +324,14 @@ amr_status amr_comm_init(amr_handle *h, const void *id128, int32_t rank, int32_t
 amr_status amr_comm_destroy(amr_handle *h);
 /* ranks the RCCL communicator spans (ncclCommCount): lets a bench line prove the gather ran over N ranks */
 amr_status amr_comm_ranks(const amr_handle *h, int32_t *n_ranks);
-/* Enqueue the gather of the batch amr_collect returned last (with amr_set_validation: of its surviving hits -- the
- * natural companion: 70x fewer records).  Collective: every rank calls it once per batch, in the same order.  Returns
- * at once; *seq (may be NULL) receives the gather's sequence number.  The library orders the kernel that reads the
- * batch's result against the later reuse of its slot by itself. */
+/* Enqueue the gather of the result amr_collect / amr_flush returned last (with amr_set_validation: of its surviving
+ * hits -- the natural companion: 70x fewer records; an amr_flush that had nothing deferred returned an empty result:
+ * zero records travel).  Collective: every rank calls it once per result, in the same order.  *seq (may be NULL)
+ * receives the gather's sequence number.  What travels is sized by the hit count: a 128-byte header from every rank,
+ * then amr_gather_wire_bytes(records) from every rank that has any.  Non-root ranks return at once; the root returns
+ * when every rank's header has arrived (it needs the counts to post its receives), i.e. it runs at most one gather
+ * ahead of the slowest rank.  The library orders the kernel that reads the batch's result against the later reuse of
+ * its slot by itself. */
 amr_status amr_gather_hits(amr_handle *h, uint64_t *seq);
 amr_status amr_gather_wait(amr_handle *h);    /* block until every gather enqueued so far has completed */
 /* Root only: the records rank src_rank contributed to gather `seq`.  Waits for the arrival of that gather's records in
@@ -332,10 +339,13 @@ amr_status amr_gather_wait(amr_handle *h);    /* block until every gather enqueu
  * until gather seq + 2 is posted. */
 amr_status amr_gather_fetch(amr_handle *h, uint64_t seq, int32_t src_rank, amr_gathered *out);
 /* The slot every rank sends, as ONE description shared by the device pack kernel, CPU hosts and the tests:
- * [header AMR_GATHER_HEADER_BYTES | n_hits call indices u64 | n_hits idx u32], amr_gather_slot_bytes(cap) bytes.
+ * [header AMR_GATHER_HEADER_BYTES | n_hits call indices u64 | n_hits idx u32], amr_gather_slot_bytes(cap) bytes in
+ * memory; on the wire the header and amr_gather_wire_bytes(n_hits) bytes of records (two messages per rank).
  * amr_gather_pack_host builds it from a host-side result (a transport other than RCCL, e.g. the gloo tests),
  * amr_gather_unpack reads one (pointers into `slot`).  Neither needs a device. */
 size_t amr_gather_slot_bytes(uint64_t cap_hits);
+/* bytes of records that travel behind the header for n_sent records: 12 * n_sent rounded up to 4 KiB (0 for none) */
+size_t amr_gather_wire_bytes(uint64_t n_sent);
 amr_status amr_gather_pack_host(const amr_result *res, uint64_t cap_hits, uint64_t seq, void *slot, size_t slot_bytes);
 amr_status amr_gather_unpack(const void *slot, size_t slot_bytes, amr_gathered *out);
 

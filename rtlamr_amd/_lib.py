@@ -14,13 +14,13 @@ AMR_OK, AMR_EINVAL, AMR_ENOMEM, AMR_EHIP, AMR_ENODEV, AMR_EOVERFLOW = 0, -1, -2,
 
 # every symbol include/amrdemod.h declares (checked by tests/test_abi.py)
 SYMBOLS = [
-    "amr_create", "amr_plan", "amr_destroy", "amr_reset", "amr_get_geometry", "amr_preamble_id", "amr_get_mag_lut", "amr_r900_enable", "amr_set_validation",
+    "amr_create", "amr_plan", "amr_destroy", "amr_device_count", "amr_reset", "amr_get_geometry", "amr_preamble_id", "amr_get_mag_lut", "amr_r900_enable", "amr_set_validation",
     "amr_set_stream", "amr_set_block_base", "amr_decode_batch", "amr_decode_batch_device", "amr_submit_device", "amr_collect", "amr_set_deferral", "amr_flush", "amr_submit_host", "amr_host_alloc", "amr_host_free", "amr_result_device", "amr_prime",
     "amr_halo_bytes", "amr_prime_blocks", "amr_copy_quantized", "amr_set_timing", "amr_get_timing", "amr_strerror",
     "amr_last_error", "amr_describe", "amr_dev_alloc", "amr_dev_free", "amr_dev_upload", "amr_dev_download",
     "amr_dev_sync", "amr_synth_noise", "amr_synth_plant",
     "amr_comm_unique_id", "amr_comm_init", "amr_comm_destroy", "amr_comm_ranks", "amr_gather_hits", "amr_gather_wait", "amr_gather_fetch",
-    "amr_gather_slot_bytes", "amr_gather_pack_host", "amr_gather_unpack",
+    "amr_gather_slot_bytes", "amr_gather_wire_bytes", "amr_gather_pack_host", "amr_gather_unpack",
 ]
 
 
@@ -146,15 +146,25 @@ def lib() -> C.CDLL:
     L.amr_gather_fetch.argtypes = [vp, C.c_uint64, C.c_int32, C.POINTER(AmrGathered)]
     L.amr_gather_slot_bytes.argtypes = [C.c_uint64]
     L.amr_gather_slot_bytes.restype = C.c_size_t
+    L.amr_gather_wire_bytes.argtypes = [C.c_uint64]
+    L.amr_gather_wire_bytes.restype = C.c_size_t
+    L.amr_device_count.argtypes = [C.POINTER(C.c_int32)]
     L.amr_gather_pack_host.argtypes = [C.POINTER(AmrResult), C.c_uint64, C.c_uint64, vp, C.c_size_t]
     L.amr_gather_unpack.argtypes = [vp, C.c_size_t, C.POINTER(AmrGathered)]
     for name in SYMBOLS:
         fn = getattr(L, name)
         if name not in ("amr_preamble_id", "amr_halo_bytes", "amr_prime_blocks", "amr_strerror", "amr_last_error",
-                        "amr_gather_slot_bytes"):
+                        "amr_gather_slot_bytes", "amr_gather_wire_bytes"):
             fn.restype = C.c_int
     _lib = L
     return L
+
+
+def device_count() -> int:
+    """gfx950 devices visible to this process (amr_device_count); 0 without a GPU."""
+    n = C.c_int32(0)
+    check(lib().amr_device_count(C.byref(n)), "amr_device_count")
+    return int(n.value)
 
 
 def check(status: int, where: str) -> None:

@@ -175,6 +175,8 @@ struct amr_handle {
     int next_slot = 0;           // slot the next submit uses
     int n_pending = 0;           // submitted, not yet collected (oldest = next_slot - n_pending)
     int last_slot = -1;          // slot of the last collected batch (amr_copy_quantized, result storage)
+    bool last_empty = false;     // the last result was the empty one of an amr_flush with nothing deferred: amr_gather_hits /
+                                 // amr_result_device then report zero records instead of the previous batch's
     uint64_t calls_done = 0, block_base = 0;
     size_t last_n_blocks = 0;
     std::vector<uint64_t> r_off;
@@ -569,7 +571,19 @@ amr_status submit(amr_handle *h, const uint8_t *d_iq, size_t n_blocks, bool sear
         h->iqhist_valid = (uint32_t)std::min<uint64_t>(v, (uint64_t)h->geom.packet_length);
     }
     if (!folded) {
-        hipLaunchKernelGGL(amr::k_hist_update, dim3(1 + ha.defer_wgs), dim3(1024), (size_t)h->hist_rows * h->sg.wpb * 4, st, ha);
+        // The copies of the deferred blocks run AHEAD of the kernel that publishes the batch ticket: amr_collect may return
+        // as soon as the ticket is there, and the caller may then overwrite the buffer the copies read
+        // (include/amrdemod.h: "the caller's buffer is free after the collect").
+        if (ha.defer_bytes) {
+            const uint32_t n16 = ha.defer_bytes / 16;
+            hipLaunchKernelGGL(k_copy16, dim3(std::min<uint32_t>(256, (n16 + 255) / 256)), dim3(256), 0, st,
+                               reinterpret_cast<const uint4 *>(ha.carry_src + ha.carry_bytes),
+                               reinterpret_cast<uint4 *>(ha.carry_dst + ha.carry_bytes), n16);
+            HIP_TRY(hipGetLastError());
+            ha.defer_bytes = 0;
+            ha.defer_wgs = 0;
+        }
+        hipLaunchKernelGGL(amr::k_hist_update, dim3(1), dim3(1024), (size_t)h->hist_rows * h->sg.wpb * 4, st, ha);
         HIP_TRY(hipGetLastError());
         AMR_DBG(st, "k_hist_update");
     }
@@ -808,6 +822,7 @@ amr_status collect(amr_handle *h, amr_result *res)
     h->n_pending--;
     if (s.search) {
         h->last_slot = si;
+        h->last_empty = false;
         h->last_n_blocks = s.n_blocks;
         const uint64_t *offs = h->validate ? s.h_offv : s.h_off;
         h->r_off.assign(offs, offs + n_pre + 1);
@@ -1143,6 +1158,8 @@ amr_status amr_set_stream(amr_handle *h, void *hip_stream)
 amr_status amr_set_block_base(amr_handle *h, uint64_t base)
 {
     if (!h) return fail(AMR_EINVAL, "null handle");
+    // deferred blocks keep the call indices they were submitted under: a new base in front of them would renumber them
+    if (h->n_head) return fail(AMR_EINVAL, "amr_set_block_base: blocks are deferred: amr_flush first");
     h->block_base = base;
     return AMR_OK;
 }
@@ -1190,6 +1207,8 @@ amr_status amr_flush(amr_handle *h, amr_result *res)
     if (h->n_head == 0) {          // nothing deferred: an empty result
         h->r_off.assign(h->sg.n_pre + 1, 0);
         h->last_total = 0;
+        h->last_searched = 0;
+        h->last_empty = true;      // a gather posted for this result sends zero records, not the previous batch's again
         if (res) {
             *res = amr_result{};
             res->n_preambles = h->sg.n_pre;
@@ -1246,7 +1265,8 @@ amr_status amr_collect(amr_handle *h, amr_result *res)
 amr_status amr_result_device(const amr_handle *h, const void **d_packed, uint64_t *n_hits)
 {
     if (!h || !d_packed || !n_hits) return fail(AMR_EINVAL, "null argument");
-    if (h->last_slot < 0) return fail(AMR_EINVAL, "no batch collected yet");
+    if (h->last_slot < 0 && !h->last_empty) return fail(AMR_EINVAL, "no batch collected yet");
+    if (h->last_empty) { *d_packed = nullptr; *n_hits = 0; return AMR_OK; }   // amr_flush with nothing deferred
     *d_packed = h->validate ? h->slot[h->last_slot].d_val : h->slot[h->last_slot].d_out;
     *n_hits = h->last_total;
     return AMR_OK;
@@ -1258,6 +1278,9 @@ size_t amr_prime_blocks(const amr_handle *h) { return h ? (size_t)h->hist_rows +
 amr_status amr_prime(amr_handle *h, const uint8_t *lead, const uint8_t *halo_iq, size_t n_blocks, int on_device)
 {
     if (!h || !halo_iq) return fail(AMR_EINVAL, "null argument");
+    // a launch without a search would demodulate the deferred blocks, drop their hits and leave every later call index
+    // short by their number
+    if (h->n_head) return fail(AMR_EINVAL, "amr_prime: blocks are deferred: amr_flush first");
     HIP_TRY(hipSetDevice(h->device));
     if (lead) {
         HIP_TRY(hipMemcpyAsync(h->d_head, lead, h->halo_bytes,
@@ -1425,8 +1448,17 @@ amr_status amr_synth_plant(int32_t device_id, void *d_iq, uint64_t n_samples, ui
 // instead of a timing assumption.  The send buffer of set k is reused by the pack of gather seq + 2 on the same stream,
 // i.e. in order behind the send that read it.
 //
-// Root side.  Behind the receives of a gather, on the same stream, an asynchronous copy brings every rank's slot
-// (header + the records it holds, sized by the capacity) into a pinned host mirror and an event marks its arrival:
+// What travels is sized by the hit count, not by the capacity (round 4; a fixed 1.5 x capacity slot was 5.2 MB per rank
+// and step for raw hits whatever the batch held).  Two phases per gather, both on the communicator's stream:
+//   1. every rank sends its 128-byte slot header (true count, records sent, per-preamble offsets, sequence number);
+//   2. every rank with records sends exactly gather_wire_bytes(n_sent) = 12 * n_sent bytes rounded up to 4 KiB.
+// A sender knows its count on the host (amr_collect returned it) and never waits.  The ROOT has to know every peer's
+// count before it can post the receives of phase 2 (RCCL point-to-point needs matching sizes): it copies the received
+// headers to pinned memory and waits for that copy -- the one host wait of the protocol, 128 bytes per rank, on the
+// root only, and only as long as the slowest peer takes to post the same gather.
+//
+// Root side.  Behind the receives of a gather, on the same stream, one kernel mirrors every rank's slot (header + the
+// records it holds) into pinned host memory and an event marks its arrival:
 // amr_gather_fetch(seq, rank) waits for that event only -- no stream synchronisation, no blocking copy -- and returns
 // pointers into the mirror.  Two sets alternate: the records of gather `seq` stay valid until gather seq + 2 is posted.
 //
@@ -1493,9 +1525,16 @@ amr_status nccl_fail(const char *what, int rc)
 constexpr uint32_t kGatherHdr = AMR_GATHER_HEADER_BYTES / 8;
 static_assert(3 + AMR_MAX_PREAMBLES + 1 <= 12 && kGatherHdr >= 13, "gather header layout");
 
+// bytes of records that travel for n_sent of them: [n_sent call indices u64 | n_sent idx u32], rounded up to 4 KiB
+__host__ __device__ inline size_t gather_wire_bytes(uint64_t n_sent)
+{
+    return ((size_t)n_sent * 12 + 4095) & ~(size_t)4095;
+}
+
+// a slot in memory: header + room for the wire bytes of `cap` records
 __host__ __device__ inline size_t gather_slot_bytes(uint64_t cap)
 {
-    return ((size_t)kGatherHdr * 8 + (size_t)cap * 12 + 255) & ~(size_t)255;
+    return ((size_t)kGatherHdr * 8 + gather_wire_bytes(cap) + 255) & ~(size_t)255;
 }
 
 // element i of `stride` workers: header words and records of a packed result [blk u64 x n | idx u32 x n | ...]
@@ -1515,6 +1554,20 @@ __global__ void k_gather_pack(const uint8_t *packed, const uint64_t *offs, uint3
     const uint64_t n = offs[n_pre];
     gather_pack_part(reinterpret_cast<const uint64_t *>(packed), reinterpret_cast<const uint32_t *>(packed + n * 8), offs, n_pre,
                      cap, seq, slot, (uint64_t)blockIdx.x * blockDim.x + threadIdx.x, (uint64_t)gridDim.x * blockDim.x);
+}
+
+// Root: headers (received contiguously, phase 1) and records (phase 2, in place behind each rank's header slot) of all
+// ranks -> the pinned host mirror, laid out as slots again.  grid (x, world): the x blocks of rank p share its records.
+__global__ void k_gather_mirror(const uint8_t *d_hdr, const uint8_t *d_recv, uint8_t *h_recv, size_t slot_bytes)
+{
+    const uint32_t p = blockIdx.y;
+    const uint4 *hdr = reinterpret_cast<const uint4 *>(d_hdr + (size_t)p * kGatherHdr * 8);
+    const uint64_t m = reinterpret_cast<const uint64_t *>(hdr)[1];
+    uint4 *dst = reinterpret_cast<uint4 *>(h_recv + (size_t)p * slot_bytes);
+    const uint4 *src = reinterpret_cast<const uint4 *>(d_recv + (size_t)p * slot_bytes);
+    const uint64_t n16 = kGatherHdr * 8 / 16 + (m * 12 + 15) / 16;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n16; i += (uint64_t)gridDim.x * blockDim.x)
+        dst[i] = i < kGatherHdr * 8 / 16 ? hdr[i] : src[i];
 }
 
 amr_status gather_unpack(const void *slot, size_t slot_bytes, amr_gathered *out)
@@ -1542,8 +1595,12 @@ struct Comm {
     size_t slot_bytes = 0;
     hipStream_t stream = nullptr;
     uint8_t *d_send[2] = {nullptr, nullptr};
-    uint8_t *d_recv[2] = {nullptr, nullptr};   // root: world slots each
+    uint8_t *d_recv[2] = {nullptr, nullptr};   // root: world slots each (records land behind each slot's header bytes)
     uint8_t *h_recv[2] = {nullptr, nullptr};   // root: pinned mirror of d_recv
+    uint8_t *d_hdr[2] = {nullptr, nullptr};    // root: world headers, contiguous (phase 1)
+    uint8_t *h_hdr[2] = {nullptr, nullptr};    // root: pinned copy of d_hdr -- the counts that size phase 2
+    uint64_t *d_zero = nullptr;                // AMR_MAX_PREAMBLES + 1 zero offsets: the packed form of an empty result
+    hipEvent_t ev_hdr = nullptr;               // root: the headers of the gather being posted are in h_hdr
     hipEvent_t ev_host[2] = {nullptr, nullptr};   // root: the mirror of set k has arrived
     uint64_t seq_of[2] = {~0ull, ~0ull};       // gather sequence number each set holds
     uint64_t next_seq = 0;
@@ -1552,6 +1609,22 @@ struct Comm {
 extern "C" {
 
 size_t amr_gather_slot_bytes(uint64_t cap_hits) { return gather_slot_bytes(cap_hits); }
+size_t amr_gather_wire_bytes(uint64_t n_sent) { return gather_wire_bytes(n_sent); }
+
+amr_status amr_device_count(int32_t *n_devices)
+{
+    if (!n_devices) return fail(AMR_EINVAL, "null argument");
+    *n_devices = 0;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return AMR_OK;    // none: not an error, the count is the answer
+    int n = 0;
+    for (int d = 0; d < ndev; ++d) {
+        hipDeviceProp_t prop;
+        if (hipGetDeviceProperties(&prop, d) == hipSuccess && strncmp(prop.gcnArchName, "gfx950", 6) == 0) ++n;
+    }
+    *n_devices = n;
+    return AMR_OK;
+}
 
 amr_status amr_gather_pack_host(const amr_result *res, uint64_t cap_hits, uint64_t seq, void *slot, size_t slot_bytes)
 {
@@ -1581,7 +1654,7 @@ amr_status amr_comm_unique_id(void *id128)
 amr_status amr_comm_init(amr_handle *h, const void *id128, int32_t rank, int32_t world, int32_t root, uint64_t cap_hits)
 {
     if (!h || !id128) return fail(AMR_EINVAL, "null argument");
-    if (world < 1 || rank < 0 || rank >= world || root < 0 || root >= world || cap_hits == 0) return fail(AMR_EINVAL, "amr_comm_init: bad rank / world / capacity");
+    if (world < 1 || world > 65535 || rank < 0 || rank >= world || root < 0 || root >= world || cap_hits == 0) return fail(AMR_EINVAL, "amr_comm_init: bad rank / world / capacity");
     if (h->comm) return fail(AMR_EINVAL, "amr_comm_init: communicator exists already");
     Rccl *r = rccl();
     if (!r) return fail(AMR_ENODEV, "RCCL (librccl.so) not found");
@@ -1600,7 +1673,12 @@ amr_status amr_comm_init(amr_handle *h, const void *id128, int32_t rank, int32_t
         if (e == hipSuccess && rank == root) e = hipMalloc((void **)&c->d_recv[k], c->slot_bytes * (size_t)world);
         if (e == hipSuccess && rank == root) e = hipHostMalloc((void **)&c->h_recv[k], c->slot_bytes * (size_t)world, hipHostMallocDefault);
         if (e == hipSuccess && rank == root) e = hipEventCreateWithFlags(&c->ev_host[k], hipEventDisableTiming);
+        if (e == hipSuccess && rank == root) e = hipMalloc((void **)&c->d_hdr[k], (size_t)world * kGatherHdr * 8);
+        if (e == hipSuccess && rank == root) e = hipHostMalloc((void **)&c->h_hdr[k], (size_t)world * kGatherHdr * 8, hipHostMallocDefault);
     }
+    if (e == hipSuccess && rank == root) e = hipEventCreateWithFlags(&c->ev_hdr, hipEventDisableTiming);
+    if (e == hipSuccess) e = hipMalloc((void **)&c->d_zero, (AMR_MAX_PREAMBLES + 1) * 8);
+    if (e == hipSuccess) e = hipMemsetAsync(c->d_zero, 0, (AMR_MAX_PREAMBLES + 1) * 8, c->stream);
     h->comm = c;
     if (e != hipSuccess) { (void)amr_comm_destroy(h); return fail(AMR_ENOMEM, "amr_comm_init: buffers", e); }
     return AMR_OK;
@@ -1631,7 +1709,11 @@ amr_status amr_comm_destroy(amr_handle *h)
         if (c->d_recv[k]) (void)hipFree(c->d_recv[k]);
         if (c->h_recv[k]) (void)hipHostFree(c->h_recv[k]);
         if (c->ev_host[k]) (void)hipEventDestroy(c->ev_host[k]);
+        if (c->d_hdr[k]) (void)hipFree(c->d_hdr[k]);
+        if (c->h_hdr[k]) (void)hipHostFree(c->h_hdr[k]);
     }
+    if (c->ev_hdr) (void)hipEventDestroy(c->ev_hdr);
+    if (c->d_zero) (void)hipFree(c->d_zero);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
     h->comm = nullptr;
@@ -1641,30 +1723,58 @@ amr_status amr_comm_destroy(amr_handle *h)
 amr_status amr_gather_hits(amr_handle *h, uint64_t *seq_out)
 {
     if (!h || !h->comm) return fail(AMR_EINVAL, "amr_gather_hits: amr_comm_init first");
-    if (h->last_slot < 0) return fail(AMR_EINVAL, "amr_gather_hits: no batch collected yet");
+    if (h->last_slot < 0 && !h->last_empty) return fail(AMR_EINVAL, "amr_gather_hits: no batch collected yet");
     Rccl *r = rccl();
     Comm *c = h->comm;
     HIP_TRY(hipSetDevice(h->device));
-    Slot &s = h->slot[h->last_slot];
-    const uint8_t *packed = h->validate ? s.d_val : s.d_out;
-    const uint64_t *offs = h->validate ? s.d_offs_val : s.d_offs_pre;
+    // the result amr_collect / amr_flush returned last; an amr_flush with nothing deferred returned an EMPTY one: zero
+    // records travel (the slot of the batch before it still holds that batch's hits)
+    const bool empty = h->last_empty;
+    Slot *s = empty ? nullptr : &h->slot[h->last_slot];
+    const uint8_t *packed = empty ? reinterpret_cast<const uint8_t *>(c->d_zero) : (h->validate ? s->d_val : s->d_out);
+    const uint64_t *offs = empty ? c->d_zero : (h->validate ? s->d_offs_val : s->d_offs_pre);
+    const uint64_t n_host = empty ? 0 : h->last_total;                 // = offs[n_pre] on the device
+    const uint64_t m_host = n_host < c->cap ? n_host : c->cap;         // records this rank sends
     const uint64_t seq = c->next_seq++;
     const int k = (int)(seq & 1);
-    // on the communicator's stream: behind the send (and the root's mirror copy) that last used buffer set k
+    // on the communicator's stream: behind the sends (and the root's mirror kernel) that last used buffer set k
     hipLaunchKernelGGL(k_gather_pack, dim3(64), dim3(256), 0, c->stream, packed, offs, h->sg.n_pre, c->cap, seq,
                        reinterpret_cast<uint64_t *>(c->d_send[k]));
     HIP_TRY(hipGetLastError());
-    // whoever overwrites this slot's result next waits for the pack kernel (enqueue_tail)
-    HIP_TRY(hipEventRecord(s.ev_pack, c->stream));
-    s.pack_pending = true;
+    if (s) {   // whoever overwrites this slot's result next waits for the pack kernel (enqueue_tail)
+        HIP_TRY(hipEventRecord(s->ev_pack, c->stream));
+        s->pack_pending = true;
+    }
+    const size_t hdr_bytes = (size_t)kGatherHdr * 8;
+    // ---- phase 1: the headers ----
     NCCL_TRY(r->GroupStart());
-    NCCL_TRY(r->Send(c->d_send[k], c->slot_bytes, kNcclUint8, c->root, c->comm, c->stream));
+    NCCL_TRY(r->Send(c->d_send[k], hdr_bytes, kNcclUint8, c->root, c->comm, c->stream));
     if (c->rank == c->root)
         for (int p = 0; p < c->world; ++p)
-            NCCL_TRY(r->Recv(c->d_recv[k] + (size_t)p * c->slot_bytes, c->slot_bytes, kNcclUint8, p, c->comm, c->stream));
+            NCCL_TRY(r->Recv(c->d_hdr[k] + (size_t)p * hdr_bytes, hdr_bytes, kNcclUint8, p, c->comm, c->stream));
     NCCL_TRY(r->GroupEnd());
-    if (c->rank == c->root) {
-        HIP_TRY(hipMemcpyAsync(c->h_recv[k], c->d_recv[k], c->slot_bytes * (size_t)c->world, hipMemcpyDeviceToHost, c->stream));
+    // ---- phase 2: the records, sized by their count ----
+    if (c->rank != c->root) {
+        if (m_host) NCCL_TRY(r->Send(c->d_send[k] + hdr_bytes, gather_wire_bytes(m_host), kNcclUint8, c->root, c->comm, c->stream));
+    } else {
+        HIP_TRY(hipMemcpyAsync(c->h_hdr[k], c->d_hdr[k], (size_t)c->world * hdr_bytes, hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(hipEventRecord(c->ev_hdr, c->stream));
+        HIP_TRY(hipEventSynchronize(c->ev_hdr));        // every rank has posted this gather; 128 bytes each
+        const uint64_t *hh = reinterpret_cast<const uint64_t *>(c->h_hdr[k]);
+        for (int p = 0; p < c->world; ++p) {
+            const uint64_t *hp = hh + (size_t)p * kGatherHdr;
+            if (hp[1] > c->cap || hp[1] > hp[0] || hp[12] != seq)
+                return fail(AMR_EHIP, "amr_gather_hits: a rank's header is inconsistent (ranks out of step, or capacities differ)");
+        }
+        NCCL_TRY(r->GroupStart());
+        if (m_host) NCCL_TRY(r->Send(c->d_send[k] + hdr_bytes, gather_wire_bytes(m_host), kNcclUint8, c->root, c->comm, c->stream));
+        for (int p = 0; p < c->world; ++p) {
+            const uint64_t m_p = hh[(size_t)p * kGatherHdr + 1];
+            if (m_p) NCCL_TRY(r->Recv(c->d_recv[k] + (size_t)p * c->slot_bytes + hdr_bytes, gather_wire_bytes(m_p), kNcclUint8, p, c->comm, c->stream));
+        }
+        NCCL_TRY(r->GroupEnd());
+        hipLaunchKernelGGL(k_gather_mirror, dim3(8, (unsigned)c->world), dim3(256), 0, c->stream, c->d_hdr[k], c->d_recv[k], c->h_recv[k], c->slot_bytes);
+        HIP_TRY(hipGetLastError());
         HIP_TRY(hipEventRecord(c->ev_host[k], c->stream));
     }
     c->seq_of[k] = seq;

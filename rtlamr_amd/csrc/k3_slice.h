@@ -8,7 +8,8 @@ namespace amr {
 __global__ __launch_bounds__(1024) void k_hist_update(const HistArgs a)
 {
     extern __shared__ uint32_t hist_tmp[];  // hr*wpb words
-    if (blockIdx.x) { defer_copy_body(a, blockIdx.x - 1, 1024); return; }
+    // one workgroup.  The copies of deferred blocks are NOT part of this kernel (submit runs them ahead of it): the ticket
+    // below tells the host that the caller's buffer is free
     hist_body(a, hist_tmp, 1024);
     // every earlier kernel of the batch has completed (same stream); the host polls these words
     if (threadIdx.x == 0) hist_publish(a);

@@ -98,9 +98,12 @@ def rows_from_gathered(off, blk, idx) -> np.ndarray:
 class HitGatherer:
     """The hit gather for hosts WITHOUT RCCL (CPU ranks, gloo): the same slot -- header, call indices, idx, laid out by
     the C library's amr_gather_pack_host / amr_gather_unpack, the very code the device pack kernel and amr_gather_fetch
-    are built from -- moved by torch.distributed.gather instead of ncclSend/ncclRecv.  Same protocol as CommGatherer:
-    fixed capacity agreed up front, one collective per batch, two buffer sets, a sequence number per gather, a batch
-    with more records than the capacity arrives truncated with its true count."""
+    are built from -- and the same two-phase protocol as amr_gather_hits, moved by torch.distributed instead of
+    ncclSend/ncclRecv: every rank sends its 128-byte header, the root reads the counts, then every rank with records
+    sends exactly amr_gather_wire_bytes(n_sent) bytes.  Fixed capacity agreed up front, two buffer sets, a sequence
+    number per gather; a batch with more records than the capacity arrives truncated with its true count."""
+
+    HDR = 128
 
     def __init__(self, n_preambles: int, cap_hits: int, root: int = 0, group=None):
         import torch
@@ -114,29 +117,61 @@ class HitGatherer:
         self.send = [torch.zeros(self.slot_bytes, dtype=torch.uint8) for _ in range(2)]
         self.recv = [[torch.zeros(self.slot_bytes, dtype=torch.uint8) for _ in range(self.world)]
                      if self.rank == root else None for _ in range(2)]
-        self.work = [None, None]
+        self.work = [[], []]
         self.seq_of = [None, None]
         self.next_seq = 0
+        self.sent_bytes = []          # per gather: bytes this rank put on the wire (header + records)
+
+    def wire_bytes(self, n_sent: int) -> int:
+        return int(self.L.amr_gather_wire_bytes(n_sent))
+
+    def _drain(self, k: int) -> None:
+        for w in self.work[k]:
+            w.wait()
+        self.work[k] = []
 
     def post(self, br) -> int:
-        """Enqueue the gather of one batch result; returns its sequence number."""
+        """Enqueue the gather of one batch result; returns its sequence number.  Like amr_gather_hits: a non-root rank
+        does not wait for anybody, the root waits for every rank's header (it needs the counts)."""
         from . import _lib
+        torch, dist = self.torch, self.dist
         seq = self.next_seq
         self.next_seq += 1
         k = seq & 1
-        if self.work[k] is not None:
-            self.work[k].wait()
+        self._drain(k)
         r, keep = _result_struct(br, self.n_pre)
         _lib.check(self.L.amr_gather_pack_host(r, self.cap, seq, self.send[k].data_ptr(), self.slot_bytes), "amr_gather_pack_host")
-        self.work[k] = self.dist.gather(self.send[k], self.recv[k], dst=self.root, group=self.group, async_op=True)
+        n_sent = min(int(r.n_hits), self.cap)
+        wire = self.wire_bytes(n_sent)
+        self.sent_bytes.append(self.HDR + wire)
+        # phase 1: the headers
+        hdrs = [torch.zeros(self.HDR, dtype=torch.uint8) for _ in range(self.world)] if self.rank == self.root else None
+        hw = dist.gather(self.send[k][: self.HDR].clone(), hdrs, dst=self.root, group=self.group, async_op=True)
+        if self.rank != self.root:
+            self.work[k].append(hw)
+            if n_sent:      # phase 2: the records, sized by their count
+                self.work[k].append(dist.isend(self.send[k][self.HDR: self.HDR + wire], dst=self.root, group=self.group, tag=seq & 0xffff))
+        else:
+            hw.wait()
+            for p in range(self.world):
+                hp = hdrs[p].numpy().view(np.uint64)
+                if int(hp[1]) > self.cap or int(hp[1]) > int(hp[0]) or int(hp[12]) != seq:
+                    raise RuntimeError(f"gather {seq}: rank {p}'s header is inconsistent (ranks out of step?)")
+                self.recv[k][p][: self.HDR] = hdrs[p]
+                m = int(hp[1])
+                if not m:
+                    continue
+                if p == self.rank:
+                    self.recv[k][p][self.HDR: self.HDR + 12 * m] = self.send[k][self.HDR: self.HDR + 12 * m]
+                else:
+                    self.work[k].append(dist.irecv(self.recv[k][p][self.HDR: self.HDR + self.wire_bytes(m)], src=p,
+                                                   group=self.group, tag=seq & 0xffff))
         self.seq_of[k] = seq
         return seq
 
     def wait(self) -> None:
         for k in range(2):
-            if self.work[k] is not None:
-                self.work[k].wait()
-                self.work[k] = None
+            self._drain(k)
 
     def fetch(self, seq: int, src_rank: int):
         """Root: (n_true, offsets, call indices, idx) of rank src_rank in gather `seq`."""
@@ -146,9 +181,7 @@ class HitGatherer:
         k = seq & 1
         if self.seq_of[k] != seq:
             raise KeyError(f"gather {seq} was never posted or has been overwritten")
-        if self.work[k] is not None:
-            self.work[k].wait()
-            self.work[k] = None
+        self._drain(k)
         g = _lib.AmrGathered()
         _lib.check(self.L.amr_gather_unpack(self.recv[k][src_rank].data_ptr(), self.slot_bytes, C.byref(g)), "amr_gather_unpack")
         if int(g.seq) != seq:

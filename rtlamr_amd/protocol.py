@@ -244,6 +244,11 @@ class Decoder:
     def gather_slot_bytes(self, cap_hits: int) -> int:
         return int(_lib.lib().amr_gather_slot_bytes(cap_hits))
 
+    @staticmethod
+    def gather_wire_bytes(n_sent: int) -> int:
+        """Bytes of records a rank with n_sent of them sends behind its 128-byte header."""
+        return int(_lib.lib().amr_gather_wire_bytes(n_sent))
+
     def comm_ranks(self) -> int:
         """Ranks the RCCL communicator spans (ncclCommCount)."""
         n = C.c_int32()

@@ -20,6 +20,7 @@ from typing import BinaryIO, Iterator, List, Tuple
 
 import numpy as np
 
+from . import _lib
 from . import protocol as ra
 
 
@@ -31,6 +32,7 @@ def replay(dec: ra.Decoder, stream: BinaryIO, batch_blocks: int = 16384, unique:
     block (main.go:252-260: the `prev` / `next` maps keyed on protocol.NewDigest)."""
     bs2 = dec.Cfg.BlockSize2
     bufs = [ra.PinnedBuffer(batch_blocks * bs2) for _ in range(3)]
+    deferring = False
     try:
         pending: List[int] = []     # buffer index per batch in flight
         prev_seen: set = set()
@@ -42,7 +44,9 @@ def replay(dec: ra.Decoder, stream: BinaryIO, batch_blocks: int = 16384, unique:
         try:
             dec.SetDeferral(True)
             deferring = True
-        except Exception:           # a decoder with the r900 second stage: batches are decoded as handed over
+        except _lib.AmrError as e:  # a decoder with the r900 second stage (AMR_EINVAL): batches are decoded as handed over
+            if e.status != _lib.AMR_EINVAL:
+                raise               # anything else (a closed handle, a device fault) is the caller's to see
             deferring = False
 
         def drain_one(flush=False):
@@ -93,6 +97,14 @@ def replay(dec: ra.Decoder, stream: BinaryIO, batch_blocks: int = 16384, unique:
             except Exception:      # the handle is beyond use; freeing the buffers is all that is left to do
                 break
             pending.pop(0)
+        # the decoder goes back to its caller as it came: nothing of THIS stream left in the head buffer (a later
+        # decode_batch / replay on the same Decoder would silently prepend those blocks), deferral off
+        if deferring:
+            try:
+                dec.flush(copy=False)               # closed early: the deferred blocks belong to an abandoned stream (discarded);
+                dec.SetDeferral(False)              # after a complete replay nothing is deferred and this is an empty result
+            except _lib.AmrError:
+                pass                                # the handle is beyond use
         for b in bufs:
             b.free()
 

@@ -118,10 +118,25 @@ def _w_gatherer(rank, world, port, out):
             for r in range(world):
                 n_true, off, b, i = g.fetch(step - 1, r)
                 (trunc if n_true > len(b) else got).append((step - 1, r, n_true, dist.rows_from_gathered(off, b, i)))
+    # what went over the wire follows the hit count (header + 12 bytes per record sent, rounded up to 4 KiB), not the capacity
+    for step in range(5):
+        n = min(2000, 3 + step * (rank + 1) * 300 + 2 + step)
+        assert g.sent_bytes[step] == 128 + ((12 * n + 4095) // 4096) * 4096, (step, g.sent_bytes)
+    # unequal remainders at the end of a stream: rank 1's amr_flush had nothing deferred (an EMPTY result), rank 0's had
+    # hits -- every rank still posts one gather per result, and the empty one carries zero records, not the batch before
+    n5 = 4 if rank == 0 else 0
+    br = BatchResult(8, 0, np.array([0, n5, n5], np.uint64), np.arange(n5, dtype=np.uint64) + 77, np.arange(n5, dtype=np.uint32),
+                     np.zeros((n5, 12), np.uint8))
+    assert g.post(br) == 5
+    assert g.sent_bytes[5] == (128 + 4096 if rank == 0 else 128)
     if rank == 0:
         for r in range(world):
             n_true, off, b, i = g.fetch(4, r)
             (trunc if n_true > len(b) else got).append((4, r, n_true, dist.rows_from_gathered(off, b, i)))
+        n_true, off, b, i = g.fetch(5, 0)
+        assert n_true == 4 and b.tolist() == [77, 78, 79, 80]
+        n_true, off, b, i = g.fetch(5, 1)
+        assert n_true == 0 and len(b) == 0 and len(i) == 0 and off.tolist() == [0, 0, 0]
         np.save(os.path.join(out, "hg.npy"), np.concatenate([x[3] for x in got]))
         np.save(os.path.join(out, "trunc.npy"), np.array([(x[0], x[1], x[2], len(x[3])) for x in trunc], np.int64))
     g.wait()
@@ -132,7 +147,8 @@ def _w_gatherer(rank, world, port, out):
 def test_hit_gatherer_drives_the_c_slot_layout(tmp_path):
     """rtlamr_amd.dist.HitGatherer on gloo: the slot every rank sends is packed by amr_gather_pack_host and read by
     amr_gather_unpack -- the code the device pack kernel and amr_gather_fetch are built from -- across buffer-set
-    reuse, a lagging rank, different data per gather, and a slot that overflows (truncated, true count kept)."""
+    reuse, a lagging rank, different data per gather, a slot that overflows (truncated, true count kept), an empty result
+    on one rank only, and the two-phase wire rule (header, then records sized by their count)."""
     port = 33500 + (os.getpid() % 2000)
     mp.spawn(_w_gatherer, args=(2, port, str(tmp_path)), nprocs=2, join=True)
     got = np.load(os.path.join(str(tmp_path), "hg.npy"))
@@ -166,7 +182,7 @@ def test_slot_layout_pack_unpack_on_cpu():
     r, keep = dist._result_struct(br, 3)
     for cap in (64, 14, 6):
         nb = int(L.amr_gather_slot_bytes(cap))
-        assert nb % 256 == 0 and nb >= 128 + 12 * cap
+        assert nb % 256 == 0 and nb >= 128 + int(L.amr_gather_wire_bytes(cap)) >= 128 + 12 * cap
         slot = np.zeros(nb, np.uint8)
         assert L.amr_gather_pack_host(r, cap, 77, slot.ctypes.data, nb) == _lib.AMR_OK
         g = _lib.AmrGathered()
@@ -175,6 +191,7 @@ def test_slot_layout_pack_unpack_on_cpu():
         m = min(cap, 14)
         assert (n_true, int(g.seq), int(g.n_preambles)) == (14, 77, 3)
         assert off.tolist() == [0, 5, 5, 14] and np.array_equal(b, blk[:m]) and np.array_equal(i, idx[:m])
+    assert [int(L.amr_gather_wire_bytes(n)) for n in (0, 1, 341, 342, 4169, 290131)] == [0, 4096, 4096, 8192, 53248, 3481600]
     slot = np.zeros(int(L.amr_gather_slot_bytes(64)), np.uint8)
     assert L.amr_gather_pack_host(r, 64, 0, slot.ctypes.data, 256) == _lib.AMR_EINVAL          # slot too small
     r.n_hits = 13

@@ -34,6 +34,35 @@ def test_gather_world1_returns_the_batch_hits():
         dec.close()
 
 
+def test_gather_after_an_empty_flush_sends_zero_records():
+    """amr_flush with nothing deferred returns an empty result; the gather posted for it must carry
+    ZERO records (ranks end a stream with unequal remainders and still post one gather per result), not the previous
+    batch's hits again; amr_result_device pairs that result with no buffer."""
+    import ctypes as C
+    from rtlamr_amd import _lib, dist
+    dec = util.make_decoder(["scm"], 72)
+    try:
+        iq, _ = util.synth_stream(["scm"], 72, 128, dec.Cfg.BlockSize, seed=23, n_packets=6)
+        dec.comm_init(dist.comm_unique_id(), 0, 1, 0, cap_hits=1 << 16)
+        dec.SetDeferral(True)
+        dec.submit_host(iq)                                  # 128 blocks: two whole wave-tiles, nothing deferred
+        br = dec.collect()
+        assert br.n_blocks == 128 and len(br.hit_idx) > 0
+        s0 = dec.gather_hits()
+        fl = dec.flush()
+        assert fl.n_blocks == 0 and len(fl.hit_idx) == 0
+        s1 = dec.gather_hits()                               # the empty result's gather
+        n_true, off, blk, idx = dec.gather_fetch(0, s0)
+        assert n_true == len(br.hit_idx) and np.array_equal(blk, np.asarray(br.hit_block, np.uint64))
+        n_true, off, blk, idx = dec.gather_fetch(0, s1)
+        assert n_true == 0 and len(blk) == 0 and len(idx) == 0 and not off.any()
+        d_ptr, n = C.c_void_p(1), C.c_uint64(99)
+        _lib.check(_lib.lib().amr_result_device(dec._require(), C.byref(d_ptr), C.byref(n)), "amr_result_device")
+        assert n.value == 0 and not d_ptr.value
+    finally:
+        dec.close()
+
+
 def test_gather_reports_truncation():
     from rtlamr_amd import dist
     dec = util.make_decoder(["scm"], 72)

@@ -142,11 +142,32 @@ def test_deferral_rules():
         assert L.amr_flush(dec._require(), C.byref(res)) == _lib.AMR_EINVAL           # a batch is in flight
         assert dec.collect().n_blocks == 64
         assert L.amr_set_deferral(dec._require(), 0) == _lib.AMR_EINVAL               # 36 blocks are deferred
+        # ... and neither a priming launch (no search: their hits would be dropped, later call indices short by 36) nor a
+        # new block base (it would renumber them) is accepted in front of them
+        assert L.amr_prime(dec._require(), None, iq.ctypes.data, 1, 0) == _lib.AMR_EINVAL
+        assert b"amr_flush first" in L.amr_last_error()
+        assert L.amr_set_block_base(dec._require(), 1000) == _lib.AMR_EINVAL
         dec.reset()
         assert dec.flush().n_blocks == 0                                              # reset forgot them
         dec.SetDeferral(False)
         want = util.oracle_run(["scm"], 72, iq)
         got = util.gpu_run(dec, iq)                                                   # and the decoder is fresh
+        util.assert_same(want, got, dec.Cfg.PacketSymbols)
+    finally:
+        dec.close()
+    # a replay closed early hands the decoder back clean: no block of the abandoned stream in the head buffer, deferral off
+    from rtlamr_amd import replay
+    import io
+    dec = util.make_decoder(["scm"], 72)
+    try:
+        iq, _ = util.synth_stream(["scm"], 72, 300, dec.Cfg.BlockSize, seed=45, n_packets=6)
+        gen = replay.replay(dec, io.BytesIO(iq.tobytes()), batch_blocks=100)
+        next(gen, None)
+        gen.close()                                       # up to two batches in flight, 36 + ... blocks deferred
+        assert L.amr_set_deferral(dec._require(), 0) == _lib.AMR_OK                   # nothing deferred, already off
+        dec.reset()
+        want = util.oracle_run(["scm"], 72, iq[: 70 * dec.Cfg.BlockSize2])
+        got = util.gpu_run(dec, iq[: 70 * dec.Cfg.BlockSize2])                        # no stale block in front of this stream
         util.assert_same(want, got, dec.Cfg.PacketSymbols)
     finally:
         dec.close()
