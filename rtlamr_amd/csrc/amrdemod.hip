@@ -360,15 +360,19 @@ amr_status enqueue_k2(amr_handle *h, Slot &s, hipStream_t st, bool rerun, bool d
     // from 512 to 8192
     bool walk_ok = !h->dense_search && !dense && n_pre <= 4 && h->sg.wpb >= 16 && h->sg.wpb <= 256;
     uint32_t walk_set = 0;
+    int last_kind = -1;
     for (uint32_t q = 0; q < n_pre && walk_ok; ++q) {
         const int kind = amr::k2_walk_kind_of(h->sg.pre_len[q], h->sg.pre_bits[q]);
         walk_ok = kind >= 0;
-        if (kind >= 0) { walk_set |= 1u << kind; k2.walk_pids |= q << (8 * kind); }
+        if (kind >= 0) { walk_set |= 1u << kind; k2.walk_pids |= q << (8 * kind); last_kind = kind; }
     }
     if (walk_ok) {
         const uint32_t n_wg = (s.n_tiles + amr::kK2WWaves - 1) / amr::kK2WWaves + extra;
-        walk_ok = amr::launch_k2_walk(h->sg.symbol_length, walk_set, 8u * ((n_wg + 7u) / 8u) /* XCD-contiguous tile order: 8 equal runs */,
-                                      amr::k2_walk_lds_bytes(h->hist_rows * h->sg.wpb), st, k2start, k2stop, k2, &le);
+        const uint32_t grid = 8u * ((n_wg + 7u) / 8u);   // XCD-contiguous tile order: 8 equal runs
+        const size_t lds = amr::k2_walk_lds_bytes(h->hist_rows * h->sg.wpb);
+        // one preamble, rows of up to 128 words: the whole row in registers, the look-ahead from the neighbour lane (k2_row.h)
+        walk_ok = (n_pre == 1 && amr::launch_k2_row(h->sg.symbol_length, (uint32_t)last_kind, grid, lds, st, k2start, k2stop, k2, &le)) ||
+                  amr::launch_k2_walk(h->sg.symbol_length, walk_set, grid, lds, st, k2start, k2stop, k2, &le);
     }
     // fallbacks: the list-based kernel splits a row's words over 4 or 8 waves, 4 or 8 words per step: rows of fewer
     // than 16 words (BlockSize 256: scm+ alone at chip length 8) and more than four preambles go through the dense kernel

@@ -1,0 +1,344 @@
+// K2 (fourth generation, one preamble) -- Decoder.Search (protocol/decode.go:255-328) with the WHOLE ROW IN REGISTERS.
+//
+// k2_walk.h walks a row through a register ring of NEED + PF chunks and, past the row end, goes on reading the next row
+// from memory: every row's look-ahead (LOOK words: 68 of 128 at SymbolLength 144, scm) is fetched twice -- 1.53 x the
+// bitstream at BlockSize 4096, 1.70 x measured (profiles/r03/pmc_summary_cfg2.json) -- and the walk is a chain of
+// exposed latencies (PF chunks of 1 KiB in flight per wave, 60 % of the wave-cycles waiting).  For ONE preamble and
+// rows of up to 128 words neither is necessary:
+//   * a lane loads its whole row at once, CPR = WPB / 4 coalesced global_load_dwordx4 back to back (the tiled4 layout:
+//     chunk c of the wave's 64 rows is one contiguous KiB): the tile's 32 KiB are in flight together, the memory
+//     system streams instead of answering five requests per wave at a time;
+//   * the look-ahead of a lane is the head of the NEXT row -- which the neighbour lane holds in its registers.  Chunk c
+//     of a lane's own row is dead once group c has been swept (the lanes of a wave run in lockstep: dead for all of
+//     them at once), so right then the register is shifted IN PLACE by one lane (v_mov_b32 dpp wave_shl:1): slot c now
+//     holds chunk CPR + c of the lane's stream.  The row is its own ring, RW = WPB, and the window code of k2_walk.h
+//     (ring index = stream word mod RW) applies unchanged.  Lane 63 continues in row 0 of the next tile: lanes
+//     0 .. NEED-2 fetch those chunks once (one load instruction) and v_readlane / v_writelane patch lane 63;
+//   * nothing is over-fetched: the bitstream is read 1.0 x plus 16 bytes per chunk of look-ahead and tile (7 % at scm).
+// Sweep, candidate list, stage 2, ranks and emission are those of k2_walk.h (same staging / counts / overflow protocol:
+// K3 and the host see no difference).  Used for a decoder whose ONE preamble is one of rtlamr's four and whose rows have
+// 16, 64 or 128 words (every single-preamble parser set except idm / netidm / r900 alone, BlockSize 8192: 256 row
+// registers do not exist; they keep the ring walk, whose re-read is 27 % there).
+#pragma once
+#include "k2_walk.h"
+
+namespace amr {
+
+template <int SL, int WPB>
+struct K2RGeom {
+    static constexpr int D = kK2WTaps;
+    static constexpr int LOOK = ((D - 1) * SL + 31) / 32;           // words beyond w that the taps of word w reach
+    static constexpr int CPR = WPB / 4;                             // chunks per row = ring size in chunks
+    static constexpr int RC = CPR;
+    static constexpr int RW = WPB;
+    static constexpr int NLA = (LOOK + 3) / 4;                      // look-ahead chunks a row walk needs (chunks 0 .. NLA-1 of the next row)
+    // slot c is shifted to the next row after group c; group g reads stream words up to 4g + 3 + LOOK + 1 (the funnel
+    // shift's second word): they must lie in slots already shifted, i.e. in chunks <= g - 1 of the next row
+    static_assert(((D - 1) * SL >> 5) + 4 < WPB, "look-ahead does not fit the row-as-ring scheme");
+    static_assert(NLA <= CPR && NLA <= 64, "look-ahead longer than a row");
+};
+
+// The BlockSize a decoder with only preamble KIND registered gets (decode.go:131-141: NextPowerOf2 of the preamble's
+// length in samples), in words; and whether k2_search_row exists for it.
+template <int SL, int KIND>
+constexpr int k2r_wpb()
+{
+    uint32_t pl = kK2WKnownLen[KIND] * (uint32_t)SL, bs = 1;
+    while (bs < pl) bs <<= 1;
+    return (int)(bs / 32);
+}
+template <int SL, int KIND>
+constexpr bool k2r_ok()
+{
+    constexpr int w = k2r_wpb<SL, KIND>();
+    return (w == 16 || w == 32 || w == 64 || w == 128) && (((kK2WTaps - 1) * SL) >> 5) + 4 < w;
+}
+
+// ---- the sweep: sixteen taps on the four words of group GG ------------------------------------------------------------
+// Tap P of the positions [32w, 32w + 32) looks at the stream bits [32w + P*SL, + 32).  SL is a multiple of 16, so a tap is
+// either word-aligned (class A) or starts at a half word (class B: the odd taps when SL = 16 mod 32).  k2_walk.h forms
+// every class-B window with a funnel shift (8 extra instructions per word; the compiler shares them between groups, which
+// costs 68 more live registers with the whole row resident: two waves per SIMD instead of three).  Here the class-B
+// taps are evaluated on the position blocks they ARE aligned to -- B-block u = positions [32u + 16, 32u + 48): its
+// window of tap P is the plain word u + (P*SL >> 5) + 1 -- and the accumulated mask is shifted back once:
+//     M[w] = A[w] & alignbit(B[w-1], B[w], 16)
+// 4 + 4 v_bitop3 and one v_alignbit per word, no shifted copy of the stream, one register of carry (B[w-1]).
+// B[-1] of a row needs own-row words only (index x_P >= 0), so a lane starts its row without its neighbour.
+template <int SL>
+struct K2RTaps {
+    static constexpr bool kHalf = (SL & 31) != 0;                   // class B exists
+    static constexpr int kStep = kHalf ? 2 : 1;                     // taps of one class: P0, P0 + kStep, ...
+};
+
+// ring slot of stream word s (the row is the ring)
+template <int WPB>
+__device__ __forceinline__ uint32_t k2r_word(const K2WRing<WPB / 4> &R, int s)
+{
+    const int i = s % WPB;
+    return R.c[i >> 2][i & 3];
+}
+
+// the class of taps P, P + STEP, ... < 16 on stream words base + (tap offset): acc &= AND of (W == bit), two taps per
+// v_bitop3 (three in the first); FOLD: the last instruction also ANDs `extra` in (the shifted class-B mask)
+template <int SL, int WPB, uint32_t BITS, int P, int STEP, bool FIRST, bool FOLD>
+__device__ __forceinline__ uint32_t k2r_chain(const K2WRing<WPB / 4> &R, int base, uint32_t acc, uint32_t extra)
+{
+    constexpr int D = kK2WTaps;
+    constexpr int x0 = (P * SL) >> 5, x1 = ((P + STEP) * SL) >> 5, x2 = ((P + 2 * STEP) * SL) >> 5;
+    constexpr uint32_t b0 = (BITS >> P) & 1u, b1 = (BITS >> (P + STEP)) & 1u, b2 = (BITS >> (P + 2 * STEP)) & 1u;
+    if constexpr (FIRST) {
+        static_assert(P + 2 * STEP < D, "a class has at least three taps");
+        constexpr uint32_t tt = 1u << (4 * b0 + 2 * b1 + b2);                       // (x == b0) & (y == b1) & (z == b2)
+        acc = __builtin_amdgcn_bitop3_b32(k2r_word<WPB>(R, base + x0), k2r_word<WPB>(R, base + x1), k2r_word<WPB>(R, base + x2), tt);
+        return k2r_chain<SL, WPB, BITS, P + 3 * STEP, STEP, false, FOLD>(R, base, acc, extra);
+    } else if constexpr (P + STEP < D) {                                          // x & (y == b0) & (z == b1)
+        constexpr uint32_t tt = 1u << (4 + 2 * b0 + b1);
+        acc = __builtin_amdgcn_bitop3_b32(acc, k2r_word<WPB>(R, base + x0), k2r_word<WPB>(R, base + x1), tt);
+        return k2r_chain<SL, WPB, BITS, P + 2 * STEP, STEP, false, FOLD>(R, base, acc, extra);
+    } else if constexpr (P < D) {                                                 // the last tap alone
+        if constexpr (FOLD) {                                                     // x & (y == b0) & z
+            constexpr uint32_t tt = 1u << (4 + 2 * b0 + 1);
+            return __builtin_amdgcn_bitop3_b32(acc, k2r_word<WPB>(R, base + x0), extra, tt);
+        } else {                                                                  // x & (y == b0)
+            constexpr uint32_t tt = (1u << (4 + 2 * b0)) | (1u << (4 + 2 * b0 + 1));
+            const uint32_t W = k2r_word<WPB>(R, base + x0);
+            return __builtin_amdgcn_bitop3_b32(acc, W, W, tt);
+        }
+    } else {
+        return FOLD ? (acc & extra) : acc;
+    }
+}
+
+// group GG: masks of its four words; Bc = class-B mask of the B-block in front of the group (in / out)
+template <int SL, int WPB, int GG, uint32_t BITS>
+__device__ __forceinline__ void k2r_sweep(const K2WRing<WPB / 4> &R, uint32_t (&M)[4], uint32_t &Bc)
+{
+    using T = K2RTaps<SL>;
+    if constexpr (T::kHalf) {
+        uint32_t B[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) B[j] = k2r_chain<SL, WPB, BITS, 1, 2, true, false>(R, GG * 4 + j + 1, 0u, 0u);
+        asm volatile("" : "+v"(B[0]), "+v"(B[1]), "+v"(B[2]), "+v"(B[3]));       // keep the two classes apart: fewer live registers
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const uint32_t Bs = __builtin_amdgcn_alignbit(j ? B[j - 1] : Bc, B[j], 16);
+            M[j] = k2r_chain<SL, WPB, BITS, 0, 2, true, true>(R, GG * 4 + j, 0u, Bs);
+        }
+        Bc = B[3];
+    } else {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) M[j] = k2r_chain<SL, WPB, BITS, 0, 1, true, false>(R, GG * 4 + j, 0u, 0u);
+    }
+}
+
+// class-B mask of the B-block in front of word 0 of the row: positions [-16, 16), own-row words only
+template <int SL, int WPB, uint32_t BITS>
+__device__ __forceinline__ uint32_t k2r_b_first(const K2WRing<WPB / 4> &R)
+{
+    if constexpr (K2RTaps<SL>::kHalf) return k2r_chain<SL, WPB, BITS, 1, 2, true, false>(R, 0, 0u, 0u);
+    else return 0u;
+}
+
+// slot C of the row: own chunk C (swept, dead in every lane) -> chunk C of the NEXT row: the neighbour lane's register,
+// lane 63: chunk C of row 0 of the next tile, which lane C fetched into X
+template <int CPRN, int C>
+__device__ __forceinline__ void k2r_shift(K2WRing<CPRN> &R, const k2w_v4u &X)
+{
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const uint32_t own = R.c[C][j];
+        uint32_t v = (uint32_t)__builtin_amdgcn_update_dpp((int)own, (int)own, 0x130 /* wave_shl:1: lane i <- lane i + 1 */, 0xf, 0xf, false);
+        const uint32_t s = (uint32_t)__builtin_amdgcn_readlane((int)X[j], C);
+        asm("v_writelane_b32 %0, %1, 63" : "+v"(v) : "s"(s));          // (this clang has no __builtin_amdgcn_writelane)
+        R.c[C][j] = v;
+    }
+}
+
+// The row's loads, hand-issued: the compiler does not see them as memory operations, so the rare-path branch inside every
+// group (k2w_record) no longer makes its waitcnt pass give up counting and wait for ALL loads in flight (k2_walk.h had to
+// load unconditionally and over-fetch for that reason).  Chunk K of the wave's tile is one KiB at tile + K KiB; the
+// instruction's immediate reaches 4 KiB, so there is one scalar base per four chunks.
+template <int CPRN, int K>
+__device__ __forceinline__ void k2r_fill(K2WRing<CPRN> &R, const uint8_t *tile, uint32_t voff)
+{
+    if constexpr (K < CPRN) {
+        const uint8_t *base = tile + (size_t)(K / 4) * 4096;          // wave-uniform: an SGPR pair
+        asm volatile("global_load_dwordx4 %0, %1, %2 offset:%3" : "=v"(R.c[K]) : "v"(voff), "s"(base), "n"((K % 4) * 1024) : "memory");
+        k2r_fill<CPRN, K + 1>(R, tile, voff);
+    }
+}
+
+// vmcnt retires in order: once at most CPRN - 1 - C1 loads are outstanding, chunks 0 .. C1 (and X, issued first) have
+// landed.  The registers that become valid here are operands of the wait or of an (empty) statement BEHIND it -- volatile
+// statements keep their order --, so that no use of them can be scheduled above the wait.
+template <int CPRN, int C0, int C1, bool FIRST = true>
+__device__ __forceinline__ void k2r_wait(K2WRing<CPRN> &R)
+{
+    static_assert(C0 <= C1 && C1 < CPRN, "chunk range");
+    if constexpr (FIRST) asm volatile("s_waitcnt vmcnt(%1)" : "+v"(R.c[C0]) : "n"(CPRN - 1 - C1) : "memory");
+    else asm volatile("" : "+v"(R.c[C0]));
+    if constexpr (C0 < C1) k2r_wait<CPRN, C0 + 1, C1, false>(R);
+}
+
+// groups GG .. CPR-1 of the row, statically unrolled: every register index, every wait count and the point where a slot
+// turns into look-ahead are compile-time facts, and the stream of loads at the top is never interrupted by a branch
+template <int SL, int WPB, int KIND, int GG>
+__device__ __forceinline__ void k2r_groups(K2WRing<WPB / 4> &R, k2w_v4u &X, uint32_t q, uint32_t w_lo, uint32_t w_hi,
+                                           uint32_t lane, uint32_t *mylist, uint32_t &list_n, uint32_t &Bc)
+{
+    using G = K2RGeom<SL, WPB>;
+    if constexpr (GG < G::CPR) {
+        // the chunks of the own row this group touches for the first time: up to stream word 4 GG + 3 + x_15 + 1
+        constexpr int hi = (4 * GG + 4 + (((kK2WTaps - 1) * SL) >> 5)) >> 2;
+        constexpr int c1 = hi < G::CPR - 1 ? hi : G::CPR - 1;
+        constexpr int hp = GG == 0 ? -1 : ((4 * (GG - 1) + 4 + (((kK2WTaps - 1) * SL) >> 5)) >> 2);
+        constexpr int c0 = hp < G::CPR - 1 ? hp + 1 : G::CPR;          // first chunk not yet waited for
+        if constexpr (c0 <= c1) k2r_wait<G::CPR, c0, c1>(R);
+        if constexpr (GG == 0) asm volatile("" : "+v"(X));           // issued first: landed with chunk 0
+        uint32_t M[4];
+        if constexpr (GG == 0) Bc = k2r_b_first<SL, WPB, kK2WKnown[KIND]>(R);
+        k2r_sweep<SL, WPB, GG, kK2WKnown[KIND]>(R, M, Bc);
+        if (__ballot((M[0] | M[1] | M[2] | M[3]) != 0))                 // rare
+            k2w_record(M, q, (uint32_t)GG, w_lo, w_hi, lane, mylist, list_n);
+        if constexpr (GG < G::NLA) k2r_shift<G::CPR, GG>(R, X);
+        k2r_groups<SL, WPB, KIND, GG + 1>(R, X, q, w_lo, w_hi, lane, mylist, list_n, Bc);
+    }
+}
+
+template <int SL, int KIND, int WPB>
+__global__ __launch_bounds__(64 * kK2WWaves, 3) void k2_search_row(const K2Args a)
+{
+    using G = K2RGeom<SL, WPB>;
+    constexpr int LG_WPB = WPB == 16 ? 4 : WPB == 32 ? 5 : WPB == 64 ? 6 : 7;
+    static_assert(WPB == 16 || WPB == 32 || WPB == 64 || WPB == 128, "rows of 16, 32, 64 or 128 words");
+    extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
+    // workgroup b runs on XCD b % 8: every XCD gets one contiguous run of tiles (the grid is rounded up to 8 equal runs)
+    const uint32_t wgT = (blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3);
+    const uint32_t n_wg = (a.n_tiles + kK2WWaves - 1) / kK2WWaves;      // workgroups that search
+    k2_announce(a);
+    if (wgT >= n_wg) {
+        (void)k2_extra_workgroup(a, a.n_tiles + (wgT - n_wg), lds, 64 * kK2WWaves);   // state update / deferred-block copies
+        return;
+    }
+    const uint32_t tid = threadIdx.x, lane = tid & 63;
+    const uint32_t v = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const uint32_t T = wgT * kK2WWaves + v;
+    if (T >= a.n_tiles) return;                                      // the last workgroup may hold fewer tiles (no barrier below)
+#if AMR_K2W_DBG
+    if (a.dbg && lane == 0) a.dbg[(size_t)T * 16 + 8] = __builtin_amdgcn_s_memrealtime();
+#endif
+    K2W_STAMP(0);
+    constexpr uint32_t wpb = WPB, lg_wpb = LG_WPB;
+    const uint32_t lg_bs = lg_wpb + 5;
+    constexpr uint32_t tile_words = 64u << LG_WPB;
+
+    // ---- the row, all of it, and the head of row 0 of the next tile (lane c: its chunk c) ----
+    const uint8_t *tile = reinterpret_cast<const uint8_t *>(a.qt + (size_t)T * tile_words);
+    K2WRing<G::CPR> R;
+    k2w_v4u X;
+    {   // X first (the first shift needs it: in-order retirement then never waits for more than its own chunks);
+        // lanes beyond NLA read chunk NLA-1 again (a valid address, never used)
+        const uint32_t xoff = (lane < (uint32_t)G::NLA ? lane : (uint32_t)G::NLA - 1) * 1024;
+        const uint8_t *next = tile + (size_t)tile_words * 4;
+        asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(X) : "v"(xoff), "s"(next) : "memory");
+    }
+    k2r_fill<G::CPR, 0>(R, tile, lane * 16);
+
+    uint32_t *mylist = lds + v * (kK2WList * 2 + 2 * 4 * 64);        // [kK2WList][2]
+    uint32_t *cnts = mylist + kK2WList * 2;                          // [64] hits per row (one preamble)
+    uint32_t *bases = cnts + 4 * 64;                                 // [64]
+    cnts[lane] = 0;
+
+    // ---- the preamble (the taps behind the sixteenth, stage 2, take their bits from the geometry) ----
+    const uint64_t pb = a.g.pre_bits[0];
+    const uint32_t pl = a.g.pre_len[0];
+
+    // ---- valid word range of this lane's row: n_lo <= R*BS + 32w < n_hi ----
+    const int64_t rowbase = ((int64_t)T * 64 + lane - 64) << lg_bs;
+    int64_t lo64 = (a.n_lo - rowbase) >> 5, hi64 = (a.n_hi - rowbase) >> 5;
+    const uint32_t w_lo = (uint32_t)(lo64 < 0 ? 0 : lo64 > (int64_t)wpb ? wpb : lo64);
+    const uint32_t w_hi = (uint32_t)(hi64 < 0 ? 0 : hi64 > (int64_t)wpb ? wpb : hi64);
+
+    // ---- stage 1: sixteen taps on every position of the row ----
+    uint32_t list_n = 0;                                             // wave-uniform
+    uint32_t Bc = 0;
+    k2r_groups<SL, WPB, KIND, 0>(R, X, 0u, w_lo, w_hi, lane, mylist, list_n, Bc);
+    K2W_STAMP(1);
+
+    // ---- stage 2: the taps behind the first 16 on the list entries (one per lane), words from memory; compaction in place ----
+    const uint32_t maxL = pl;
+    const uint32_t n_cand = list_n < (uint32_t)kK2WList ? list_n : (uint32_t)kK2WList;
+    uint32_t n_keep = 0;                                             // wave-uniform
+    const uint32_t *tw = a.qt + (size_t)T * tile_words;
+    for (uint32_t e0 = 0; e0 < n_cand; e0 += 64) {
+        const uint32_t e = e0 + lane;
+        uint32_t key = 0, m = 0;
+        if (e < n_cand) { key = mylist[e * 2]; m = mylist[e * 2 + 1]; }
+        const uint32_t l = (key >> 8) & 63, w = key & 0xff;
+        for (uint32_t p = kK2WTaps; p < maxL; p += 4) {              // four taps per round: their eight loads are in flight together
+            if (!__any(m != 0)) break;
+            uint32_t Wd[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const uint32_t pk = p + k < maxL ? p + k : maxL - 1;
+                const uint32_t o = pk * SL;
+                const uint32_t x = w + (o >> 5);
+                // word x of the stream that starts with row l of this tile: tiled row l + x / wpb (may be row 0 of the next tile)
+                const uint32_t A = tw[qt_index(l + (x >> lg_wpb), x & (wpb - 1), lg_wpb)];
+                const uint32_t B = tw[qt_index(l + ((x + 1) >> lg_wpb), (x + 1) & (wpb - 1), lg_wpb)];
+                Wd[k] = (o & 31) ? __builtin_amdgcn_alignbit(A, B, 16) : A;
+            }
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+                if (p + k < pl) m &= ((pb >> (p + k)) & 1) ? Wd[k] : ~Wd[k];
+        }
+        const uint64_t b = __ballot(m != 0);
+        if (m != 0) {   // survivors move to the front, order preserved (slot <= e, earlier entries already read)
+            const uint32_t slot = n_keep + __builtin_amdgcn_mbcnt_hi((uint32_t)(b >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)b, 0));
+            mylist[slot * 2] = key;
+            mylist[slot * 2 + 1] = m;
+            atomicAdd(&cnts[l], (uint32_t)__popc(m));
+        }
+        n_keep += __popcll(b);
+    }
+    K2W_STAMP(2);
+
+    // ---- ranks: exclusive scan over the rows in stream order (row-major: all of row l before row l+1) ----
+    const uint32_t val = cnts[lane];
+    const uint32_t inc = k2w_wave_scan(val);
+    const uint32_t total = __builtin_amdgcn_readlane(inc, 63);
+    bases[lane] = inc - val;
+
+    // ---- emit: every surviving entry by 32 lanes at once, lane b = bit b (MSB first = stream order).  The list is in
+    // walk order: word-major across the rows, ascending words inside a row -- which is all the ranks need ----
+    uint32_t run = 0;
+    for (uint32_t e = 0; e < n_keep; ++e) {
+        const uint32_t key = __builtin_amdgcn_readfirstlane(mylist[e * 2]);
+        const uint32_t m = __builtin_amdgcn_readfirstlane(mylist[e * 2 + 1]);
+        const uint32_t l = (key >> 8) & 63, w = key & 0xff;
+        const uint32_t r = __builtin_amdgcn_readlane(run, l);
+        const uint32_t base = bases[l] + r;
+        if (lane < 32 && ((m >> (31 - lane)) & 1)) {
+            const uint32_t before = lane ? __popc(m >> (32 - lane)) : 0;
+            const uint32_t rank = base + before;
+            if (rank < a.cap) a.staging[(size_t)T * a.cap + rank] = (l << lg_bs) + (w << 5) + lane;
+        }
+        run += (lane == l) ? __popc(m) : 0;
+    }
+    K2W_STAMP(3);
+#if AMR_K2W_DBG
+    if (a.dbg && lane == 0) {
+        a.dbg[(size_t)T * 16 + 7] = ((unsigned long long)n_cand << 32) | n_keep;
+        a.dbg[(size_t)T * 16 + 9] = __builtin_amdgcn_s_memrealtime();
+    }
+#endif
+    if (lane == 0) {
+        const uint32_t c = total < a.cap ? total : a.cap;
+        a.counts[T] = c;
+        if (c) atomicAdd(&a.gcnt[T >> 6], c);
+        if (total > a.cap) atomicOr(a.overflow, 1u);
+        if (list_n > (uint32_t)kK2WList) atomicOr(a.overflow, 2u);
+    }
+}
+
+}  // namespace amr

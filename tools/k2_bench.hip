@@ -2,7 +2,9 @@
 // (developer tool, not product code).  Geometry: scm at chip length 72 by default (rows of 128 words), or "idm" / "all"
 // (rows of 256 words).
 //   hipcc --offload-arch=gfx950 -O3 -std=c++17 -DAMR_K2W_DBG=1 -Irtlamr_amd/csrc -Iinclude -o build/k2b tools/k2_bench.hip
-// usage: k2b [scm|idm|all] [n_tiles incl. the history tile] [reps]
+// usage: k2b [scm|idm|all] [n_tiles incl. the history tile] [reps] [cold]
+// "scm" also runs k2_search_row<144, 0, 128> (k2_row.h) on the same bitstream and compares counts and staging with the walk;
+// cold: a 1 GiB buffer is streamed through the chip in front of every launch (what K1 does to the caches in the product)
 // Note: the bitstream stays in the 256 MB Infinity Cache between launches here; in the product K1 has just streamed a GiB
 // through it and K2 reads a cold bitstream (scm: 20-25 us here, 34 us in the bench's --depth 1 profile).
 #include <hip/hip_runtime.h>
@@ -12,7 +14,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <vector>
-#include "k2_walk.h"
+#include "k2_row.h"
 
 #ifndef K2B_PF1
 #define K2B_PF1 AMR_K2W_PF1
@@ -21,6 +23,78 @@
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { fprintf(stderr, "%s: %s\n", #x, hipGetErrorString(e_)); exit(1); } } while (0)
 
 static uint64_t bits_of(const char *s) { uint64_t v = 0; for (int p = 0; s[p]; ++p) v |= (uint64_t)(s[p] == '1') << p; return v; }
+
+__global__ void k_stream_read(const uint4 *p, size_t n16, uint32_t *sink)
+{
+    typedef uint32_t v4 __attribute__((ext_vector_type(4)));
+    uint32_t acc = 0;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n16; i += (size_t)gridDim.x * blockDim.x) {
+        const v4 v = __builtin_nontemporal_load(reinterpret_cast<const v4 *>(p) + i);
+        acc ^= v.x ^ v.y ^ v.z ^ v.w;
+    }
+    if (acc == 0x12345679u) *sink = acc;
+}
+static uint4 *g_cold = nullptr; static uint32_t *g_sink = nullptr; static const size_t kColdBytes = (size_t)1 << 30;
+static void cold_pass() { if (g_cold) hipLaunchKernelGGL(k_stream_read, dim3(4096), dim3(256), 0, 0, g_cold, kColdBytes / 16, g_sink); }
+
+// the row kernel (one preamble, rows of up to 128 words) on the same arguments; compares with what the walk left behind
+template <int SL, int KIND, int WPB>
+static void run_row(const char *name, amr::K2Args a, uint32_t n_tiles, int reps, unsigned long long *d_dbg)
+{
+    using namespace amr;
+    std::vector<uint32_t> cnt0((size_t)n_tiles), st0((size_t)n_tiles * a.cap);
+    CK(hipMemcpy(cnt0.data(), a.counts, cnt0.size() * 4, hipMemcpyDeviceToHost));
+    CK(hipMemcpy(st0.data(), a.staging, st0.size() * 4, hipMemcpyDeviceToHost));
+    CK(hipMemset(a.counts, 0xff, cnt0.size() * 4)); CK(hipMemset(a.staging, 0xff, st0.size() * 4));
+    const uint32_t n_wg = (n_tiles + kK2WWaves - 1) / kK2WWaves;
+    const uint32_t grid = 8u * ((n_wg + 7u) / 8u);
+    const size_t lds = k2_walk_lds_bytes(0);
+    CK(hipFuncSetAttribute((const void *)k2_search_row<SL, KIND, WPB>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipEvent_t e0, e1;
+    CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    std::vector<float> ms;
+    const uint32_t groups = k2_groups(n_tiles);
+    for (int r = 0; r < reps + 30; ++r) {
+        CK(hipMemsetAsync(a.gcnt, 0, (size_t)groups * a.g.n_pre * 4, 0));
+        CK(hipMemsetAsync(a.overflow, 0, 4, 0));
+        cold_pass();
+        a.dbg = (r == reps + 29) ? d_dbg : nullptr;
+        hipExtLaunchKernelGGL((k2_search_row<SL, KIND, WPB>), dim3(grid), dim3(64 * kK2WWaves), lds, 0, e0, e1, 0, a);
+        CK(hipEventSynchronize(e1));
+        float t; CK(hipEventElapsedTime(&t, e0, e1));
+        if (r >= 30) ms.push_back(t);
+    }
+    std::sort(ms.begin(), ms.end());
+    uint32_t ovf = 0; CK(hipMemcpy(&ovf, a.overflow, 4, hipMemcpyDeviceToHost));
+    std::vector<uint32_t> cnt((size_t)n_tiles), st((size_t)n_tiles * a.cap);
+    CK(hipMemcpy(cnt.data(), a.counts, cnt.size() * 4, hipMemcpyDeviceToHost));
+    CK(hipMemcpy(st.data(), a.staging, st.size() * 4, hipMemcpyDeviceToHost));
+    unsigned long long hits = 0, bad_c = 0, bad_s = 0;
+    for (uint32_t T = 0; T < n_tiles; ++T) {
+        hits += cnt[T];
+        if (cnt[T] != cnt0[T]) { if (bad_c++ < 5) printf("    tile %u: count %u, walk %u\n", T, cnt[T], cnt0[T]); continue; }
+        for (uint32_t i = 0; i < cnt[T]; ++i)
+            if (st[(size_t)T * a.cap + i] != st0[(size_t)T * a.cap + i]) { if (bad_s++ < 5) printf("    tile %u hit %u: %u, walk %u\n", T, i, st[(size_t)T * a.cap + i], st0[(size_t)T * a.cap + i]); }
+    }
+    printf("k2r %-4s SL=%d KIND=%d WPB=%d tiles=%u grid=%u: min %.1f med %.1f p90 %.1f us   hits %llu overflow %u   vs walk: %llu count mismatches, %llu position mismatches %s\n",
+           name, SL, KIND, WPB, n_tiles, grid, ms[0] * 1e3, ms[ms.size() / 2] * 1e3, ms[ms.size() * 9 / 10] * 1e3, hits, ovf, bad_c, bad_s,
+           (bad_c || bad_s) ? "** MISMATCH **" : "(identical)");
+    if (!AMR_K2W_DBG) return;
+    std::vector<unsigned long long> d((size_t)n_tiles * 16);
+    CK(hipMemcpy(d.data(), d_dbg, d.size() * 8, hipMemcpyDeviceToHost));
+    std::vector<double> walk, life, start, end;
+    unsigned long long t0 = ~0ull;
+    for (uint32_t T = 0; T < n_tiles; ++T) t0 = std::min(t0, d[(size_t)T * 16 + 8]);
+    for (uint32_t T = 0; T < n_tiles; ++T) {
+        const unsigned long long *w = &d[(size_t)T * 16];
+        walk.push_back((double)(w[1] - w[0]));
+        life.push_back((w[9] - w[8]) * 0.01); start.push_back((w[8] - t0) * 0.01); end.push_back((w[9] - t0) * 0.01);
+    }
+    auto q = [](std::vector<double> v, double f) { std::sort(v.begin(), v.end()); return v[(size_t)(f * (v.size() - 1))]; };
+    printf("    cycles  walk %.0f / %.0f / %.0f (p10 / med / p90)\n", q(walk, .1), q(walk, .5), q(walk, .9));
+    printf("    us      wave life %.1f / %.1f / %.1f   start %.1f / %.1f / %.1f   end %.1f / %.1f / %.1f (max %.1f)\n",
+           q(life, .1), q(life, .5), q(life, .9), q(start, .1), q(start, .5), q(start, .9), q(end, .1), q(end, .5), q(end, .9), q(end, 1.0));
+}
 
 template <int SL, int SET>
 static void run(const char *name, amr::K2Args a, uint32_t n_tiles, int reps, unsigned long long *d_dbg)
@@ -37,6 +111,7 @@ static void run(const char *name, amr::K2Args a, uint32_t n_tiles, int reps, uns
     for (int r = 0; r < reps + 30; ++r) {
         CK(hipMemsetAsync(a.gcnt, 0, (size_t)groups * a.g.n_pre * 4, 0));
         CK(hipMemsetAsync(a.overflow, 0, 4, 0));
+        cold_pass();
         a.dbg = (r == reps + 29) ? d_dbg : nullptr;
         hipExtLaunchKernelGGL((k2_search_walk<SL, SET>), dim3(grid), dim3(64 * kK2WWaves), lds, 0, e0, e1, 0, a);
         CK(hipEventSynchronize(e1));
@@ -83,6 +158,10 @@ int main(int argc, char **argv)
     const bool wide = strcmp(kind, "scm") != 0;
     const uint32_t n_tiles = argc > 2 ? (uint32_t)atoi(argv[2]) : (wide ? 4097u : 2049u);
     const int reps = argc > 3 ? atoi(argv[3]) : 40;
+    if (argc > 4 && !strcmp(argv[4], "cold")) {
+        CK(hipMalloc((void **)&g_cold, kColdBytes)); CK(hipMalloc((void **)&g_sink, 4));
+        CK(hipMemset(g_cold, 1, kColdBytes));
+    }
     K2Args a{};
     SearchGeom &g = a.g;
     g.block_size = wide ? 8192 : 4096; g.lg_block_size = wide ? 13 : 12; g.wpb = g.block_size / 32; g.lg_wpb = wide ? 8 : 7;
@@ -110,7 +189,7 @@ int main(int argc, char **argv)
     CK(hipMalloc((void **)&a.overflow, 4));
     unsigned long long *d_dbg; CK(hipMalloc((void **)&d_dbg, (size_t)n_tiles * 16 * 8));
     a.n_lo = -(int64_t)g.packet_length; a.n_hi = (int64_t)(n_tiles - 1) * 64 * g.block_size - g.packet_length;   // tile 0 = history tile
-    if (!strcmp(kind, "scm")) run<144, 1>("scm", a, n_tiles, reps, d_dbg);
+    if (!strcmp(kind, "scm")) { run<144, 1>("scm", a, n_tiles, reps, d_dbg); run_row<144, 0, 128>("scm", a, n_tiles, reps, d_dbg); }
     else if (!strcmp(kind, "idm")) run<144, 4>("idm", a, n_tiles, reps, d_dbg);
     else run<144, 15>("all", a, n_tiles, reps, d_dbg);
     return 0;
