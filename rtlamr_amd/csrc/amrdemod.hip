@@ -146,6 +146,7 @@ struct amr_handle {
     // stream: stream dependencies were tried and cost ~10 us of bubbles per batch, cfg2 0.237 ms per step against 0.227).
     bool lazy_tail = false;
     uint64_t *d_tail_done = nullptr;   // device word: ticket of the last batch whose second-stream part has finished
+    uint64_t *d_k1_started = nullptr;  // device word: ticket of the last batch whose K1 has all its waves on the chip (k_gate)
     uint64_t *h_flags = nullptr;  // pinned: [0] ticket of the last batch whose search has started, [1] whose stream-A part is done
     bool timing_valid = false;
     amr_timing timing{};
@@ -446,6 +447,7 @@ amr_status enqueue_search(amr_handle *h, Slot &s, bool rerun = false, bool dense
 }
 
 amr_status launch_ready_tails(amr_handle *h, bool last_too = false);
+amr_status launch_tail(amr_handle *h, Slot &t);
 
 __global__ void k_copy16(const uint4 *src, uint4 *dst, uint32_t n16)
 {
@@ -512,6 +514,14 @@ amr_status submit(amr_handle *h, const uint8_t *d_iq, size_t n_blocks, bool sear
 
     s.timed = h->timing_level;
     hipEvent_t e0 = s.timed ? s.ev0 : nullptr, e1 = s.timed ? s.ev1 : nullptr;
+    // A caller that keeps batches in flight gets K3 (K4, K5) of a batch on the second stream, next to the END of the
+    // following batch's K1 and its search (see below, "the tail of the previous batch").
+    const bool lazy = search && (h->lazy_tail || h->n_pending >= 1);
+    if (lazy) h->lazy_tail = true;
+    const bool all_coop = rows > 0 && rows <= h->k1_coop_max;   // see below
+    const bool gate_prev = prev.pending && prev.search && prev.tail_split && !prev.tail_enqueued;
+    amr::K1Args k1_last = k1;                     // the launch that announces itself to the gate: the batch's last one
+    if (gate_prev) { k1_last.started = h->d_k1_started; k1_last.started_value = s.ticket; }
     // One launch per "round" for long blocks: K1 holds 8 waves per CU, and a launch that exactly fills the chip keeps its
     // waves in step -- all of them read together and write their output bursts together.  A larger grid runs the later
     // rounds out of step (output stores trickle into the read stream all the time): BlockSize 4096, 4 GiB: 0.895 ms in
@@ -520,28 +530,38 @@ amr_status submit(amr_handle *h, const uint8_t *d_iq, size_t n_blocks, bool sear
     // keep the single launch.
     const uint32_t round = bs >= 4096 ? (uint32_t)h->n_cus * 8u : full;
     // Small batches entirely as one wave per block (k1_coop.h): a wave-tile costs a whole wave life (150-175 us) however few
-    // tiles there are; a wave per block finishes in ~50 us as long as the waves fit the chip side by side.
-    const bool all_coop = rows > 0 && rows <= h->k1_coop_max;
+    // tiles there are; a wave per block finishes in ~50 us as long as the waves fit the chip side by side (all_coop).
     if (all_coop) {
-        amr::launch_k1_coop(h->geom.chip_length, 0u, (uint32_t)rows, st, k1, e0, e1);
+        amr::launch_k1_coop(h->geom.chip_length, 0u, (uint32_t)rows, st, k1_last, e0, e1);
     } else {
         for (uint32_t w0 = 0; w0 < full; w0 += round) {
             const uint32_t n = std::min(round, full - w0);
-            k1.wg_first = w0;
-            amr::launch_k1(h->geom.chip_length, dim3(n), st, k1, w0 == 0 ? e0 : nullptr, (w0 + n == full && !rem) ? e1 : nullptr);
+            const bool last = w0 + n == full && !rem;
+            amr::K1Args &kk = last ? k1_last : k1;
+            kk.wg_first = w0;
+            amr::launch_k1(h->geom.chip_length, dim3(n), st, kk, w0 == 0 ? e0 : nullptr, last ? e1 : nullptr);
         }
         if (rem)     // the blocks behind the last whole wave-tile (sync callers, flush): a wave each
-            amr::launch_k1_coop(h->geom.chip_length, full * 64u, rem, st, k1, full ? nullptr : e0, e1);
+            amr::launch_k1_coop(h->geom.chip_length, full * 64u, rem, st, k1_last, full ? nullptr : e0, e1);
     }
     HIP_TRY(hipGetLastError());
     AMR_DBG(st, "k1_demod");
+    // The tail of the previous batch (its K3, K4, K5 and the kernel that publishes its ticket), enqueued NOW on the second
+    // stream behind a gate that opens when this batch's K1 has every wave on the chip.  K1 holds all LDS and all but 16
+    // registers per SIMD, so the tail's workgroups get on the chip only where K1 waves retire: they fill the ragged end
+    // of the K1 launch and the start of the search, and nobody waits for the host to notice anything (round 3 launched
+    // the tail from the host when it saw the search start: 13 us later, and the state update of that search -- the last
+    // thing in front of the next K1 -- waited for K3 to finish: K1-to-K1 232 us for K1 185 + K2 25).
+    // (Measured on one box, profiles/r04/k2_tail_ab/: host-launched tail 0.262-0.265 ms per step, gated 0.249-0.256, everything
+    // behind K2 on the compute stream 0.289; the gate's extra delay -- 0, 6 or 20 us --, whether it is enqueued before
+    // or behind K2, and stream priorities make no difference that survives the run-to-run noise.)
+    if (gate_prev) {
+        hipLaunchKernelGGL(amr::k_gate, dim3(1), dim3(1), 0, h->tail_stream, h->d_k1_started, s.ticket, 600u /* 6 us */);
+        HIP_TRY(hipGetLastError());
+        AMR_TRY(launch_tail(h, prev));
+    }
     s.dense = h->dense_hold > 0;
     if (s.dense) h->dense_hold--;
-    // A caller that keeps batches in flight gets K3 (K4, K5) of this batch on the second stream, launched by the host
-    // when the NEXT batch's K1 has finished: they then share the machine with that batch's search (which leaves room)
-    // instead of standing between two K1 launches (which do not).
-    const bool lazy = search && (h->lazy_tail || h->n_pending >= 1);
-    if (lazy) h->lazy_tail = true;
     // state carried to the next batch (decode.go:165-166): the last rows of this slot's bitstream become the history
     // tile of the NEXT slot, the last HBA bytes of IQ (and the deferred blocks behind them) go to the head buffer, the
     // next slot's search words are reset.  Whatever does it is also the last thing in front of the next K1 launch, which
@@ -985,8 +1005,9 @@ amr_status amr_create(const amr_protocol *protos, int32_t n_protos, int32_t devi
     if (e == hipSuccess) e = hipStreamCreateWithFlags(&h->tail_stream, hipStreamNonBlocking);
     if (e == hipSuccess) e = hipHostMalloc((void **)&h->h_flags, 16, hipHostMallocCoherent);
     if (e == hipSuccess) { h->h_flags[0] = 0; h->h_flags[1] = 0; }
-    if (e == hipSuccess) e = hipMalloc((void **)&h->d_tail_done, 8);
-    if (e == hipSuccess) e = hipMemset(h->d_tail_done, 0, 8);
+    if (e == hipSuccess) e = hipMalloc((void **)&h->d_tail_done, 16);
+    if (e == hipSuccess) e = hipMemset(h->d_tail_done, 0, 16);
+    if (e == hipSuccess) h->d_k1_started = h->d_tail_done + 1;
     h->stream = h->own_stream;
     for (Slot &sl : h->slot) {
         if (e == hipSuccess) e = hipEventCreate(&sl.ev0);

@@ -49,6 +49,7 @@ __global__ __launch_bounds__(64) void k1c_demod(const K1Args a)
     float *lut = reinterpret_cast<float *>(lds + G::kLut);
     float *ring = reinterpret_cast<float *>(lds + G::kRing);
     const uint32_t lane = threadIdx.x;
+    k1_announce(a, lane);
     const uint32_t b = a.wg_first + blockIdx.x;            // block of the launch (row 64 + b of the bitstream)
     const uint32_t bs = a.block_size, bs2 = bs * 2, wpb = bs >> 5;
 #pragma unroll

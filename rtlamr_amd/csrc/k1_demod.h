@@ -93,7 +93,26 @@ struct K1Args {
     // 1: wave-tile 0 of the launch lies in the head buffer (blocks deferred from the previous batch in front, the first
     // blocks of this batch copied in behind them, see submit() in amrdemod.hip); wave-tiles >= 1 are at iq + row * bs2
     uint32_t head_rows;
+    // Pipelined callers (amrdemod.hip, submit): the LAST workgroup of the batch's last K1 launch stores started_value here
+    // when it starts -- by then every wave of the launch has its slot.  A gate kernel on the second stream waits for it and
+    // lets the previous batch's K3 in: its workgroups then find room only where K1 waves retire, i.e. they fill the ragged
+    // end of this launch instead of standing in front of it.  null: no announcement.
+    uint64_t *started;
+    uint64_t started_value;
 };
+
+__device__ __forceinline__ void k1_announce(const K1Args &a, uint32_t lane)
+{
+    // A store the optimiser cannot see (no "memory" clobber: it touches nothing this kernel reads), write-through (sc1) so
+    // that the gate's agent-scope load on another XCD finds it.  Written as __hip_atomic_store it makes hipcc give up
+    // the scalar loads of the kernel arguments behind it: the DMA's base pointers then arrive in VGPR pairs, which the
+    // "s" operands of the inline asm cannot take.
+    if (a.started && blockIdx.x == gridDim.x - 1 && lane == 0) {
+        uint64_t *p = a.started;
+        const uint64_t v = a.started_value;
+        asm volatile("global_store_dwordx2 %0, %1, off sc1" :: "v"(p), "v"(v));
+    }
+}
 
 // start of the row stream (block 0 of the wave-tile, byte 0) a wave-tile reads
 template <int HBA>
@@ -482,6 +501,7 @@ __global__ __launch_bounds__(64, 2) void k1_demod(const K1Args a)
     const uint32_t tiles_lds = (uint32_t)(uintptr_t)(lds_ptr_t)tiles;
 
     const uint32_t lane = threadIdx.x;
+    k1_announce(a, lane);
     const uint32_t wg = a.wg_first + blockIdx.x;
     const uint32_t bs2 = a.block_size * 2;
     const uint32_t wpb = a.block_size >> 5;

@@ -456,6 +456,7 @@ __global__ __launch_bounds__(64, 2) void k1t_demod(const K1Args a)
     if ((uint32_t)(uintptr_t)(lds_ptr_t)k1t_lds != 0) __builtin_trap();
 
     const uint32_t lane = threadIdx.x;
+    k1_announce(a, lane);
 #if AMR_K1T_CLK
     const uint64_t clk0 = __builtin_readcyclecounter(), rt0 = __builtin_amdgcn_s_memrealtime();
 #endif

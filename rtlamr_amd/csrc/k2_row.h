@@ -15,7 +15,8 @@
 //     (ring index = stream word mod RW) applies unchanged.  Lane 63 continues in row 0 of the next tile: lanes
 //     0 .. NEED-2 fetch those chunks once (one load instruction) and v_readlane / v_writelane patch lane 63;
 //   * nothing is over-fetched: the bitstream is read 1.0 x plus 16 bytes per chunk of look-ahead and tile (7 % at scm).
-// Sweep, candidate list, stage 2, ranks and emission are those of k2_walk.h (same staging / counts / overflow protocol:
+// Candidate list, stage 2 and ranks are those of k2_walk.h, the sweep and the emission are restated below (same staging /
+// counts / overflow protocol:
 // K3 and the host see no difference).  Used for a decoder whose ONE preamble is one of rtlamr's four and whose rows have
 // 16, 64 or 128 words (every single-preamble parser set except idm / netidm / r900 alone, BlockSize 8192: 256 row
 // registers do not exist; they keep the ring walk, whose re-read is 27 % there).
@@ -24,9 +25,19 @@
 
 namespace amr {
 
-template <int SL, int WPB>
+// Taps the sweep applies to every position: all of the preamble when its reach still fits the row-as-ring scheme (scm: 21
+// symbols -- no candidate list of near-misses, no second stage; scm+ has 16 anyway), the first sixteen otherwise (idm,
+// netidm, r900: 32 symbols reach past the row; scm at SymbolLength 96, where 21 symbols fill the 2048-sample block).
+template <int SL, int KIND, int WPB>
+constexpr int k2r_taps()
+{
+    constexpr int len = (int)kK2WKnownLen[KIND];
+    return (len <= 24 && (((len - 1) * SL) >> 5) + 4 < WPB) ? len : kK2WTaps;
+}
+
+template <int SL, int WPB, int DT = kK2WTaps>
 struct K2RGeom {
-    static constexpr int D = kK2WTaps;
+    static constexpr int D = DT;
     static constexpr int LOOK = ((D - 1) * SL + 31) / 32;           // words beyond w that the taps of word w reach
     static constexpr int CPR = WPB / 4;                             // chunks per row = ring size in chunks
     static constexpr int RC = CPR;
@@ -80,21 +91,20 @@ __device__ __forceinline__ uint32_t k2r_word(const K2WRing<WPB / 4> &R, int s)
 
 // the class of taps P, P + STEP, ... < 16 on stream words base + (tap offset): acc &= AND of (W == bit), two taps per
 // v_bitop3 (three in the first); FOLD: the last instruction also ANDs `extra` in (the shifted class-B mask)
-template <int SL, int WPB, uint32_t BITS, int P, int STEP, bool FIRST, bool FOLD>
+template <int SL, int WPB, int D, uint32_t BITS, int P, int STEP, bool FIRST, bool FOLD>
 __device__ __forceinline__ uint32_t k2r_chain(const K2WRing<WPB / 4> &R, int base, uint32_t acc, uint32_t extra)
 {
-    constexpr int D = kK2WTaps;
     constexpr int x0 = (P * SL) >> 5, x1 = ((P + STEP) * SL) >> 5, x2 = ((P + 2 * STEP) * SL) >> 5;
     constexpr uint32_t b0 = (BITS >> P) & 1u, b1 = (BITS >> (P + STEP)) & 1u, b2 = (BITS >> (P + 2 * STEP)) & 1u;
     if constexpr (FIRST) {
         static_assert(P + 2 * STEP < D, "a class has at least three taps");
         constexpr uint32_t tt = 1u << (4 * b0 + 2 * b1 + b2);                       // (x == b0) & (y == b1) & (z == b2)
         acc = __builtin_amdgcn_bitop3_b32(k2r_word<WPB>(R, base + x0), k2r_word<WPB>(R, base + x1), k2r_word<WPB>(R, base + x2), tt);
-        return k2r_chain<SL, WPB, BITS, P + 3 * STEP, STEP, false, FOLD>(R, base, acc, extra);
+        return k2r_chain<SL, WPB, D, BITS, P + 3 * STEP, STEP, false, FOLD>(R, base, acc, extra);
     } else if constexpr (P + STEP < D) {                                          // x & (y == b0) & (z == b1)
         constexpr uint32_t tt = 1u << (4 + 2 * b0 + b1);
         acc = __builtin_amdgcn_bitop3_b32(acc, k2r_word<WPB>(R, base + x0), k2r_word<WPB>(R, base + x1), tt);
-        return k2r_chain<SL, WPB, BITS, P + 2 * STEP, STEP, false, FOLD>(R, base, acc, extra);
+        return k2r_chain<SL, WPB, D, BITS, P + 2 * STEP, STEP, false, FOLD>(R, base, acc, extra);
     } else if constexpr (P < D) {                                                 // the last tap alone
         if constexpr (FOLD) {                                                     // x & (y == b0) & z
             constexpr uint32_t tt = 1u << (4 + 2 * b0 + 1);
@@ -110,32 +120,32 @@ __device__ __forceinline__ uint32_t k2r_chain(const K2WRing<WPB / 4> &R, int bas
 }
 
 // group GG: masks of its four words; Bc = class-B mask of the B-block in front of the group (in / out)
-template <int SL, int WPB, int GG, uint32_t BITS>
+template <int SL, int WPB, int D, int GG, uint32_t BITS>
 __device__ __forceinline__ void k2r_sweep(const K2WRing<WPB / 4> &R, uint32_t (&M)[4], uint32_t &Bc)
 {
     using T = K2RTaps<SL>;
     if constexpr (T::kHalf) {
         uint32_t B[4];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) B[j] = k2r_chain<SL, WPB, BITS, 1, 2, true, false>(R, GG * 4 + j + 1, 0u, 0u);
+        for (int j = 0; j < 4; ++j) B[j] = k2r_chain<SL, WPB, D, BITS, 1, 2, true, false>(R, GG * 4 + j + 1, 0u, 0u);
         asm volatile("" : "+v"(B[0]), "+v"(B[1]), "+v"(B[2]), "+v"(B[3]));       // keep the two classes apart: fewer live registers
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const uint32_t Bs = __builtin_amdgcn_alignbit(j ? B[j - 1] : Bc, B[j], 16);
-            M[j] = k2r_chain<SL, WPB, BITS, 0, 2, true, true>(R, GG * 4 + j, 0u, Bs);
+            M[j] = k2r_chain<SL, WPB, D, BITS, 0, 2, true, true>(R, GG * 4 + j, 0u, Bs);
         }
         Bc = B[3];
     } else {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) M[j] = k2r_chain<SL, WPB, BITS, 0, 1, true, false>(R, GG * 4 + j, 0u, 0u);
+        for (int j = 0; j < 4; ++j) M[j] = k2r_chain<SL, WPB, D, BITS, 0, 1, true, false>(R, GG * 4 + j, 0u, 0u);
     }
 }
 
 // class-B mask of the B-block in front of word 0 of the row: positions [-16, 16), own-row words only
-template <int SL, int WPB, uint32_t BITS>
+template <int SL, int WPB, int D, uint32_t BITS>
 __device__ __forceinline__ uint32_t k2r_b_first(const K2WRing<WPB / 4> &R)
 {
-    if constexpr (K2RTaps<SL>::kHalf) return k2r_chain<SL, WPB, BITS, 1, 2, true, false>(R, 0, 0u, 0u);
+    if constexpr (K2RTaps<SL>::kHalf) return k2r_chain<SL, WPB, D, BITS, 1, 2, true, false>(R, 0, 0u, 0u);
     else return 0u;
 }
 
@@ -182,33 +192,34 @@ __device__ __forceinline__ void k2r_wait(K2WRing<CPRN> &R)
 
 // groups GG .. CPR-1 of the row, statically unrolled: every register index, every wait count and the point where a slot
 // turns into look-ahead are compile-time facts, and the stream of loads at the top is never interrupted by a branch
-template <int SL, int WPB, int KIND, int GG>
+template <int SL, int WPB, int KIND, int D, int GG>
 __device__ __forceinline__ void k2r_groups(K2WRing<WPB / 4> &R, k2w_v4u &X, uint32_t q, uint32_t w_lo, uint32_t w_hi,
                                            uint32_t lane, uint32_t *mylist, uint32_t &list_n, uint32_t &Bc)
 {
-    using G = K2RGeom<SL, WPB>;
+    using G = K2RGeom<SL, WPB, D>;
     if constexpr (GG < G::CPR) {
-        // the chunks of the own row this group touches for the first time: up to stream word 4 GG + 3 + x_15 + 1
-        constexpr int hi = (4 * GG + 4 + (((kK2WTaps - 1) * SL) >> 5)) >> 2;
+        // the chunks of the own row this group touches for the first time: up to stream word 4 GG + 3 + x_last + 1
+        constexpr int hi = (4 * GG + 4 + (((D - 1) * SL) >> 5)) >> 2;
         constexpr int c1 = hi < G::CPR - 1 ? hi : G::CPR - 1;
-        constexpr int hp = GG == 0 ? -1 : ((4 * (GG - 1) + 4 + (((kK2WTaps - 1) * SL) >> 5)) >> 2);
+        constexpr int hp = GG == 0 ? -1 : ((4 * (GG - 1) + 4 + (((D - 1) * SL) >> 5)) >> 2);
         constexpr int c0 = hp < G::CPR - 1 ? hp + 1 : G::CPR;          // first chunk not yet waited for
         if constexpr (c0 <= c1) k2r_wait<G::CPR, c0, c1>(R);
         if constexpr (GG == 0) asm volatile("" : "+v"(X));           // issued first: landed with chunk 0
         uint32_t M[4];
-        if constexpr (GG == 0) Bc = k2r_b_first<SL, WPB, kK2WKnown[KIND]>(R);
-        k2r_sweep<SL, WPB, GG, kK2WKnown[KIND]>(R, M, Bc);
+        if constexpr (GG == 0) Bc = k2r_b_first<SL, WPB, D, (uint32_t)kK2WKnownAll[KIND]>(R);
+        k2r_sweep<SL, WPB, D, GG, (uint32_t)kK2WKnownAll[KIND]>(R, M, Bc);
         if (__ballot((M[0] | M[1] | M[2] | M[3]) != 0))                 // rare
             k2w_record(M, q, (uint32_t)GG, w_lo, w_hi, lane, mylist, list_n);
         if constexpr (GG < G::NLA) k2r_shift<G::CPR, GG>(R, X);
-        k2r_groups<SL, WPB, KIND, GG + 1>(R, X, q, w_lo, w_hi, lane, mylist, list_n, Bc);
+        k2r_groups<SL, WPB, KIND, D, GG + 1>(R, X, q, w_lo, w_hi, lane, mylist, list_n, Bc);
     }
 }
 
 template <int SL, int KIND, int WPB>
 __global__ __launch_bounds__(64 * kK2WWaves, 3) void k2_search_row(const K2Args a)
 {
-    using G = K2RGeom<SL, WPB>;
+    constexpr int D = k2r_taps<SL, KIND, WPB>();
+    using G = K2RGeom<SL, WPB, D>;
     constexpr int LG_WPB = WPB == 16 ? 4 : WPB == 32 ? 5 : WPB == 64 ? 6 : 7;
     static_assert(WPB == 16 || WPB == 32 || WPB == 64 || WPB == 128, "rows of 16, 32, 64 or 128 words");
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
@@ -259,38 +270,41 @@ __global__ __launch_bounds__(64 * kK2WWaves, 3) void k2_search_row(const K2Args 
     const uint32_t w_lo = (uint32_t)(lo64 < 0 ? 0 : lo64 > (int64_t)wpb ? wpb : lo64);
     const uint32_t w_hi = (uint32_t)(hi64 < 0 ? 0 : hi64 > (int64_t)wpb ? wpb : hi64);
 
-    // ---- stage 1: sixteen taps on every position of the row ----
+    // ---- stage 1: D taps on every position of the row ----
     uint32_t list_n = 0;                                             // wave-uniform
     uint32_t Bc = 0;
-    k2r_groups<SL, WPB, KIND, 0>(R, X, 0u, w_lo, w_hi, lane, mylist, list_n, Bc);
+    k2r_groups<SL, WPB, KIND, D, 0>(R, X, 0u, w_lo, w_hi, lane, mylist, list_n, Bc);
     K2W_STAMP(1);
 
-    // ---- stage 2: the taps behind the first 16 on the list entries (one per lane), words from memory; compaction in place ----
-    const uint32_t maxL = pl;
+    // ---- stage 2: the taps behind the first D on the list entries (one per lane), words from memory, eight taps (sixteen
+    // loads) in flight per round; compaction in place.  Nothing to do when the sweep applied the whole preamble (scm, scm+)
     const uint32_t n_cand = list_n < (uint32_t)kK2WList ? list_n : (uint32_t)kK2WList;
     uint32_t n_keep = 0;                                             // wave-uniform
     const uint32_t *tw = a.qt + (size_t)T * tile_words;
+    const uint32_t maxL = pl;
     for (uint32_t e0 = 0; e0 < n_cand; e0 += 64) {
         const uint32_t e = e0 + lane;
         uint32_t key = 0, m = 0;
         if (e < n_cand) { key = mylist[e * 2]; m = mylist[e * 2 + 1]; }
         const uint32_t l = (key >> 8) & 63, w = key & 0xff;
-        for (uint32_t p = kK2WTaps; p < maxL; p += 4) {              // four taps per round: their eight loads are in flight together
-            if (!__any(m != 0)) break;
-            uint32_t Wd[4];
+        if constexpr (D < (int)kK2WKnownLen[KIND]) {
+            for (uint32_t p = D; p < maxL; p += 8) {
+                if (!__any(m != 0)) break;
+                uint32_t Wd[8];
 #pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                const uint32_t pk = p + k < maxL ? p + k : maxL - 1;
-                const uint32_t o = pk * SL;
-                const uint32_t x = w + (o >> 5);
-                // word x of the stream that starts with row l of this tile: tiled row l + x / wpb (may be row 0 of the next tile)
-                const uint32_t A = tw[qt_index(l + (x >> lg_wpb), x & (wpb - 1), lg_wpb)];
-                const uint32_t B = tw[qt_index(l + ((x + 1) >> lg_wpb), (x + 1) & (wpb - 1), lg_wpb)];
-                Wd[k] = (o & 31) ? __builtin_amdgcn_alignbit(A, B, 16) : A;
+                for (int k = 0; k < 8; ++k) {
+                    const uint32_t pk = p + k < maxL ? p + k : maxL - 1;
+                    const uint32_t o = pk * SL;
+                    const uint32_t x = w + (o >> 5);
+                    // word x of the stream that starts with row l of this tile: tiled row l + x / wpb (may be row 0 of the next tile)
+                    const uint32_t A = tw[qt_index(l + (x >> lg_wpb), x & (wpb - 1), lg_wpb)];
+                    const uint32_t B = tw[qt_index(l + ((x + 1) >> lg_wpb), (x + 1) & (wpb - 1), lg_wpb)];
+                    Wd[k] = (o & 31) ? __builtin_amdgcn_alignbit(A, B, 16) : A;
+                }
+#pragma unroll
+                for (int k = 0; k < 8; ++k)
+                    if (p + k < pl) m &= ((pb >> (p + k)) & 1) ? Wd[k] : ~Wd[k];
             }
-#pragma unroll
-            for (int k = 0; k < 4; ++k)
-                if (p + k < pl) m &= ((pb >> (p + k)) & 1) ? Wd[k] : ~Wd[k];
         }
         const uint64_t b = __ballot(m != 0);
         if (m != 0) {   // survivors move to the front, order preserved (slot <= e, earlier entries already read)
@@ -309,21 +323,35 @@ __global__ __launch_bounds__(64 * kK2WWaves, 3) void k2_search_row(const K2Args 
     const uint32_t total = __builtin_amdgcn_readlane(inc, 63);
     bases[lane] = inc - val;
 
-    // ---- emit: every surviving entry by 32 lanes at once, lane b = bit b (MSB first = stream order).  The list is in
-    // walk order: word-major across the rows, ascending words inside a row -- which is all the ranks need ----
-    uint32_t run = 0;
-    for (uint32_t e = 0; e < n_keep; ++e) {
-        const uint32_t key = __builtin_amdgcn_readfirstlane(mylist[e * 2]);
-        const uint32_t m = __builtin_amdgcn_readfirstlane(mylist[e * 2 + 1]);
-        const uint32_t l = (key >> 8) & 63, w = key & 0xff;
-        const uint32_t r = __builtin_amdgcn_readlane(run, l);
-        const uint32_t base = bases[l] + r;
-        if (lane < 32 && ((m >> (31 - lane)) & 1)) {
-            const uint32_t before = lane ? __popc(m >> (32 - lane)) : 0;
-            const uint32_t rank = base + before;
-            if (rank < a.cap) a.staging[(size_t)T * a.cap + rank] = (l << lg_bs) + (w << 5) + lane;
+    // ---- emit.  The list is in walk order: word-major across the rows, ascending words inside a row, so the slot of an
+    // entry = the hits of the rows in front of its row + the hits of the earlier entries of its own row.  Sixty-four
+    // entries at a time live in registers (lane e = entry e): their slots come out of one pass of v_readlane broadcasts,
+    // and the positions of an entry are then written by 32 lanes at once (lane b = bit b, MSB first = stream order) from
+    // broadcast values -- no LDS or memory latency inside either loop (k2_walk.h re-reads the list entry by entry: 700
+    // cycles per entry; a tile with two packets holds eight).
+    uint32_t run = 0;                                                // lane l: hits of row l emitted by earlier rounds
+    for (uint32_t e0 = 0; e0 < n_keep; e0 += 64) {
+        const uint32_t e = e0 + lane;
+        uint32_t key = 0, m = 0;
+        if (e < n_keep) { key = mylist[e * 2]; m = mylist[e * 2 + 1]; }
+        const uint32_t l = (key >> 8) & 63, c = (uint32_t)__popc(m);
+        uint32_t slot = bases[l] + (uint32_t)__builtin_amdgcn_ds_bpermute((int)(l << 2), (int)run);
+        const uint32_t n = n_keep - e0 < 64u ? n_keep - e0 : 64u;    // wave-uniform
+        uint32_t add = 0;
+        for (uint32_t j = 0; j < n; ++j) {
+            const uint32_t lj = (uint32_t)__builtin_amdgcn_readlane((int)l, (int)j), cj = (uint32_t)__builtin_amdgcn_readlane((int)c, (int)j);
+            slot += (lane > j && l == lj) ? cj : 0u;
+            add += (lane == lj) ? cj : 0u;
         }
-        run += (lane == l) ? __popc(m) : 0;
+        for (uint32_t j = 0; j < n; ++j) {
+            const uint32_t kj = (uint32_t)__builtin_amdgcn_readlane((int)key, (int)j), mj = (uint32_t)__builtin_amdgcn_readlane((int)m, (int)j);
+            const uint32_t sj = (uint32_t)__builtin_amdgcn_readlane((int)slot, (int)j);
+            if (lane < 32 && ((mj >> (31 - lane)) & 1)) {
+                const uint32_t rank = sj + (lane ? __popc(mj >> (32 - lane)) : 0);
+                if (rank < a.cap) a.staging[(size_t)T * a.cap + rank] = (((kj >> 8) & 63) << lg_bs) + ((kj & 0xff) << 5) + lane;
+            }
+        }
+        run += add;
     }
     K2W_STAMP(3);
 #if AMR_K2W_DBG

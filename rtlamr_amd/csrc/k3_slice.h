@@ -342,6 +342,19 @@ __global__ void k_done(uint64_t *flag, uint64_t value, uint64_t *dev_flag)
     __hip_atomic_store(flag, value, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
+// First kernel of a tail that was enqueued AHEAD of time (submit of the following batch): holds the second stream until
+// that batch's K1 has all its waves on the chip (K1Args::started), plus `delay` ticks of the 100 MHz clock for the other
+// XCDs' dispatchers.  One lane; it sleeps between polls and needs no LDS and 8 registers, so it fits next to a full K1.
+__global__ void k_gate(const uint64_t *flag, uint64_t value, uint32_t delay)
+{
+    const uint64_t t0 = __builtin_amdgcn_s_memrealtime();
+    while (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < value &&
+           __builtin_amdgcn_s_memrealtime() - t0 < 400000000ull)        // 4 s: a device that lost the K1 launch; the host will see the fault
+        __builtin_amdgcn_s_sleep(16);
+    const uint64_t t1 = __builtin_amdgcn_s_memrealtime();
+    while (__builtin_amdgcn_s_memrealtime() - t1 < delay) __builtin_amdgcn_s_sleep(8);
+}
+
 // Tests: tiled rows 64.. -> linear MSB-first byte stream (decode.go:259-265 packing).
 __global__ void k_untile(const uint32_t *qt, uint32_t *out, uint32_t n_blocks, uint32_t lg_wpb)
 {

@@ -34,8 +34,31 @@ __global__ void k_stream_read(const uint4 *p, size_t n16, uint32_t *sink)
     }
     if (acc == 0x12345679u) *sink = acc;
 }
+// "coldw": what K1 does in front of K2 in the product -- one wave per tile, XCD-contiguous tile order, streams its share of
+// a GiB (nt loads) and WRITES its tile of the bitstream (sc1 stores, from a shadow copy of the same bits)
+__global__ __launch_bounds__(64) void k_k1_like(const uint4 *cold, size_t n16_per_wave, const uint4 *shadow, uint4 *qt, uint32_t tile16, uint32_t *sink)
+{
+    typedef uint32_t v4 __attribute__((ext_vector_type(4)));
+    const uint32_t wt = (blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3);
+    const v4 *src = reinterpret_cast<const v4 *>(cold) + (size_t)wt * n16_per_wave;
+    uint32_t acc = 0;
+    for (size_t i = threadIdx.x; i < n16_per_wave; i += 64) { const v4 v = __builtin_nontemporal_load(src + i); acc ^= v.x ^ v.y ^ v.z ^ v.w; }
+    const uint4 *sh = shadow + (size_t)(wt + 1) * tile16;      // tile 0 = history tile: not written by K1
+    uint4 *dst = qt + (size_t)(wt + 1) * tile16;
+    for (uint32_t i = threadIdx.x; i < tile16; i += 64) {
+        const v4 x = reinterpret_cast<const v4 *>(sh)[i];
+        v4 *pd = reinterpret_cast<v4 *>(dst) + i;
+        asm volatile("global_store_dwordx4 %0, %1, off sc1" :: "v"(pd), "v"(x) : "memory");
+    }
+    if (acc == 0x12345679u) *sink = acc;
+}
 static uint4 *g_cold = nullptr; static uint32_t *g_sink = nullptr; static const size_t kColdBytes = (size_t)1 << 30;
-static void cold_pass() { if (g_cold) hipLaunchKernelGGL(k_stream_read, dim3(4096), dim3(256), 0, 0, g_cold, kColdBytes / 16, g_sink); }
+static const uint4 *g_shadow = nullptr; static uint4 *g_qt = nullptr; static uint32_t g_tile16 = 0, g_wtiles = 0;
+static void cold_pass()
+{
+    if (g_shadow) hipLaunchKernelGGL(k_k1_like, dim3(g_wtiles), dim3(64), 0, 0, g_cold, kColdBytes / 16 / g_wtiles, g_shadow, g_qt, g_tile16, g_sink);
+    else if (g_cold) hipLaunchKernelGGL(k_stream_read, dim3(4096), dim3(256), 0, 0, g_cold, kColdBytes / 16, g_sink);
+}
 
 // the row kernel (one preamble, rows of up to 128 words) on the same arguments; compares with what the walk left behind
 template <int SL, int KIND, int WPB>
@@ -158,7 +181,8 @@ int main(int argc, char **argv)
     const bool wide = strcmp(kind, "scm") != 0;
     const uint32_t n_tiles = argc > 2 ? (uint32_t)atoi(argv[2]) : (wide ? 4097u : 2049u);
     const int reps = argc > 3 ? atoi(argv[3]) : 40;
-    if (argc > 4 && !strcmp(argv[4], "cold")) {
+    const bool coldw = argc > 4 && !strcmp(argv[4], "coldw");
+    if (argc > 4 && (!strcmp(argv[4], "cold") || coldw)) {
         CK(hipMalloc((void **)&g_cold, kColdBytes)); CK(hipMalloc((void **)&g_sink, 4));
         CK(hipMemset(g_cold, 1, kColdBytes));
     }
@@ -180,7 +204,29 @@ int main(int argc, char **argv)
         std::vector<uint32_t> h(qt_bytes / 4);
         uint64_t s = 0x9e3779b97f4a7c15ull;
         for (auto &w : h) { s ^= s << 13; s ^= s >> 7; s ^= s << 17; w = (uint32_t)(s >> 16); }
+        if (getenv("K2B_BURSTS")) {   // what planted packets look like: K2B_BURSTS per tile, each 72 adjacent positions that match the preamble
+            const int per_tile = atoi(getenv("K2B_BURSTS"));
+            const uint32_t lg_wpb = g.lg_wpb, wpb = g.wpb;
+            auto setbit = [&](uint64_t n, int v) {      // stream bit n counted from row 64 (first batch row), first sample in bit 31
+                const uint64_t R = 64 + n / g.block_size; const uint32_t w = (uint32_t)((n % g.block_size) >> 5), b = 31 - (uint32_t)(n & 31);
+                const size_t i = ((R >> 6) << (6 + lg_wpb)) + ((size_t)(w >> 2) << 8) + ((R & 63) << 2) + (w & 3);
+                if (i < h.size()) h[i] = (h[i] & ~(1u << b)) | ((uint32_t)v << b);
+            };
+            const uint64_t tile_bits = (uint64_t)64 * g.block_size;
+            (void)wpb;
+            for (uint32_t T = 0; T + 2 < n_tiles; ++T)
+                for (int k = 0; k < per_tile; ++k) {
+                    s ^= s << 13; s ^= s >> 7; s ^= s << 17;
+                    const uint64_t o = (uint64_t)T * tile_bits + (s >> 20) % (tile_bits - 40000);
+                    for (uint32_t p = 0; p < g.pre_len[0]; ++p)
+                        for (int d = 0; d < 72; ++d) setbit(o + (uint64_t)p * g.symbol_length + d, (int)((g.pre_bits[0] >> p) & 1));
+                }
+        }
         CK(hipMemcpy(d_qt, h.data(), qt_bytes, hipMemcpyHostToDevice));
+    }
+    if (coldw) {
+        uint4 *sh; CK(hipMalloc((void **)&sh, qt_bytes)); CK(hipMemcpy(sh, d_qt, qt_bytes, hipMemcpyDeviceToDevice));
+        g_shadow = sh; g_qt = reinterpret_cast<uint4 *>(d_qt); g_tile16 = (uint32_t)(tile_words / 4); g_wtiles = (n_tiles - 1) & ~7u;
     }
     a.qt = d_qt; a.n_tiles = n_tiles; a.cap = 1024;
     CK(hipMalloc((void **)&a.counts, (size_t)n_tiles * g.n_pre * 4));
