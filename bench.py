@@ -92,6 +92,10 @@ def build_packets(wl: dict, shard: int, bs: int, n_samples: int):
     return pk
 
 
+def golden_key(wl: dict, n_blocks: int, shard: int) -> str:
+    return f"{wl['name']}|blocks={n_blocks}|shard={shard}" + ("|data=uniform" if wl.get("data") == "uniform" else "")
+
+
 def device_workload(dec, wl: dict, shard_idx: int, n_blocks: int, local_rank: int = 0):
     """Shard `shard_idx` of the workload's stream, generated in HBM (SURVEY.md 8d generator, K0), and -- for shards
     behind the first -- the decoder primed with the blocks in front of it (amr_prime), as a rank of a multi-GPU run
@@ -104,17 +108,18 @@ def device_workload(dec, wl: dict, shard_idx: int, n_blocks: int, local_rank: in
     n_samples = n_blocks * bs
     d_iq = C.c_void_p()
     _lib.check(L.amr_dev_alloc(local_rank, n_blocks * bs2, C.byref(d_iq)), "amr_dev_alloc")
-    pk = build_packets(wl, shard_idx, bs, n_samples)
+    uni = wl.get("data") == "uniform"      # SURVEY.md 8d's second distribution: uniform random bytes, nothing planted
+    pk = [] if uni else build_packets(wl, shard_idx, bs, n_samples)
     synth.device_fill(local_rank, d_iq.value, n_samples, seed=1, first_sample=shard_idx * n_samples, packets=pk,
-                      chip_length=chip)
+                      chip_length=chip, uniform_bytes=uni)
     if shard_idx > 0:   # rebuild the history a single decoder would carry into this shard
         pb = dec.prime_blocks()
         hb = pb + 1
         d_h = C.c_void_p()
         _lib.check(L.amr_dev_alloc(local_rank, hb * bs2, C.byref(d_h)), "amr_dev_alloc")
-        prev = build_packets(wl, shard_idx - 1, bs, n_samples)
+        prev = [] if uni else build_packets(wl, shard_idx - 1, bs, n_samples)
         synth.device_fill(local_rank, d_h.value, hb * bs, seed=1, first_sample=shard_idx * n_samples - hb * bs,
-                          packets=prev[-8:] + pk[:1], chip_length=chip)
+                          packets=prev[-8:] + pk[:1], chip_length=chip, uniform_bytes=uni)
         dec.prime_device(d_h.value + bs2, pb, d_lead=d_h.value + bs2 - dec.halo_bytes())
         dec.set_block_base(shard_idx * n_blocks)
         _lib.check(L.amr_dev_free(local_rank, d_h), "amr_dev_free")
@@ -260,6 +265,10 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--workload", default="cfg2", help="cfg2 (default), cfg3, cfg4:<chip>, cfg5")
     ap.add_argument("--blocks", type=int, default=0, help="blocks per GPU per step (default: the workload's size)")
+    ap.add_argument("--data", choices=["synthetic", "uniform"], default="synthetic",
+                    help="synthetic: 2.4 Msps-shaped noise (binomial around 127/128) + planted CRC-valid packets (default, the "
+                         "headline); uniform: uniform random bytes, nothing planted -- SURVEY.md 8d's second distribution, the "
+                         "worst case for the magnitude LUT's LDS gathers")
     ap.add_argument("--spinup-ms", type=float, default=250.0, help="untimed passes before the warm-up (shader clock ramp)")
     ap.add_argument("--depth", type=int, default=3, help="batches in flight (1..3)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -273,6 +282,7 @@ def main():
                          "GPU (default; turns --validate on) or every hit the search found")
     args = ap.parse_args()
     wl = workload(args.workload)
+    wl["data"] = args.data
 
     # ---- who am I: a rank of a launcher's job, the only rank, or the process that has to start the ranks ----
     from rtlamr_amd import launch
@@ -336,7 +346,7 @@ def main():
         gold = json.load(open(GOLDEN))
     except Exception:
         gold = {}
-    key = f"{wl['name']}|blocks={n_blocks}|shard={shard_idx}"
+    key = golden_key(wl, n_blocks, shard_idx)
     verify = not args.no_verify
     aligned = n_blocks % 64 == 0       # otherwise deferral shifts the calls a result covers from step to step
 
@@ -541,7 +551,7 @@ def main():
             n_true, off, blk, idx = gatherer.fetch(seq, r)
             rows = shard.rows_from_gathered(off, blk, idx)
             rows[:, 1] -= last.first_block - shard_idx * n_blocks   # every rank has made the same number of calls
-            kr = f"{wl['name']}|blocks={n_blocks}|shard={r if world > 1 else shard_idx}"
+            kr = golden_key(wl, n_blocks, r if world > 1 else shard_idx)
             if verify and aligned and kr in gold:
                 g = gold[kr]["steady"]
                 want = (g["validated"] if validating else g)["hits_sha256"]
@@ -553,7 +563,7 @@ def main():
                            f"records of all {world} rank(s) == oracle golden" if not gstat["bad"] else
                            "MISMATCH: " + "; ".join(gstat["bad"][:4]))
         rc = rc or (6 if gstat["bad"] else 0)
-    if verify and rank == 0 and shard_idx == 0 and not validating:
+    if verify and rank == 0 and shard_idx == 0 and not validating and wl["data"] != "uniform":
         n_want, n_missing, n_extra = verify_batch(ra, wl, local_rank, d_iq.value, n_blocks, pk, bs, n_samples)
         ok = n_missing == 0 and n_extra == 0 and n_want > 0
         check["planted"] = (f"{n_want} planted messages recovered, none missing, none unexpected" if ok else
@@ -588,7 +598,7 @@ def main():
             "steady_ms_per_step": round(steady_ms, 4),
             "pipeline_fill_ms": round(dt * 1e3 - args.steps * steady_ms, 4),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32", "data": "synthetic",
+            "dtype": "f32", "data": "synthetic" if wl["data"] != "uniform" else "synthetic (uniform random bytes)",
             "config": {"workload": f"{wl['name']}: {'+'.join(wl['protos'])} chip {chip}, {n_blocks} blocks of {bs2} B per GPU",
                        "protocols": wl["protos"], "chip_length": chip,
                        "block_size": bs, "bytes_per_gpu_per_step": nbytes, "planted_packets_per_gpu": len(pk),
@@ -606,8 +616,10 @@ def main():
                          "whole_path_frac_timed": round(alg_bytes / (ms_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
                          "k1_ms": round(k1_ms, 4), "search_ms": round(float(np.mean(search_ms)), 4),
                          "kernel_timing": (f"HIP events on the dispatches of every {args.k1_events}th timed step ({len(demod_ms)} steps): "
-                                           "K1 duration; search_ms = K2 duration + K3.. duration (two streams once batches are in "
-                                           "flight: K3 of a batch runs next to the following batch's K2)"),
+                                           "K1 duration; search_ms = K2 duration (with batches in flight K3.. of a batch run on a "
+                                           "second stream, let in when the following batch's K1 has all its waves on the chip: they "
+                                           "fill its ragged end and the start of that batch's K2; steady_ms_per_step - k1_ms is "
+                                           "everything a step costs besides K1)"),
                          "algorithmic_bytes_per_launch": alg_bytes},
         }
         if distributed:

@@ -107,7 +107,8 @@ typedef struct amr_result {
 /* Timing of the last batch, measured with HIP events on the handle's stream. */
 typedef struct amr_timing {
     float demod_ms;   /* K1: magnitude + csum matched filter + quantize + pack */
-    float search_ms;  /* K2 + K3: preamble search, compaction, slice */
+    float search_ms;  /* K2 + K3: preamble search, compaction, slice (pipelined callers: K2 only -- K3 of a batch runs
+                         on a second stream next to the end of the following batch's K1 and has no duration of its own) */
     float total_ms;   /* first kernel start to last kernel end (device side) */
 } amr_timing;
 
@@ -287,6 +288,9 @@ amr_status amr_dev_sync(int32_t device_id);
  * Q = 120 + popcount((h >> 16) & 0xFFFF).  first_sample = stream index of d_iq[0].
  */
 amr_status amr_synth_noise(int32_t device_id, void *d_iq, uint64_t n_samples, uint64_t seed, uint64_t first_sample);
+/* The second distribution of SURVEY.md 8d: uniform random bytes, I = bits 32..39, Q = bits 40..47 of the same hash
+ * (every magnitude-LUT entry equally likely: the worst case for the LUT gathers of the demodulation kernel). */
+amr_status amr_synth_uniform(int32_t device_id, void *d_iq, uint64_t n_samples, uint64_t seed, uint64_t first_sample);
 
 /*
  * Add Manchester-OOK bursts: packet j starts at stream sample start[j], carries

@@ -77,6 +77,8 @@ def lib():
         L.orc_r900_filter.restype = None
         L.orc_synth_noise.argtypes = [C.c_void_p, C.c_uint64, C.c_uint64, C.c_uint64]
         L.orc_synth_noise.restype = None
+        L.orc_synth_uniform.argtypes = [C.c_void_p, C.c_uint64, C.c_uint64, C.c_uint64]
+        L.orc_synth_uniform.restype = None
         L.orc_synth_plant.argtypes = [C.c_void_p, C.c_uint64, C.c_uint64, C.c_int, C.c_uint64, C.c_char_p, C.c_uint32,
                                       C.c_int, C.c_int]
         L.orc_synth_plant.restype = None
@@ -224,17 +226,20 @@ def default_threads() -> int:
     return max(1, min(64, os.cpu_count() or 1))
 
 
-def synth_stream(n_samples: int, seed: int, first_sample: int, packets, chip_length: int, n_threads: int = 0) -> np.ndarray:
-    """uint8[2*n_samples]: SURVEY 8d noise + planted packets (objects with start, data, n_bits, d_i, d_q), made by
-    synth_gen.c on n_threads threads.  Byte-identical to rtlamr_amd.synth.noise + plant and to the device generator."""
+def synth_stream(n_samples: int, seed: int, first_sample: int, packets, chip_length: int, n_threads: int = 0,
+                 uniform: bool = False) -> np.ndarray:
+    """uint8[2*n_samples]: SURVEY 8d noise (uniform: its second distribution, uniform random bytes) + planted packets
+    (objects with start, data, n_bits, d_i, d_q), made by synth_gen.c on n_threads threads.  Byte-identical to
+    rtlamr_amd.synth.noise / uniform + plant and to the device generator."""
     L = lib()
+    gen = L.orc_synth_uniform if uniform else L.orc_synth_noise
     out = np.empty(2 * n_samples, np.uint8)
     nt = n_threads or default_threads()
     step = max(1 << 20, -(-n_samples // (4 * nt)) & ~7)
     jobs = []
     for s0 in range(0, n_samples, step):
         n = min(step, n_samples - s0)
-        jobs.append(lambda s0=s0, n=n: L.orc_synth_noise(out.ctypes.data + 2 * s0, n, seed, first_sample + s0))
+        jobs.append(lambda s0=s0, n=n: gen(out.ctypes.data + 2 * s0, n, seed, first_sample + s0))
     _run_threads(jobs, nt)
     for p in packets:       # packets never overlap: order does not matter; each is a few thousand samples
         L.orc_synth_plant(out.ctypes.data, n_samples, first_sample, chip_length, int(p.start), bytes(p.data),

@@ -32,6 +32,16 @@ void orc_synth_noise(uint8_t *out, uint64_t n_samples, uint64_t seed, uint64_t f
     }
 }
 
+/* the second distribution of SURVEY.md 8d: uniform random bytes (device twin: k_synth_noise<true>) */
+void orc_synth_uniform(uint8_t *out, uint64_t n_samples, uint64_t seed, uint64_t first_sample)
+{
+    for (uint64_t i = 0; i < n_samples; i++) {
+        const uint64_t h = splitmix64(seed ^ (first_sample + i));
+        out[2 * i] = (uint8_t)(h >> 32);
+        out[2 * i + 1] = (uint8_t)(h >> 40);
+    }
+}
+
 /*
  * One packet: starts at stream sample `start`, n_bits bits (MSB first inside each byte of `bits`).
  * iq holds stream samples [first_sample, first_sample + n_samples); samples outside are skipped.

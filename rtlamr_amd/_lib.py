@@ -18,7 +18,7 @@ SYMBOLS = [
     "amr_set_stream", "amr_set_block_base", "amr_decode_batch", "amr_decode_batch_device", "amr_submit_device", "amr_collect", "amr_set_deferral", "amr_flush", "amr_submit_host", "amr_host_alloc", "amr_host_free", "amr_result_device", "amr_prime",
     "amr_halo_bytes", "amr_prime_blocks", "amr_copy_quantized", "amr_set_timing", "amr_get_timing", "amr_strerror",
     "amr_last_error", "amr_describe", "amr_dev_alloc", "amr_dev_free", "amr_dev_upload", "amr_dev_download",
-    "amr_dev_sync", "amr_synth_noise", "amr_synth_plant",
+    "amr_dev_sync", "amr_synth_noise", "amr_synth_uniform", "amr_synth_plant",
     "amr_comm_unique_id", "amr_comm_init", "amr_comm_destroy", "amr_comm_ranks", "amr_gather_hits", "amr_gather_wait", "amr_gather_fetch",
     "amr_gather_slot_bytes", "amr_gather_wire_bytes", "amr_gather_pack_host", "amr_gather_unpack",
 ]
@@ -135,6 +135,7 @@ def lib() -> C.CDLL:
     L.amr_dev_download.argtypes = [C.c_int32, vp, vp, C.c_size_t]
     L.amr_dev_sync.argtypes = [C.c_int32]
     L.amr_synth_noise.argtypes = [C.c_int32, vp, C.c_uint64, C.c_uint64, C.c_uint64]
+    L.amr_synth_uniform.argtypes = [C.c_int32, vp, C.c_uint64, C.c_uint64, C.c_uint64]
     L.amr_synth_plant.argtypes = [C.c_int32, vp, C.c_uint64, C.c_uint64, C.c_int32, C.c_uint32, vp, vp,
                                   C.c_uint32, C.c_uint32, vp, vp]
     L.amr_comm_unique_id.argtypes = [vp]

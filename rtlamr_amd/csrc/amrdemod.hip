@@ -102,6 +102,7 @@ struct Slot {
     int timed = 0;                // timing level the batch in flight was submitted with
     bool tail_enqueued = true;    // K3.. of the batch in flight have been launched (false: collect launches them)
     bool tail_split = false;      // ... on the second stream
+    bool tail_gated = false;      // ... enqueued ahead, behind k_gate: K3 then runs next to the following K1's end and search
     bool folded = false;          // the state update ran inside the search kernel: no stream-A ticket for this batch
     hipEvent_t ev_k2 = nullptr, ev_t = nullptr;   // K2 stop, K3 start (timing level 2 with the tail on the second stream)
     hipEvent_t ev_pack = nullptr; bool pack_pending = false;   // multi-GPU gather: its pack kernel still reads d_out / d_val of this slot
@@ -559,6 +560,7 @@ amr_status submit(amr_handle *h, const uint8_t *d_iq, size_t n_blocks, bool sear
         hipLaunchKernelGGL(amr::k_gate, dim3(1), dim3(1), 0, h->tail_stream, h->d_k1_started, s.ticket, 600u /* 6 us */);
         HIP_TRY(hipGetLastError());
         AMR_TRY(launch_tail(h, prev));
+        prev.tail_gated = true;
     }
     s.dense = h->dense_hold > 0;
     if (s.dense) h->dense_hold--;
@@ -582,6 +584,7 @@ amr_status submit(amr_handle *h, const uint8_t *d_iq, size_t n_blocks, bool sear
     }
     s.tail_enqueued = !lazy;
     s.tail_split = lazy;
+    s.tail_gated = false;
     s.folded = folded;
 
     if (h->r900_pid >= 0) {   // the PL samples that precede the next batch (r900.go:168-170 keeps them as magnitudes)
@@ -834,7 +837,10 @@ amr_status collect(amr_handle *h, amr_result *res)
         float b2 = 0;
         if (s.timed >= 2 && s.search && s.tail_split && hipEventSynchronize(s.ev2) == hipSuccess &&
             hipEventElapsedTime(&b, s.ev_s, s.ev_k2) == hipSuccess && hipEventElapsedTime(&b2, s.ev_t, s.ev2) == hipSuccess)
-            h->timing = amr_timing{a, b + b2, a + b + b2};   // K2 and the tail ran apart: their durations, added up
+            // K2 and the tail ran apart: their durations, added up -- unless the tail was let in at the following K1's start
+            // (tail_gated): its workgroups then trickle in where K1 waves retire and its "duration" spans that whole K1;
+            // what the batch cost the compute stream besides K1 is its K2
+            h->timing = s.tail_gated ? amr_timing{a, b, a + b} : amr_timing{a, b + b2, a + b + b2};
         else if (s.timed >= 2 && s.search && !s.tail_split && hipEventSynchronize(s.ev2) == hipSuccess &&
             hipEventElapsedTime(&b, s.ev_s, s.ev2) == hipSuccess && hipEventElapsedTime(&c, s.ev0, s.ev2) == hipSuccess)
             h->timing = amr_timing{a, b, c};
@@ -1418,16 +1424,27 @@ amr_status amr_dev_sync(int32_t device_id)
     return AMR_OK;
 }
 
-amr_status amr_synth_noise(int32_t device_id, void *d_iq, uint64_t n_samples, uint64_t seed, uint64_t first_sample)
+static amr_status synth_fill(bool uniform, int32_t device_id, void *d_iq, uint64_t n_samples, uint64_t seed, uint64_t first_sample)
 {
     if (!d_iq || (n_samples & 7)) return fail(AMR_EINVAL, "n_samples must be a multiple of 8");
     HIP_TRY(hipSetDevice(device_id));
     const uint64_t threads = n_samples / 8;
-    hipLaunchKernelGGL(amr::k_synth_noise, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, 0, (uint8_t *)d_iq,
-                       n_samples, seed, first_sample);
+    const dim3 grid((unsigned)((threads + 255) / 256));
+    if (uniform) hipLaunchKernelGGL(amr::k_synth_noise<true>, grid, dim3(256), 0, 0, (uint8_t *)d_iq, n_samples, seed, first_sample);
+    else hipLaunchKernelGGL(amr::k_synth_noise<false>, grid, dim3(256), 0, 0, (uint8_t *)d_iq, n_samples, seed, first_sample);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipDeviceSynchronize());
     return AMR_OK;
+}
+
+amr_status amr_synth_noise(int32_t device_id, void *d_iq, uint64_t n_samples, uint64_t seed, uint64_t first_sample)
+{
+    return synth_fill(false, device_id, d_iq, n_samples, seed, first_sample);
+}
+
+amr_status amr_synth_uniform(int32_t device_id, void *d_iq, uint64_t n_samples, uint64_t seed, uint64_t first_sample)
+{
+    return synth_fill(true, device_id, d_iq, n_samples, seed, first_sample);
 }
 
 amr_status amr_synth_plant(int32_t device_id, void *d_iq, uint64_t n_samples, uint64_t first_sample, int32_t chip_length,

@@ -16,6 +16,9 @@ __host__ __device__ inline uint64_t splitmix64(uint64_t x)
 }
 
 // 8 samples (16 bytes) per thread; n_samples must be a multiple of 8.
+// UNIFORM: the second input distribution of SURVEY.md 8d -- uniform random bytes, I = bits 32..39 and Q = bits 40..47 of
+// the same hash: every LUT entry equally likely (the worst case for LDS bank conflicts in K1's gathers).
+template <bool UNIFORM>
 __global__ void k_synth_noise(uint8_t *iq, uint64_t n_samples, uint64_t seed, uint64_t first_sample)
 {
     const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -28,8 +31,8 @@ __global__ void k_synth_noise(uint8_t *iq, uint64_t n_samples, uint64_t seed, ui
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
             const uint64_t h = splitmix64(seed ^ (first_sample + s0 + 2 * k + j));
-            const uint32_t I = 119u + __popc((uint32_t)h & 0xFFFFu);
-            const uint32_t Q = 120u + __popc((uint32_t)(h >> 16) & 0xFFFFu);
+            const uint32_t I = UNIFORM ? (uint32_t)(h >> 32) & 0xFFu : 119u + __popc((uint32_t)h & 0xFFFFu);
+            const uint32_t Q = UNIFORM ? (uint32_t)(h >> 40) & 0xFFu : 120u + __popc((uint32_t)(h >> 16) & 0xFFFFu);
             v |= (I | (Q << 8)) << (16 * j);
         }
         w[k] = v;

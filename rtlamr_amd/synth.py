@@ -44,6 +44,17 @@ def noise(n_samples: int, seed: int, first_sample: int = 0) -> np.ndarray:
     return out
 
 
+def uniform(n_samples: int, seed: int, first_sample: int = 0) -> np.ndarray:
+    """uint8[2*n_samples] interleaved I,Q of the second distribution of SURVEY.md 8d: uniform random bytes (I = bits
+    32..39, Q = bits 40..47 of the hash); twin of k_synth_noise<true> and orc_synth_uniform."""
+    n = np.arange(first_sample, first_sample + n_samples, dtype=np.uint64)
+    h = splitmix64(np.uint64(seed) ^ n)
+    out = np.empty(2 * n_samples, np.uint8)
+    out[0::2] = ((h >> np.uint64(32)) & np.uint64(0xFF)).astype(np.uint8)
+    out[1::2] = ((h >> np.uint64(40)) & np.uint64(0xFF)).astype(np.uint8)
+    return out
+
+
 @dataclass
 class Packet:
     start: int      # stream sample index of the first chip
@@ -102,11 +113,12 @@ def packet_schedule(n_packets: int, n_samples: int, packet_samples: int, seed: i
 
 
 def device_fill(device_id: int, d_ptr: int, n_samples: int, seed: int, first_sample: int,
-                packets: Sequence[Packet], chip_length: int) -> None:
-    """Noise + packets directly in device memory (K0)."""
+                packets: Sequence[Packet], chip_length: int, uniform_bytes: bool = False) -> None:
+    """Noise (or uniform random bytes) + packets directly in device memory (K0)."""
     from . import _lib
     L = _lib.lib()
-    _lib.check(L.amr_synth_noise(device_id, C.c_void_p(d_ptr), n_samples, seed, first_sample), "amr_synth_noise")
+    fill = L.amr_synth_uniform if uniform_bytes else L.amr_synth_noise
+    _lib.check(fill(device_id, C.c_void_p(d_ptr), n_samples, seed, first_sample), "amr_synth_noise")
     by_len = {}
     for p in packets:                      # one plant call per packet length (scm 96, scm+ 128, idm 736 bits)
         by_len.setdefault(p.n_bits, []).append(p)

@@ -55,7 +55,7 @@ def _digest(wl, g, rows, pkt, q) -> dict:
     return d
 
 
-def golden_for(spec: str, shard: int, n_blocks: int = 0, threads: int = 0) -> dict:
+def golden_for(spec: str, shard: int, n_blocks: int = 0, threads: int = 0, uniform: bool = False) -> dict:
     """{"first": the shard decoded from the state a single Decoder carries into it (stream start, or the blocks
     bench.device_workload primes with), "steady": the shard decoded with its OWN tail as history -- what every
     timed step of bench.py after the first sees, since the steps replay one buffer}."""
@@ -65,16 +65,16 @@ def golden_for(spec: str, shard: int, n_blocks: int = 0, threads: int = 0) -> di
     bs, bs2 = g.block_size, g.block_size2
     n_blocks = n_blocks or wl["nbytes"] // bs2
     n_samples = n_blocks * bs
-    pk = bench.build_packets(wl, shard, bs, n_samples)
-    iq = orc.synth_stream(n_samples, 1, shard * n_samples, pk, wl["chip"], threads)
+    pk = [] if uniform else bench.build_packets(wl, shard, bs, n_samples)     # --data uniform: random bytes, nothing planted
+    iq = orc.synth_stream(n_samples, 1, shard * n_samples, pk, wl["chip"], threads, uniform=uniform)
     hb = (g.packet_length + bs - 1) // bs + 2
     out = {}
     for state in ("first", "steady"):
         if state == "steady":
             head = iq[-hb * bs2:]
         elif shard > 0:      # the blocks bench.py primes a shard's decoder with: same noise, same packets
-            prev = bench.build_packets(wl, shard - 1, bs, n_samples)[-8:]
-            head = orc.synth_stream(hb * bs, 1, shard * n_samples - hb * bs, prev + pk[:1], wl["chip"], threads)
+            prev = [] if uniform else bench.build_packets(wl, shard - 1, bs, n_samples)[-8:]
+            head = orc.synth_stream(hb * bs, 1, shard * n_samples - hb * bs, prev + pk[:1], wl["chip"], threads, uniform=uniform)
         else:
             head = iq[:0]
         nh = head.size // bs2
@@ -85,8 +85,8 @@ def golden_for(spec: str, shard: int, n_blocks: int = 0, threads: int = 0) -> di
     return out
 
 
-def key(spec: str, n_blocks: int, shard: int) -> str:
-    return f"{spec}|blocks={n_blocks}|shard={shard}"
+def key(spec: str, n_blocks: int, shard: int, uniform: bool = False) -> str:
+    return f"{spec}|blocks={n_blocks}|shard={shard}" + ("|data=uniform" if uniform else "")
 
 
 def main():
@@ -95,6 +95,7 @@ def main():
     ap.add_argument("--shards", nargs="*", type=int, default=list(range(8)))
     ap.add_argument("--blocks", type=int, default=0, help="blocks per shard (default: the workload's size)")
     ap.add_argument("--threads", type=int, default=0)
+    ap.add_argument("--uniform", action="store_true", help="bench.py --data uniform: uniform random bytes, nothing planted")
     args = ap.parse_args()
     try:
         gold = json.load(open(OUT))
@@ -108,8 +109,9 @@ def main():
         nb = args.blocks or wl["nbytes"] // probe.geom.block_size2
         for shard in args.shards:
             t0 = time.time()
-            gold[key(wl["name"], nb, shard)] = golden_for(spec, shard, nb, args.threads)
-            print(f"{key(wl['name'], nb, shard)}: {gold[key(wl['name'], nb, shard)]['first']['n_hits']} hits "
+            k = key(wl["name"], nb, shard, args.uniform)
+            gold[k] = golden_for(spec, shard, nb, args.threads, args.uniform)
+            print(f"{k}: {gold[k]['first']['n_hits']} hits "
                   f"({time.time() - t0:.1f} s)", flush=True)
             json.dump(gold, open(OUT, "w"), indent=1, sort_keys=True)
 

@@ -141,9 +141,13 @@ def test_device_generator_matches_numpy_twin():
         synth.device_fill(0, d.value, n, 9, first, pk, 72)
         dev = np.empty(2 * n, np.uint8)
         _lib.check(L.amr_dev_download(0, dev.ctypes.data, d, dev.size), "download")
+        synth.device_fill(0, d.value, n, 9, first, [], 72, uniform_bytes=True)     # the second distribution (--data uniform)
+        dev_u = np.empty(2 * n, np.uint8)
+        _lib.check(L.amr_dev_download(0, dev_u.ctypes.data, d, dev_u.size), "download")
     finally:
         L.amr_dev_free(0, d)
     assert np.array_equal(host, dev)
+    assert np.array_equal(synth.uniform(n, seed=9, first_sample=first), dev_u)
 
 
 @pytest.mark.parametrize("protos,chip,n_blocks,npk", [(["scm"], 72, 300, 14), (["idm"], 72, 150, 6),

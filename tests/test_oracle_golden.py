@@ -207,6 +207,12 @@ def test_c_generator_equals_numpy_generator():
         synth.plant(a, pk, chip, first_sample=first)
         b = orc.synth_stream(n, 5, first, pk, chip, n_threads=3)
         assert np.array_equal(a, b)
+    # the second distribution (uniform random bytes, bench.py --data uniform): same twins, and it IS uniform
+    a = synth.uniform(n, 5, first)
+    b = orc.synth_stream(n, 5, first, [], 72, n_threads=3, uniform=True)
+    assert np.array_equal(a, b)
+    hist = np.bincount(a, minlength=256)
+    assert hist.min() > 0.7 * hist.mean() and hist.max() < 1.3 * hist.mean()
 
 
 @pytest.mark.parametrize("protos,chip,n_blocks", [(["scm"], 72, 700), (["idm"], 72, 320),
