@@ -207,6 +207,77 @@ __device__ __forceinline__ void k2w_sweep_set(const K2WRing<K2WGeom<SL, PF>::RC>
     }
 }
 
+// ---- SymbolLength = 16 mod 32: two classes of taps (round 4) ---------------------------------------------------------------
+// Every odd tap then starts at a half word, and the sweeps above form its window with a funnel shift (one more instruction
+// per odd tap and word; shared by the preambles of a set, not by one preamble alone).  Evaluated instead on the position
+// blocks they ARE aligned to -- B-block u = positions [32u + 16, 32u + 48): the window of odd tap P is the plain ring word
+// u + (P*SL >> 5) + 1 -- the odd taps need no shifted windows at all; their mask is shifted back once per word:
+//     M[w] = A[w] & alignbit(B[w-1], B[w], 16)        (A: the even taps on the ordinary blocks)
+// 4 + 4 v_bitop3 and one v_alignbit per word and preamble: 9 instead of 16 for one preamble, 36 instead of 40 for the
+// set of four, and no window temporaries.  One register of carry per preamble (B of the word in front of the group);
+// at the start of a row it is computed from the row's own words (indices x_P >= 0).  k2_row.h uses the same scheme.
+template <int SL>
+constexpr bool k2w_has_half() { return (SL & 31) != 0; }
+
+template <int SL, int PF>
+__device__ __forceinline__ uint32_t k2w_ring_word(const K2WRing<K2WGeom<SL, PF>::RC> &R, int s)
+{
+    const int i = s % K2WGeom<SL, PF>::RW;
+    return R.c[i >> 2][i & 3];
+}
+
+// taps P, P + 2, ... < 16 of one class on ring words base + (tap offset); FOLD: the last instruction also ANDs `extra` in
+template <int SL, int PF, uint32_t BITS, int P, bool FIRST, bool FOLD>
+__device__ __forceinline__ uint32_t k2w_chain(const K2WRing<K2WGeom<SL, PF>::RC> &R, int base, uint32_t acc, uint32_t extra)
+{
+    constexpr int D = kK2WTaps;
+    constexpr int x0 = (P * SL) >> 5, x1 = ((P + 2) * SL) >> 5, x2 = ((P + 4) * SL) >> 5;
+    constexpr uint32_t b0 = (BITS >> P) & 1u, b1 = (BITS >> (P + 2)) & 1u, b2 = (BITS >> (P + 4)) & 1u;
+    if constexpr (FIRST) {
+        constexpr uint32_t tt = 1u << (4 * b0 + 2 * b1 + b2);                       // (x == b0) & (y == b1) & (z == b2)
+        acc = __builtin_amdgcn_bitop3_b32(k2w_ring_word<SL, PF>(R, base + x0), k2w_ring_word<SL, PF>(R, base + x1),
+                                          k2w_ring_word<SL, PF>(R, base + x2), tt);
+        return k2w_chain<SL, PF, BITS, P + 6, false, FOLD>(R, base, acc, extra);
+    } else if constexpr (P + 2 < D) {                                             // x & (y == b0) & (z == b1)
+        constexpr uint32_t tt = 1u << (4 + 2 * b0 + b1);
+        acc = __builtin_amdgcn_bitop3_b32(acc, k2w_ring_word<SL, PF>(R, base + x0), k2w_ring_word<SL, PF>(R, base + x1), tt);
+        return k2w_chain<SL, PF, BITS, P + 4, false, FOLD>(R, base, acc, extra);
+    } else {                                                                      // the last tap of the class alone
+        static_assert(P < D, "eight taps per class");
+        if constexpr (FOLD) {                                                     // x & (y == b0) & z
+            constexpr uint32_t tt = 1u << (4 + 2 * b0 + 1);
+            return __builtin_amdgcn_bitop3_b32(acc, k2w_ring_word<SL, PF>(R, base + x0), extra, tt);
+        } else {                                                                  // x & (y == b0)
+            constexpr uint32_t tt = (1u << (4 + 2 * b0)) | (1u << (4 + 2 * b0 + 1));
+            const uint32_t W = k2w_ring_word<SL, PF>(R, base + x0);
+            return __builtin_amdgcn_bitop3_b32(acc, W, W, tt);
+        }
+    }
+}
+
+// one preamble, the four words of group GG; Bc: class-B mask of the word in front of the group (in / out)
+template <int SL, int PF, int GG, uint32_t BITS>
+__device__ __forceinline__ void k2w_sweep_ab(const K2WRing<K2WGeom<SL, PF>::RC> &R, uint32_t (&M)[4], uint32_t &Bc)
+{
+    uint32_t B[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) B[j] = k2w_chain<SL, PF, BITS, 1, true, false>(R, GG * 4 + j + 1, 0u, 0u);
+    asm volatile("" : "+v"(B[0]), "+v"(B[1]), "+v"(B[2]), "+v"(B[3]));
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const uint32_t Bs = __builtin_amdgcn_alignbit(j ? B[j - 1] : Bc, B[j], 16);
+        M[j] = k2w_chain<SL, PF, BITS, 0, true, true>(R, GG * 4 + j, 0u, Bs);
+    }
+    Bc = B[3];
+}
+
+// class-B mask of the B-block in front of word 0 of a row: own-row words only (ring slots x_P, filled before the walk)
+template <int SL, int PF, uint32_t BITS>
+__device__ __forceinline__ uint32_t k2w_b_first(const K2WRing<K2WGeom<SL, PF>::RC> &R)
+{
+    return k2w_chain<SL, PF, BITS, 1, true, false>(R, 0, 0u, 0u);
+}
+
 // record the non-zero masks of one group and preamble (rare path)
 __device__ __forceinline__ void k2w_record(const uint32_t (&M)[4], uint32_t q, uint32_t g, uint32_t w_lo, uint32_t w_hi, uint32_t lane,
                                            uint32_t *mylist, uint32_t &list_n)
@@ -230,11 +301,12 @@ __device__ __forceinline__ void k2w_record(const uint32_t (&M)[4], uint32_t q, u
 // one known preamble (KIND, present in the launch's SET) on the four words of group GG
 template <int SL, int PF, int GG, int SET, int KIND>
 __device__ __forceinline__ void k2w_kind(const K2WRing<K2WGeom<SL, PF>::RC> &R, uint32_t pids, uint32_t g, uint32_t w_lo, uint32_t w_hi,
-                                         uint32_t lane, uint32_t *mylist, uint32_t &list_n)
+                                         uint32_t lane, uint32_t *mylist, uint32_t &list_n, uint32_t (&Bc)[4])
 {
     if constexpr ((SET >> KIND) & 1) {
         uint32_t M[4];
-        k2w_sweep<SL, PF, GG, kK2WKnown[KIND]>(R, M);
+        if constexpr (k2w_has_half<SL>()) k2w_sweep_ab<SL, PF, GG, kK2WKnown[KIND]>(R, M, Bc[KIND]);
+        else k2w_sweep<SL, PF, GG, kK2WKnown[KIND]>(R, M);
         if (__ballot((M[0] | M[1] | M[2] | M[3]) != 0))                 // rare
             k2w_record(M, (pids >> (8 * KIND)) & 0xffu, g, w_lo, w_hi, lane, mylist, list_n);
     }
@@ -249,24 +321,30 @@ __device__ __forceinline__ void k2w_kind(const K2WRing<K2WGeom<SL, PF>::RC> &R, 
 template <int SL, int PF, int SET, int GG>
 __device__ __forceinline__ void k2w_groups(K2WRing<K2WGeom<SL, PF>::RC> &R, const K2WCtx &cx, uint32_t g0, uint32_t n_groups,
                                            uint32_t pids, uint32_t w_lo, uint32_t w_hi,
-                                           uint32_t lane, uint32_t *mylist, uint32_t &list_n)
+                                           uint32_t lane, uint32_t *mylist, uint32_t &list_n, uint32_t (&Bc)[4])
 {
     using G = K2WGeom<SL, PF>;
     if constexpr (GG < G::RC) {
         const uint32_t g = g0 + GG;
         if (g >= n_groups) return;                                  // wave-uniform
         if constexpr ((SET & (SET - 1)) == 0) {                     // one preamble
-            k2w_kind<SL, PF, GG, SET, 0>(R, pids, g, w_lo, w_hi, lane, mylist, list_n);
-            k2w_kind<SL, PF, GG, SET, 1>(R, pids, g, w_lo, w_hi, lane, mylist, list_n);
-            k2w_kind<SL, PF, GG, SET, 2>(R, pids, g, w_lo, w_hi, lane, mylist, list_n);
-            k2w_kind<SL, PF, GG, SET, 3>(R, pids, g, w_lo, w_hi, lane, mylist, list_n);
+            k2w_kind<SL, PF, GG, SET, 0>(R, pids, g, w_lo, w_hi, lane, mylist, list_n, Bc);
+            k2w_kind<SL, PF, GG, SET, 1>(R, pids, g, w_lo, w_hi, lane, mylist, list_n, Bc);
+            k2w_kind<SL, PF, GG, SET, 2>(R, pids, g, w_lo, w_hi, lane, mylist, list_n, Bc);
+            k2w_kind<SL, PF, GG, SET, 3>(R, pids, g, w_lo, w_hi, lane, mylist, list_n, Bc);
         } else {                                                    // several: tap-major (k2w_sweep_set)
             uint32_t M[4][4];
 #pragma unroll
             for (int k = 0; k < 4; ++k)
 #pragma unroll
                 for (int j = 0; j < 4; ++j) M[k][j] = 0;
-            k2w_sweep_set<SL, PF, GG, SET, 0>(R, M);
+            if constexpr (k2w_has_half<SL>()) {      // preamble after preamble: the classes leave nothing to share between them
+                if constexpr (SET & 1) { k2w_sweep_ab<SL, PF, GG, kK2WKnown[0]>(R, M[0], Bc[0]); asm volatile("" : "+v"(M[0][0]), "+v"(M[0][1]), "+v"(M[0][2]), "+v"(M[0][3])); }
+                if constexpr (SET & 2) { k2w_sweep_ab<SL, PF, GG, kK2WKnown[1]>(R, M[1], Bc[1]); asm volatile("" : "+v"(M[1][0]), "+v"(M[1][1]), "+v"(M[1][2]), "+v"(M[1][3])); }
+                if constexpr (SET & 4) { k2w_sweep_ab<SL, PF, GG, kK2WKnown[2]>(R, M[2], Bc[2]); asm volatile("" : "+v"(M[2][0]), "+v"(M[2][1]), "+v"(M[2][2]), "+v"(M[2][3])); }
+                if constexpr (SET & 8) { k2w_sweep_ab<SL, PF, GG, kK2WKnown[3]>(R, M[3], Bc[3]); }
+            } else
+                k2w_sweep_set<SL, PF, GG, SET, 0>(R, M);
 #pragma unroll
             for (int k = 0; k < 4; ++k)
                 if (((SET >> k) & 1) && __ballot((M[k][0] | M[k][1] | M[k][2] | M[k][3]) != 0))   // rare
@@ -276,7 +354,7 @@ __device__ __forceinline__ void k2w_groups(K2WRing<K2WGeom<SL, PF>::RC> &R, cons
         // inside a branch makes the compiler's waitcnt pass give up counting and wait for ALL loads in flight at every
         // group (vmcnt(0): 64 exposed memory latencies per row walk)
         k2w_load<G::RC>(R, cx, GG, g + G::RC);
-        k2w_groups<SL, PF, SET, GG + 1>(R, cx, g0, n_groups, pids, w_lo, w_hi, lane, mylist, list_n);
+        k2w_groups<SL, PF, SET, GG + 1>(R, cx, g0, n_groups, pids, w_lo, w_hi, lane, mylist, list_n, Bc);
     }
 }
 
@@ -366,8 +444,15 @@ __global__ __launch_bounds__(64 * kK2WWaves) void k2_search_walk(const K2Args a)
     K2WRing<G::RC> R;
     k2w_fill<G::RC, 0>(R, cx, n_chunks);
     uint32_t list_n = 0;                                             // wave-uniform
+    uint32_t Bc[4] = {0u, 0u, 0u, 0u};                               // class-B carries (SymbolLength = 16 mod 32), per kind
+    if constexpr (k2w_has_half<SL>()) {
+        if constexpr (SET & 1) Bc[0] = k2w_b_first<SL, PF, kK2WKnown[0]>(R);
+        if constexpr (SET & 2) Bc[1] = k2w_b_first<SL, PF, kK2WKnown[1]>(R);
+        if constexpr (SET & 4) Bc[2] = k2w_b_first<SL, PF, kK2WKnown[2]>(R);
+        if constexpr (SET & 8) Bc[3] = k2w_b_first<SL, PF, kK2WKnown[3]>(R);
+    }
     for (uint32_t g0 = 0; g0 < cpr; g0 += G::RC)
-        k2w_groups<SL, PF, SET, 0>(R, cx, g0, cpr, a.walk_pids, w_lo, w_hi, lane, mylist, list_n);
+        k2w_groups<SL, PF, SET, 0>(R, cx, g0, cpr, a.walk_pids, w_lo, w_hi, lane, mylist, list_n, Bc);
     K2W_STAMP(1);
 
     // ---- stage 2: the taps behind the first 16 on the list entries (one per lane), words from memory; compaction in place ----

@@ -15,7 +15,7 @@ dst = os.path.join(root, 'profiles', tag)
 os.makedirs(dst, exist_ok=True)
 for w in ('cfg2', 'cfg3', 'cfg5'):
     summary = collections.defaultdict(dict)
-    for sub in ('pmc_fetch', 'pmc_write', 'pmc_sq_a', 'pmc_sq_b'):
+    for sub in ('pmc_fetch', 'pmc_write', 'pmc_sq_a', 'pmc_sq_b'):   # (round 4: the PMC passes run bench.py --depth 1)
         agg = collections.defaultdict(lambda: collections.defaultdict(list))
         for f in glob.glob(os.path.join(src, w, sub, '**', '*counter_collection.csv'), recursive=True):
             for r in csv.DictReader(open(f)):
@@ -39,11 +39,19 @@ for w in ('cfg2', 'cfg3', 'cfg5'):
                    'profile': f'profiles/{tag}/pmc_summary_cfg2.json', 'tag': tag}
             json.dump(out, open(os.path.join(root, 'profiles', 'k1_hbm_traffic.json'), 'w'), indent=1)
             print(json.dumps(out))
+# round 4: the LDS counters of K1 on the second input distribution (uniform random bytes) next to the synthetic noise
+uni = collections.defaultdict(lambda: collections.defaultdict(list))
+for f in glob.glob(os.path.join(src, 'uniform', 'pmc_sq_b', '**', '*counter_collection.csv'), recursive=True):
+    for r in csv.DictReader(open(f)):
+        uni[r['Kernel_Name'].split('(')[0]][r['Counter_Name']].append(float(r['Counter_Value']))
+if uni:
+    json.dump({k: {c: {'mean': sum(v) / len(v), 'launches': len(v)} for c, v in cs.items()} for k, cs in uni.items()},
+              open(os.path.join(dst, 'pmc_summary_cfg2_uniform.json'), 'w'), indent=1, sort_keys=True)
 for p in glob.glob(os.path.join(src, 'bench_*.log')):
     lines = [l for l in open(p) if l.startswith('{')]
     if lines:
         open(os.path.join(dst, os.path.basename(p).replace('.log', '.json')), 'w').write(lines[-1])
-for name in ('fresh_runs.txt', 'single_block.txt'):
+for name in ('fresh_runs.txt', 'single_block.txt', 'timeline_cfg2.txt', 'timeline_cfg5.txt', 'bench_gpus2_refusal.txt'):
     if os.path.exists(os.path.join(src, name)):
         shutil.copy(os.path.join(src, name), os.path.join(dst, name))
 for w in ('cfg2', 'cfg3', 'cfg5'):
