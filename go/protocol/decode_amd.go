@@ -27,6 +27,7 @@ package protocol
 import "C"
 
 import (
+	"fmt"
 	"log"
 	"math"
 	"os"
@@ -156,8 +157,21 @@ func (d *Decoder) RegisterProtocol(p Parser) {
 	}
 }
 
+// DeviceError is what a failed library call panics with.  The reference's Decoder API has no error returns (its only
+// failure, a short block, is a runtime panic: decode.go:222), so the binding keeps the signatures and panics too -- with
+// a typed value a library caller can recover() and inspect, instead of ending the process (main.go, a CLI, simply lets
+// it propagate: same exit as log.Fatalf, with a stack).
+type DeviceError struct {
+	Call   string // the C entry point
+	Status int    // amr_status (include/amrdemod.h): AMR_EINVAL -1, AMR_ENOMEM -2, AMR_EHIP -3, AMR_ENODEV -4, AMR_EOVERFLOW -5
+	Text   string // amr_strerror + amr_last_error
+}
+
+func (e *DeviceError) Error() string { return fmt.Sprintf("%s: status %d: %s", e.Call, e.Status, e.Text) }
+
 func fatal(what string, st C.amr_status) {
-	log.Fatalf("%s: %s: %s", what, C.GoString(C.amr_strerror(st)), C.GoString(C.amr_last_error()))
+	panic(&DeviceError{Call: what, Status: int(st),
+		Text: C.GoString(C.amr_strerror(st)) + ": " + C.GoString(C.amr_last_error())})
 }
 
 // Allocate: decode.go:131-160.  The geometry comes back from the library, which
