@@ -38,6 +38,33 @@ __global__ __launch_bounds__(64) void k(float *out, const float *in, int tiles, 
                 s += mi;
                 p = lane == i ? s : p;
             }
+        } else if (MODE == 5) {   // round 4: every lane runs the SAME chain on scalar operands (64 readlanes up front), the running
+                                  // sum goes to LDS step by step (all lanes store the same dword) -- the filter phase reads sums from LDS anyway
+            __shared__ float ring5[64];
+            int ms[64];
+#pragma unroll
+            for (int i = 0; i < 64; ++i) ms[i] = __builtin_amdgcn_readlane(__float_as_int(m), i);
+            p = carry;
+#pragma unroll
+            for (int i = 0; i < 64; ++i) {
+                asm volatile("v_add_f32 %0, %1, %0" : "+v"(p) : "s"(ms[i]));
+                asm volatile("ds_write_b32 %0, %1 offset:%2" :: "v"(0), "v"(p), "n"(i * 4) : "memory");
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            p = ring5[lane];      // lane i: prefix i (what the DPP chain leaves in the register)
+        } else if (MODE == 6) {   // as 5, readlane and add interleaved (the readlane of step i+1 issues behind the add of step i)
+            __shared__ float ring6[64];
+            p = carry;
+            int mi = __builtin_amdgcn_readlane(__float_as_int(m), 0);
+#pragma unroll
+            for (int i = 0; i < 64; ++i) {
+                const int mn = __builtin_amdgcn_readlane(__float_as_int(m), i < 63 ? i + 1 : 63);
+                asm volatile("v_add_f32 %0, %1, %0" : "+v"(p) : "s"(mi));
+                asm volatile("ds_write_b32 %0, %1 offset:%2" :: "v"(0), "v"(p), "n"(i * 4) : "memory");
+                mi = mn;
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            p = ring6[lane];
         } else {                  // plain dependent adds (lower bound)
             p = carry;
 #pragma unroll
@@ -69,5 +96,7 @@ int main()
     run<1>("v_add_dpp row_shr:1 + s_nop 1 (timing)");
     run<2>("readlane + v_add under shrinking exec");
     run<3>("readlane + v_add + cndmask");
+    run<5>("64 readlanes, then uniform v_add(sgpr) + ds_write per step");
+    run<6>("readlane / v_add(sgpr) / ds_write interleaved");
     return 0;
 }
