@@ -3,7 +3,7 @@
 # driver's command), cfg3 and cfg5, PMC passes (at --depth 1: with counters the profiler runs one kernel at a time, and
 # the gate kernel of the pipelined tail would wait out its time-out for a K1 that cannot start beside it), the kernel
 # timeline of the pipelined bench, then the unprofiled bench lines of every workload, all on ONE box in one call.
-# Raw output under gpurun_out/prof_<tag>/; tools/summarise_r03.py <tag> turns it into profiles/<tag>/.
+# Raw output under gpurun_out/prof_<tag>/; tools/summarise_profiles.py <tag> turns it into profiles/<tag>/.
 TAG=${1:-r04}
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/prof_$TAG; rm -rf $O; mkdir -p $O
