@@ -372,8 +372,9 @@ amr_status enqueue_k2(amr_handle *h, Slot &s, hipStream_t st, bool rerun, bool d
         const uint32_t n_wg = (s.n_tiles + amr::kK2WWaves - 1) / amr::kK2WWaves + extra;
         const uint32_t grid = 8u * ((n_wg + 7u) / 8u);   // XCD-contiguous tile order: 8 equal runs
         const size_t lds = amr::k2_walk_lds_bytes(h->hist_rows * h->sg.wpb);
-        // one preamble, rows of up to 128 words: the whole row in registers, the look-ahead from the neighbour lane (k2_row.h)
-        walk_ok = (n_pre == 1 && amr::launch_k2_row(h->sg.symbol_length, (uint32_t)last_kind, grid, lds, st, k2start, k2stop, k2, &le)) ||
+        // one preamble: the whole row in registers (rows of 256 words: two lanes per row), the look-ahead from the
+        // neighbour lane (k2_row.h); it sizes its own grid (one or two waves per tile) around the `extra` workgroups
+        walk_ok = (n_pre == 1 && amr::launch_k2_row(h->sg.symbol_length, (uint32_t)last_kind, extra, lds, st, k2start, k2stop, k2, &le)) ||
                   amr::launch_k2_walk(h->sg.symbol_length, walk_set, grid, lds, st, k2start, k2stop, k2, &le);
     }
     // fallbacks: the list-based kernel splits a row's words over 4 or 8 waves, 4 or 8 words per step: rows of fewer
@@ -1057,6 +1058,17 @@ amr_status amr_destroy(amr_handle *h)
 {
     if (!h) return AMR_OK;
     (void)hipSetDevice(h->device);
+#if AMR_GATE_CLK
+    {   // diagnostic build: shader clock seen by the gate kernels (they sleep through the first rounds of the following K1)
+        (void)hipDeviceSynchronize();
+        static unsigned long long hc[4096];
+        if (hipMemcpyFromSymbol(hc, HIP_SYMBOL(amr::k_gate_clk), sizeof hc) == hipSuccess) {
+            double cyc = 0, tick = 0; int n = 0;
+            for (int i = 0; i < 2048; ++i) if (hc[2 * i + 1] > 1000) { cyc += (double)hc[2 * i]; tick += (double)hc[2 * i + 1]; ++n; }
+            if (n) fprintf(stderr, "AMR_GATE_CLK: %d gates, mean wait %.1f us, shader clock while waiting %.3f GHz\n", n, tick / n * 0.01, cyc / tick * 0.1);
+        }
+    }
+#endif
     // the communicator first: its stream may still hold a pack kernel that reads the slots' result buffers
     if (h->comm) (void)amr_comm_destroy(h);
     if (h->stream) (void)hipStreamSynchronize(h->stream);

@@ -23,6 +23,10 @@
 #pragma once
 #include "k2_walk.h"
 
+#ifndef AMR_K2R_WPE
+#define AMR_K2R_WPE 3      // waves per SIMD the register allocation aims at
+#endif
+
 namespace amr {
 
 // Taps the sweep applies to every position: all of the preamble when its reach still fits the row-as-ring scheme (scm: 21
@@ -58,11 +62,26 @@ constexpr int k2r_wpb()
     while (bs < pl) bs <<= 1;
     return (int)(bs / 32);
 }
+// lanes a row is split over: 1 up to 128 words (0: no row kernel for this geometry).  Rows of 256 words (idm / netidm /
+// r900 alone at chip length 72 .. 96) run as TWO lanes per row in the harness only (AMR_K2R_LPR2, tools/k2_bench.hip):
+// the kernel is bit-identical to the walk and 20 % faster on its own (idm, 4 GiB: 64.0 -> 51.4 us), but in the pipelined
+// product the FIRST of the two K1 rounds behind it then takes 500 us instead of 390 (shader clock unchanged; not at
+// --depth 1, not with one-round batches: profiles/r04/k2_row2_cfg3.txt) and cfg3 loses 7 %.  Not understood; not used.
+#ifndef AMR_K2R_LPR2
+#define AMR_K2R_LPR2 0
+#endif
+template <int SL, int KIND>
+constexpr int k2r_lpr()
+{
+    constexpr int w = k2r_wpb<SL, KIND>();
+    return (w == 16 || w == 32 || w == 64 || w == 128) ? 1 : (w == 256 && AMR_K2R_LPR2) ? 2 : 0;
+}
 template <int SL, int KIND>
 constexpr bool k2r_ok()
 {
-    constexpr int w = k2r_wpb<SL, KIND>();
-    return (w == 16 || w == 32 || w == 64 || w == 128) && (((kK2WTaps - 1) * SL) >> 5) + 4 < w;
+    constexpr int lpr = k2r_lpr<SL, KIND>();
+    if (lpr == 0) return false;
+    return (((kK2WTaps - 1) * SL) >> 5) + 4 < k2r_wpb<SL, KIND>() / lpr;
 }
 
 // ---- the sweep: sixteen taps on the four words of group GG ------------------------------------------------------------
@@ -215,17 +234,27 @@ __device__ __forceinline__ void k2r_groups(K2WRing<WPB / 4> &R, k2w_v4u &X, uint
     }
 }
 
-template <int SL, int KIND, int WPB>
-__global__ __launch_bounds__(64 * kK2WWaves, 3) void k2_search_row(const K2Args a)
+// LPR: lanes per row.  1: a lane holds a whole row of WPB words (rows of up to 128 words).  2 (round 4, rows of 256
+// words: idm / netidm / r900 alone at chip lengths 72 .. 96): a row is split over TWO NEIGHBOURING lanes, WPB = 128 words
+// each -- lane 2r takes the first half of row r, lane 2r + 1 the second, so the stream of every lane still continues in
+// the lane above it and the in-place shift works unchanged; a wave then covers 32 rows, two waves a tile (they sit in
+// one workgroup and meet once, for the second wave's rank offset inside the tile's staging slot).  A wave-load of chunk k
+// touches the two chunks k and k + 32 of the tile, 512 contiguous bytes of each.
+template <int SL, int KIND, int WPB, int LPR = 1>
+__global__ __launch_bounds__(64 * kK2WWaves, AMR_K2R_WPE) void k2_search_row(const K2Args a)
 {
     constexpr int D = k2r_taps<SL, KIND, WPB>();
     using G = K2RGeom<SL, WPB, D>;
     constexpr int LG_WPB = WPB == 16 ? 4 : WPB == 32 ? 5 : WPB == 64 ? 6 : 7;
-    static_assert(WPB == 16 || WPB == 32 || WPB == 64 || WPB == 128, "rows of 16, 32, 64 or 128 words");
+    static_assert(WPB == 16 || WPB == 32 || WPB == 64 || WPB == 128, "16, 32, 64 or 128 words per lane");
+    static_assert(LPR == 1 || (LPR == 2 && WPB == 128), "two lanes per row: rows of 256 words");
+    constexpr int LG_LPR = LPR == 2 ? 1 : 0;
+    constexpr int RPW = 64 / LPR;                                    // rows per wave
+    constexpr uint32_t lg_rw = LG_WPB + LG_LPR, rw = (uint32_t)WPB * LPR;   // words per ROW
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
     // workgroup b runs on XCD b % 8: every XCD gets one contiguous run of tiles (the grid is rounded up to 8 equal runs)
     const uint32_t wgT = (blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3);
-    const uint32_t n_wg = (a.n_tiles + kK2WWaves - 1) / kK2WWaves;      // workgroups that search
+    const uint32_t n_wg = (a.n_tiles * LPR + kK2WWaves - 1) / kK2WWaves;   // workgroups that search
     k2_announce(a);
     if (wgT >= n_wg) {
         (void)k2_extra_workgroup(a, a.n_tiles + (wgT - n_wg), lds, 64 * kK2WWaves);   // state update / deferred-block copies
@@ -233,45 +262,51 @@ __global__ __launch_bounds__(64 * kK2WWaves, 3) void k2_search_row(const K2Args 
     }
     const uint32_t tid = threadIdx.x, lane = tid & 63;
     const uint32_t v = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const uint32_t T = wgT * kK2WWaves + v;
-    if (T >= a.n_tiles) return;                                      // the last workgroup may hold fewer tiles (no barrier below)
+    const uint32_t wave = wgT * kK2WWaves + v;
+    const uint32_t T = wave >> LG_LPR, h2 = wave & (LPR - 1);        // tile; which RPW rows of it
+    const bool active = T < a.n_tiles;                               // wave-uniform
+    if (LPR == 1 && !active) return;                                 // (LPR 2: the waves of a workgroup meet at a barrier below)
+    uint32_t *mylist = lds + v * (kK2WList * 2 + 2 * 4 * 64);        // [kK2WList][2]
+    uint32_t *cnts = mylist + kK2WList * 2;                          // [64] hits per lane-row (one preamble)
+    uint32_t *bases = cnts + 4 * 64;                                 // [64]
+    uint32_t *wtot = lds + kK2WList * 2 + 64;                        // [kK2WWaves] hits per wave (LPR 2; unused words of wave 0's counts)
+    const uint32_t lg_bs = lg_rw + 5;
+    constexpr uint32_t tile_words = 64u << (LG_WPB + LG_LPR);
+    uint32_t total = 0, list_n = 0, n_keep = 0;                      // wave-uniform
+    const uint32_t rt = RPW * h2 + (lane >> LG_LPR), hl = lane & (LPR - 1);   // this lane: row of the tile, part of the row
+    const uint32_t *tw = a.qt + (size_t)T * tile_words;
+    if (active) {
 #if AMR_K2W_DBG
-    if (a.dbg && lane == 0) a.dbg[(size_t)T * 16 + 8] = __builtin_amdgcn_s_memrealtime();
+    if (a.dbg && lane == 0 && h2 == 0) a.dbg[(size_t)T * 16 + 8] = __builtin_amdgcn_s_memrealtime();
 #endif
     K2W_STAMP(0);
-    constexpr uint32_t wpb = WPB, lg_wpb = LG_WPB;
-    const uint32_t lg_bs = lg_wpb + 5;
-    constexpr uint32_t tile_words = 64u << LG_WPB;
 
-    // ---- the row, all of it, and the head of row 0 of the next tile (lane c: its chunk c) ----
-    const uint8_t *tile = reinterpret_cast<const uint8_t *>(a.qt + (size_t)T * tile_words);
+    // ---- the lane's words, all of them, and the head of what follows lane 63 (lane c: its chunk c) ----
+    const uint8_t *tile = reinterpret_cast<const uint8_t *>(tw);
     K2WRing<G::CPR> R;
     k2w_v4u X;
     {   // X first (the first shift needs it: in-order retirement then never waits for more than its own chunks);
-        // lanes beyond NLA read chunk NLA-1 again (a valid address, never used)
+        // lanes beyond NLA read chunk NLA-1 again (a valid address, never used).  Lane 63's stream continues in the row
+        // behind the wave's last one: row RPW (h2 + 1) of this tile, or row 0 of the next tile
         const uint32_t xoff = (lane < (uint32_t)G::NLA ? lane : (uint32_t)G::NLA - 1) * 1024;
-        const uint8_t *next = tile + (size_t)tile_words * 4;
+        const uint8_t *next = (h2 + 1 < (uint32_t)LPR) ? tile + (size_t)RPW * (h2 + 1) * 16 : tile + (size_t)tile_words * 4;
         asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(X) : "v"(xoff), "s"(next) : "memory");
     }
-    k2r_fill<G::CPR, 0>(R, tile, lane * 16);
+    k2r_fill<G::CPR, 0>(R, tile, (uint32_t)G::CPR * hl * 1024u + rt * 16u);
 
-    uint32_t *mylist = lds + v * (kK2WList * 2 + 2 * 4 * 64);        // [kK2WList][2]
-    uint32_t *cnts = mylist + kK2WList * 2;                          // [64] hits per row (one preamble)
-    uint32_t *bases = cnts + 4 * 64;                                 // [64]
     cnts[lane] = 0;
 
-    // ---- the preamble (the taps behind the sixteenth, stage 2, take their bits from the geometry) ----
+    // ---- the preamble (the taps behind the D-th, stage 2, take their bits from the geometry) ----
     const uint64_t pb = a.g.pre_bits[0];
     const uint32_t pl = a.g.pre_len[0];
 
-    // ---- valid word range of this lane's row: n_lo <= R*BS + 32w < n_hi ----
-    const int64_t rowbase = ((int64_t)T * 64 + lane - 64) << lg_bs;
-    int64_t lo64 = (a.n_lo - rowbase) >> 5, hi64 = (a.n_hi - rowbase) >> 5;
-    const uint32_t w_lo = (uint32_t)(lo64 < 0 ? 0 : lo64 > (int64_t)wpb ? wpb : lo64);
-    const uint32_t w_hi = (uint32_t)(hi64 < 0 ? 0 : hi64 > (int64_t)wpb ? wpb : hi64);
+    // ---- valid word range of this lane: n_lo <= R*BS + 32 (row word) < n_hi, row word = WPB * hl + w ----
+    const int64_t rowbase = ((int64_t)T * 64 + rt - 64) << lg_bs;
+    int64_t lo64 = ((a.n_lo - rowbase) >> 5) - (int64_t)(WPB * hl), hi64 = ((a.n_hi - rowbase) >> 5) - (int64_t)(WPB * hl);
+    const uint32_t w_lo = (uint32_t)(lo64 < 0 ? 0 : lo64 > (int64_t)WPB ? WPB : lo64);
+    const uint32_t w_hi = (uint32_t)(hi64 < 0 ? 0 : hi64 > (int64_t)WPB ? WPB : hi64);
 
-    // ---- stage 1: D taps on every position of the row ----
-    uint32_t list_n = 0;                                             // wave-uniform
+    // ---- stage 1: D taps on every position of the lane's words ----
     uint32_t Bc = 0;
     k2r_groups<SL, WPB, KIND, D, 0>(R, X, 0u, w_lo, w_hi, lane, mylist, list_n, Bc);
     K2W_STAMP(1);
@@ -279,14 +314,13 @@ __global__ __launch_bounds__(64 * kK2WWaves, 3) void k2_search_row(const K2Args 
     // ---- stage 2: the taps behind the first D on the list entries (one per lane), words from memory, eight taps (sixteen
     // loads) in flight per round; compaction in place.  Nothing to do when the sweep applied the whole preamble (scm, scm+)
     const uint32_t n_cand = list_n < (uint32_t)kK2WList ? list_n : (uint32_t)kK2WList;
-    uint32_t n_keep = 0;                                             // wave-uniform
-    const uint32_t *tw = a.qt + (size_t)T * tile_words;
     const uint32_t maxL = pl;
     for (uint32_t e0 = 0; e0 < n_cand; e0 += 64) {
         const uint32_t e = e0 + lane;
         uint32_t key = 0, m = 0;
         if (e < n_cand) { key = mylist[e * 2]; m = mylist[e * 2 + 1]; }
-        const uint32_t l = (key >> 8) & 63, w = key & 0xff;
+        const uint32_t kl = (key >> 8) & 63;                         // the lane that found it
+        const uint32_t l = RPW * h2 + (kl >> LG_LPR), w = (uint32_t)WPB * (kl & (LPR - 1)) + (key & 0xff);   // row of the tile, row word
         if constexpr (D < (int)kK2WKnownLen[KIND]) {
             for (uint32_t p = D; p < maxL; p += 8) {
                 if (!__any(m != 0)) break;
@@ -296,9 +330,9 @@ __global__ __launch_bounds__(64 * kK2WWaves, 3) void k2_search_row(const K2Args 
                     const uint32_t pk = p + k < maxL ? p + k : maxL - 1;
                     const uint32_t o = pk * SL;
                     const uint32_t x = w + (o >> 5);
-                    // word x of the stream that starts with row l of this tile: tiled row l + x / wpb (may be row 0 of the next tile)
-                    const uint32_t A = tw[qt_index(l + (x >> lg_wpb), x & (wpb - 1), lg_wpb)];
-                    const uint32_t B = tw[qt_index(l + ((x + 1) >> lg_wpb), (x + 1) & (wpb - 1), lg_wpb)];
+                    // word x of the stream that starts with row l of this tile: tiled row l + x / rw (may be row 0 of the next tile)
+                    const uint32_t A = tw[qt_index(l + (x >> lg_rw), x & (rw - 1), lg_rw)];
+                    const uint32_t B = tw[qt_index(l + ((x + 1) >> lg_rw), (x + 1) & (rw - 1), lg_rw)];
                     Wd[k] = (o & 31) ? __builtin_amdgcn_alignbit(A, B, 16) : A;
                 }
 #pragma unroll
@@ -311,31 +345,42 @@ __global__ __launch_bounds__(64 * kK2WWaves, 3) void k2_search_row(const K2Args 
             const uint32_t slot = n_keep + __builtin_amdgcn_mbcnt_hi((uint32_t)(b >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)b, 0));
             mylist[slot * 2] = key;
             mylist[slot * 2 + 1] = m;
-            atomicAdd(&cnts[l], (uint32_t)__popc(m));
+            atomicAdd(&cnts[kl], (uint32_t)__popc(m));
         }
         n_keep += __popcll(b);
     }
     K2W_STAMP(2);
 
-    // ---- ranks: exclusive scan over the rows in stream order (row-major: all of row l before row l+1) ----
+    // ---- ranks: exclusive scan over the lanes in stream order (lane-major = row-major: all of a row before the next) ----
     const uint32_t val = cnts[lane];
     const uint32_t inc = k2w_wave_scan(val);
-    const uint32_t total = __builtin_amdgcn_readlane(inc, 63);
+    total = __builtin_amdgcn_readlane(inc, 63);
     bases[lane] = inc - val;
+    }   // active
 
-    // ---- emit.  The list is in walk order: word-major across the rows, ascending words inside a row, so the slot of an
-    // entry = the hits of the rows in front of its row + the hits of the earlier entries of its own row.  Sixty-four
+    // ---- two waves per tile: the second one's hits come behind the first one's in the tile's staging slot ----
+    uint32_t tile_base = 0, tile_total = total;
+    if constexpr (LPR > 1) {
+        if (lane == 0) wtot[v] = active ? total : 0u;
+        __syncthreads();
+        if (!active) return;
+        tile_base = h2 ? wtot[v - 1] : 0u;
+        tile_total = wtot[v & ~1u] + wtot[v | 1u];
+    }
+
+    // ---- emit.  The list is in walk order: word-major across the lanes, ascending words inside a lane, so the slot of an
+    // entry = the hits of the lanes in front of its lane + the hits of the earlier entries of its own lane.  Sixty-four
     // entries at a time live in registers (lane e = entry e): their slots come out of one pass of v_readlane broadcasts,
     // and the positions of an entry are then written by 32 lanes at once (lane b = bit b, MSB first = stream order) from
     // broadcast values -- no LDS or memory latency inside either loop (k2_walk.h re-reads the list entry by entry: 700
     // cycles per entry; a tile with two packets holds eight).
-    uint32_t run = 0;                                                // lane l: hits of row l emitted by earlier rounds
+    uint32_t run = 0;                                                // lane l: hits of lane-row l emitted by earlier rounds
     for (uint32_t e0 = 0; e0 < n_keep; e0 += 64) {
         const uint32_t e = e0 + lane;
         uint32_t key = 0, m = 0;
         if (e < n_keep) { key = mylist[e * 2]; m = mylist[e * 2 + 1]; }
         const uint32_t l = (key >> 8) & 63, c = (uint32_t)__popc(m);
-        uint32_t slot = bases[l] + (uint32_t)__builtin_amdgcn_ds_bpermute((int)(l << 2), (int)run);
+        uint32_t slot = tile_base + bases[l] + (uint32_t)__builtin_amdgcn_ds_bpermute((int)(l << 2), (int)run);
         const uint32_t n = n_keep - e0 < 64u ? n_keep - e0 : 64u;    // wave-uniform
         uint32_t add = 0;
         for (uint32_t j = 0; j < n; ++j) {
@@ -348,23 +393,27 @@ __global__ __launch_bounds__(64 * kK2WWaves, 3) void k2_search_row(const K2Args 
             const uint32_t sj = (uint32_t)__builtin_amdgcn_readlane((int)slot, (int)j);
             if (lane < 32 && ((mj >> (31 - lane)) & 1)) {
                 const uint32_t rank = sj + (lane ? __popc(mj >> (32 - lane)) : 0);
-                if (rank < a.cap) a.staging[(size_t)T * a.cap + rank] = (((kj >> 8) & 63) << lg_bs) + ((kj & 0xff) << 5) + lane;
+                const uint32_t klj = (kj >> 8) & 63;
+                const uint32_t row = RPW * h2 + (klj >> LG_LPR), wrow = (uint32_t)WPB * (klj & (LPR - 1)) + (kj & 0xff);
+                if (rank < a.cap) a.staging[(size_t)T * a.cap + rank] = (row << lg_bs) + (wrow << 5) + lane;
             }
         }
         run += add;
     }
     K2W_STAMP(3);
 #if AMR_K2W_DBG
-    if (a.dbg && lane == 0) {
-        a.dbg[(size_t)T * 16 + 7] = ((unsigned long long)n_cand << 32) | n_keep;
+    if (a.dbg && lane == 0 && h2 == 0) {
+        a.dbg[(size_t)T * 16 + 7] = ((unsigned long long)list_n << 32) | n_keep;
         a.dbg[(size_t)T * 16 + 9] = __builtin_amdgcn_s_memrealtime();
     }
 #endif
     if (lane == 0) {
-        const uint32_t c = total < a.cap ? total : a.cap;
-        a.counts[T] = c;
-        if (c) atomicAdd(&a.gcnt[T >> 6], c);
-        if (total > a.cap) atomicOr(a.overflow, 1u);
+        if (h2 == 0) {
+            const uint32_t c = tile_total < a.cap ? tile_total : a.cap;
+            a.counts[T] = c;
+            if (c) atomicAdd(&a.gcnt[T >> 6], c);
+            if (tile_total > a.cap) atomicOr(a.overflow, 1u);
+        }
         if (list_n > (uint32_t)kK2WList) atomicOr(a.overflow, 2u);
     }
 }

@@ -345,13 +345,26 @@ __global__ void k_done(uint64_t *flag, uint64_t value, uint64_t *dev_flag)
 // First kernel of a tail that was enqueued AHEAD of time (submit of the following batch): holds the second stream until
 // that batch's K1 has all its waves on the chip (K1Args::started), plus `delay` ticks of the 100 MHz clock for the other
 // XCDs' dispatchers.  One lane; it sleeps between polls and needs no LDS and 8 registers, so it fits next to a full K1.
+#ifndef AMR_GATE_CLK
+#define AMR_GATE_CLK 0      // diagnostic builds: the gate measures the shader clock while it waits (cycles per 100 MHz tick)
+#endif
+#if AMR_GATE_CLK
+__device__ unsigned long long k_gate_clk[4096];
+#endif
 __global__ void k_gate(const uint64_t *flag, uint64_t value, uint32_t delay)
 {
     const uint64_t t0 = __builtin_amdgcn_s_memrealtime();
+#if AMR_GATE_CLK
+    const uint64_t c0 = __builtin_readcyclecounter();
+#endif
     while (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < value &&
            __builtin_amdgcn_s_memrealtime() - t0 < 400000000ull)        // 4 s: a device that lost the K1 launch; the host will see the fault
         __builtin_amdgcn_s_sleep(16);
     const uint64_t t1 = __builtin_amdgcn_s_memrealtime();
+#if AMR_GATE_CLK
+    k_gate_clk[(value & 2047) * 2] = __builtin_readcyclecounter() - c0;
+    k_gate_clk[(value & 2047) * 2 + 1] = t1 - t0;
+#endif
     while (__builtin_amdgcn_s_memrealtime() - t1 < delay) __builtin_amdgcn_s_sleep(8);
 }
 

@@ -20,8 +20,9 @@ bool launch_k1_coop(int chip_length, uint32_t first_block, uint32_t n_blocks, hi
 bool launch_k2_walk(uint32_t symbol_length, uint32_t set, uint32_t grid, size_t lds_bytes, hipStream_t st, hipEvent_t start, hipEvent_t stop,
                     const K2Args &a, hipError_t *err);
 // K2 for ONE of rtlamr's preambles (kind 0..3 of k2_walk_kind_of) with the whole row in registers (k2_row.h): every
-// single-preamble decoder whose rows have 16..128 words.  false: no kernel for this (SymbolLength, kind, row length)
-bool launch_k2_row(uint32_t symbol_length, uint32_t kind, uint32_t grid, size_t lds_bytes, hipStream_t st, hipEvent_t start, hipEvent_t stop,
+// single-preamble decoder whose rows have 16..256 words.  extra_wgs: workgroups behind the searching ones (state update,
+// deferred-block copies).  false: no kernel for this (SymbolLength, kind, row length)
+bool launch_k2_row(uint32_t symbol_length, uint32_t kind, uint32_t extra_wgs, size_t lds_bytes, hipStream_t st, hipEvent_t start, hipEvent_t stop,
                    const K2Args &a, hipError_t *err);
 // which of rtlamr's four preambles (k2_walk.h) a registered preamble is, -1: none
 int k2_walk_kind_of(uint32_t len, uint64_t bits);

@@ -1,7 +1,7 @@
 // K2 harness: k2_search_walk<SL, SET> alone on a random bitstream, with the per-wave phase stamps of AMR_K2W_DBG
 // (developer tool, not product code).  Geometry: scm at chip length 72 by default (rows of 128 words), or "idm" / "all"
 // (rows of 256 words).
-//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -DAMR_K2W_DBG=1 -Irtlamr_amd/csrc -Iinclude -o build/k2b tools/k2_bench.hip
+//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -DAMR_K2W_DBG=1 -DAMR_K2R_LPR2=1 -Irtlamr_amd/csrc -Iinclude -o build/k2b tools/k2_bench.hip
 // usage: k2b [scm|idm|all] [n_tiles incl. the history tile] [reps] [cold]
 // "scm" also runs k2_search_row<144, 0, 128> (k2_row.h) on the same bitstream and compares counts and staging with the walk;
 // cold: a 1 GiB buffer is streamed through the chip in front of every launch (what K1 does to the caches in the product)
@@ -61,7 +61,7 @@ static void cold_pass()
 }
 
 // the row kernel (one preamble, rows of up to 128 words) on the same arguments; compares with what the walk left behind
-template <int SL, int KIND, int WPB>
+template <int SL, int KIND, int WPB, int LPR = 1>
 static void run_row(const char *name, amr::K2Args a, uint32_t n_tiles, int reps, unsigned long long *d_dbg)
 {
     using namespace amr;
@@ -69,10 +69,10 @@ static void run_row(const char *name, amr::K2Args a, uint32_t n_tiles, int reps,
     CK(hipMemcpy(cnt0.data(), a.counts, cnt0.size() * 4, hipMemcpyDeviceToHost));
     CK(hipMemcpy(st0.data(), a.staging, st0.size() * 4, hipMemcpyDeviceToHost));
     CK(hipMemset(a.counts, 0xff, cnt0.size() * 4)); CK(hipMemset(a.staging, 0xff, st0.size() * 4));
-    const uint32_t n_wg = (n_tiles + kK2WWaves - 1) / kK2WWaves;
+    const uint32_t n_wg = (n_tiles * LPR + kK2WWaves - 1) / kK2WWaves;
     const uint32_t grid = 8u * ((n_wg + 7u) / 8u);
     const size_t lds = k2_walk_lds_bytes(0);
-    CK(hipFuncSetAttribute((const void *)k2_search_row<SL, KIND, WPB>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    CK(hipFuncSetAttribute((const void *)k2_search_row<SL, KIND, WPB, LPR>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipEvent_t e0, e1;
     CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
     std::vector<float> ms;
@@ -82,7 +82,7 @@ static void run_row(const char *name, amr::K2Args a, uint32_t n_tiles, int reps,
         CK(hipMemsetAsync(a.overflow, 0, 4, 0));
         cold_pass();
         a.dbg = (r == reps + 29) ? d_dbg : nullptr;
-        hipExtLaunchKernelGGL((k2_search_row<SL, KIND, WPB>), dim3(grid), dim3(64 * kK2WWaves), lds, 0, e0, e1, 0, a);
+        hipExtLaunchKernelGGL((k2_search_row<SL, KIND, WPB, LPR>), dim3(grid), dim3(64 * kK2WWaves), lds, 0, e0, e1, 0, a);
         CK(hipEventSynchronize(e1));
         float t; CK(hipEventElapsedTime(&t, e0, e1));
         if (r >= 30) ms.push_back(t);
@@ -236,7 +236,7 @@ int main(int argc, char **argv)
     unsigned long long *d_dbg; CK(hipMalloc((void **)&d_dbg, (size_t)n_tiles * 16 * 8));
     a.n_lo = -(int64_t)g.packet_length; a.n_hi = (int64_t)(n_tiles - 1) * 64 * g.block_size - g.packet_length;   // tile 0 = history tile
     if (!strcmp(kind, "scm")) { run<144, 1>("scm", a, n_tiles, reps, d_dbg); run_row<144, 0, 128>("scm", a, n_tiles, reps, d_dbg); }
-    else if (!strcmp(kind, "idm")) run<144, 4>("idm", a, n_tiles, reps, d_dbg);
+    else if (!strcmp(kind, "idm")) { run<144, 4>("idm", a, n_tiles, reps, d_dbg); run_row<144, 2, 128, 2>("idm", a, n_tiles, reps, d_dbg); }
     else run<144, 15>("all", a, n_tiles, reps, d_dbg);
     return 0;
 }
