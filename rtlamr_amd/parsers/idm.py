@@ -44,33 +44,6 @@ class IDM(Message):
     def MeterID(self): return self.ERTSerialNumber
     def MeterType(self): return self.ERTType
     def Checksum(self): return self.PacketCRC.to_bytes(2, "big")
-    def _fields(self):
-        """(name, CSV form, plain-text form) in the order of IDM.Record / IDM.String (idm/idm.go:176-221)."""
-        hx = lambda v, w: "0x%0*X" % (w, v)
-        raw = lambda b: bytes(b).hex().upper()          # Go prints a byte slice with %02X as its hex digits
-        iv = self.DifferentialConsumptionIntervals
-        return [("Preamble", hx(self.Preamble, 8), None), ("PacketTypeID", hx(self.PacketTypeID, 2), None),
-                ("PacketLength", hx(self.PacketLength, 2), None), ("HammingCode", hx(self.HammingCode, 2), None),
-                ("ApplicationVersion", hx(self.ApplicationVersion, 2), None), ("ERTType", hx(self.ERTType, 2), None),
-                ("ERTSerialNumber", str(self.ERTSerialNumber), "% 10d" % self.ERTSerialNumber),
-                ("ConsumptionIntervalCount", str(self.ConsumptionIntervalCount), None),
-                ("ModuleProgrammingState", hx(self.ModuleProgrammingState, 2), None),
-                ("TamperCounters", raw(self.TamperCounters), None),
-                ("AsynchronousCounters", hx(self.AsynchronousCounters, 2), None),
-                ("PowerOutageFlags", raw(self.PowerOutageFlags), None),
-                ("LastConsumptionCount", str(self.LastConsumptionCount), None),
-                ("DifferentialConsumptionIntervals", [str(v) for v in iv], "[" + " ".join(str(v) for v in iv) + "]"),
-                ("TransmitTimeOffset", str(self.TransmitTimeOffset), None),
-                ("SerialNumberCRC", hx(self.SerialNumberCRC, 4), None), ("PacketCRC", hx(self.PacketCRC, 4), None)]
-
-    def Record(self):
-        out = []
-        for _, csv, _ in self._fields():
-            out.extend(csv if isinstance(csv, list) else [csv])
-        return out
-
-    def __str__(self):
-        return "{" + " ".join(f"{n}:{(txt if txt is not None else csv)}" for n, csv, txt in self._fields()) + "}"
 
 
 class IdmParser(Parser):
@@ -137,30 +110,6 @@ class NetIDM(Message):
     def MeterID(self): return self.ERTSerialNumber
     def MeterType(self): return self.ERTType
     def Checksum(self): return self.PacketCRC.to_bytes(2, "big")
-    def _fields(self):
-        """(name, CSV form, plain-text form) in the order of NetIDM.Record / NetIDM.String (netidm/netidm.go:186-235)."""
-        hx = lambda v, w: "0x%0*X" % (w, v)
-        iv = self.DifferentialConsumptionIntervals
-        return [("Preamble", hx(self.Preamble, 8), None), ("ProtocolID", hx(self.ProtocolID, 2), None),
-                ("PacketLength", hx(self.PacketLength, 2), None), ("HammingCode", hx(self.HammingCode, 2), None),
-                ("ApplicationVersion", hx(self.ApplicationVersion, 2), None), ("ERTType", hx(self.ERTType, 2), None),
-                ("ERTSerialNumber", str(self.ERTSerialNumber), "% 10d" % self.ERTSerialNumber),
-                ("ConsumptionIntervalCount", str(self.ConsumptionIntervalCount), None),
-                ("ProgrammingState", hx(self.ProgrammingState, 2), None),
-                ("LastGeneration", str(self.LastGeneration), None), ("LastConsumption", str(self.LastConsumption), None),
-                ("LastConsumptionNet", str(self.LastConsumptionNet), None),
-                ("DifferentialConsumptionIntervals", [str(v) for v in iv], "[" + " ".join(str(v) for v in iv) + "]"),
-                ("TransmitTimeOffset", str(self.TransmitTimeOffset), None),
-                ("SerialNumberCRC", hx(self.SerialNumberCRC, 4), None), ("PacketCRC", hx(self.PacketCRC, 4), None)]
-
-    def Record(self):
-        out = []
-        for _, csv, _ in self._fields():
-            out.extend(csv if isinstance(csv, list) else [csv])
-        return out
-
-    def __str__(self):
-        return "{" + " ".join(f"{n}:{(txt if txt is not None else csv)}" for n, csv, txt in self._fields()) + "}"
 
 
 class NetIdmParser(IdmParser):
@@ -201,8 +150,6 @@ class SCMPlus(Message):
     def MeterID(self): return self.EndpointID
     def MeterType(self): return self.EndpointType
     def Checksum(self): return self.PacketCRC.to_bytes(2, "big")
-    def Record(self): return [hex(self.FrameSync), hex(self.ProtocolID), hex(self.EndpointType), str(self.EndpointID),
-                              str(self.Consumption), hex(self.Tamper), hex(self.PacketCRC)]
 
 
 class ScmPlusParser(Parser):

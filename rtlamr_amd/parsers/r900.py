@@ -36,14 +36,6 @@ class R900(Message):
     def MeterType(self): return self.Unkn1
     def Checksum(self): return self.checksum
 
-    def Record(self) -> List[str]:
-        return [str(v) for v in (self.ID, self.Unkn1, self.NoUse, self.BackFlow, self.Consumption, self.Unkn3,
-                                 self.Leak, self.LeakNow)]
-
-    def __str__(self):
-        return (f"{{ID:{self.ID:10d} Unkn1:0x{self.Unkn1:02X} NoUse:{self.NoUse:2d} BackFlow:{self.BackFlow:1d} "
-                f"Consumption:{self.Consumption:8d} Unkn3:0x{self.Unkn3:02X} Leak:{self.Leak:2d} LeakNow:{self.LeakNow:1d}}}")
-
 
 class R900Parser(Parser):
     ALWAYS_PARSE = False   # nothing to do for a block without r900 hits: the per-block filter has moved to the GPU

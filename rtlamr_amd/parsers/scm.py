@@ -30,14 +30,6 @@ class SCM(Message):
     def MeterType(self): return self.Type
     def Checksum(self): return self.ChecksumVal.to_bytes(2, "big")
 
-    def Record(self) -> List[str]:
-        return [str(self.ID), str(self.Type), hex(self.TamperPhy), hex(self.TamperEnc), str(self.Consumption),
-                hex(self.ChecksumVal)]
-
-    def __str__(self):
-        return (f"{{ID:{self.ID:8d} Type:{self.Type:2d} Tamper:{{Phy:{self.TamperPhy:02X} Enc:{self.TamperEnc:02X}}} "
-                f"Consumption:{self.Consumption:8d} CRC:0x{self.ChecksumVal:04X}}}")
-
 
 class ScmParser(Parser):
     """scm.Parser (scm/scm.go:33-91)."""

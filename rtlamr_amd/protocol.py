@@ -75,7 +75,11 @@ class Message:
     def MeterID(self) -> int: raise NotImplementedError
     def MeterType(self) -> int: raise NotImplementedError
     def Checksum(self) -> bytes: raise NotImplementedError
-    def Record(self) -> List[str]: raise NotImplementedError
+
+    # Message.Record (parse.go:83: the CSV / JSON / XML columns) is output plumbing, out of scope here: the
+    # mirrors keep the four identifying methods the receive loop's dedupe reads (protocol.NewDigest, parse.go:95-101)
+    def __str__(self):
+        return f"{{{self.MsgType()} ID:{self.MeterID()} Type:{self.MeterType()} Checksum:0x{bytes(self.Checksum()).hex().upper()}}}"
 
 
 class Parser:

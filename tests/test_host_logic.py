@@ -136,21 +136,3 @@ def test_run_parsers_groups_hits_per_block_and_preamble():
         [("SCM", 111)],                              # block 10: two hits, identical bytes -> one message (seen map)
         [("IDM", 333), ("NetIDM", 333)],             # block 11: the shared preamble feeds both parsers
         [("SCM", 222)]]                              # block 12
-
-
-def test_idm_and_netidm_records_have_the_reference_columns():
-    """idm.IDM.Record / String (idm/idm.go:176-221): 16 scalar columns + 47 intervals; netidm (netidm/netidm.go:186-235):
-    15 + 27; hex fields zero-padded upper case, byte-slice fields as plain hex, the serial right-aligned in String."""
-    from rtlamr_amd.parsers.idm import IDM, NetIDM
-    m = IDM(0x555516A3, 0x1C, 0x5C, 0xC6, 4, 7, 12345678, 3, 0xBC, bytes([1, 2, 3, 4, 5, 6]), 0x12, bytes(6), 99,
-            list(range(47)), 17, 0xABCD, 0x1D0F)
-    r = m.Record()
-    assert len(r) == 16 + 47 and r[0] == "0x555516A3" and r[4] == "0x04" and r[6] == "12345678"
-    assert r[9] == "010203040506" and r[10] == "0x12" and r[13:13 + 47] == [str(i) for i in range(47)]
-    assert r[-3:] == ["17", "0xABCD", "0x1D0F"]
-    s = str(m)
-    assert s.startswith("{Preamble:0x555516A3 PacketTypeID:0x1C ") and "ERTSerialNumber:  12345678 " in s
-    assert "DifferentialConsumptionIntervals:[0 1 2 " in s and s.endswith("PacketCRC:0x1D0F}")
-    n = NetIDM(0x555516A3, 0x1C, 0x5C, 0xC6, 4, 7, 123, 3, 0xBC, 5, 6, 7, list(range(27)), 17, 0xABCD, 0x1D0F)
-    assert len(n.Record()) == 15 + 27 and n.Record()[9:12] == ["5", "6", "7"]
-    assert "LastGeneration:5 LastConsumption:6 LastConsumptionNet:7 " in str(n)
