@@ -623,7 +623,10 @@ def main():
                          "algorithmic_bytes_per_launch": alg_bytes},
         }
         if distributed:
-            sent = 128 + dec.gather_wire_bytes(n_hits)      # header + records of the last step, as amr_gather_hits sends them
+            # what amr_gather_hits put on the wire for the last step: small slots (validated hits) whole, large ones as a
+            # 128-byte header + the records sized by their count
+            two_phase = dec.gather_two_phase(gatherer.cap)
+            sent = 128 + dec.gather_wire_bytes(n_hits) if two_phase else int(gatherer.slot_bytes)
             ranks = dec.comm_ranks()
             if not (ranks == world == args.gpus or os.environ.get("AMR_BENCH_FORCE_DIST") == "1"):
                 check["ranks"] = f"MISMATCH: --gpus {args.gpus}, WORLD_SIZE {world}, RCCL communicator spans {ranks}"
@@ -631,7 +634,10 @@ def main():
             out["config"].update({"rccl_ranks": ranks,
                                   "gather_bytes_per_step": {"sent_per_rank": sent, "payload_per_rank": 128 + 12 * n_hits,
                                                             "slot_capacity_bytes": int(gatherer.slot_bytes),
-                                                            "into_root": sent * world, "rule": "128-byte header + 12 B per record rounded up to 4 KiB (amr_gather_wire_bytes)"},
+                                                            "into_root": sent * world,
+                                                            "rule": ("128-byte header + 12 B per record rounded up to 4 KiB (amr_gather_wire_bytes): "
+                                                                     "two messages, the root waits for the headers" if two_phase else
+                                                                     "slot of up to 256 KiB: one message per rank, nobody waits")},
                                   "gather_records": "validated hits (K5)" if validating else "raw hits (--gather raw)"})
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(wl, dec, d_iq.value, bs2)

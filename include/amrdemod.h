@@ -331,11 +331,12 @@ amr_status amr_comm_ranks(const amr_handle *h, int32_t *n_ranks);
 /* Enqueue the gather of the result amr_collect / amr_flush returned last (with amr_set_validation: of its surviving
  * hits -- the natural companion: 70x fewer records; an amr_flush that had nothing deferred returned an empty result:
  * zero records travel).  Collective: every rank calls it once per result, in the same order.  *seq (may be NULL)
- * receives the gather's sequence number.  What travels is sized by the hit count: a 128-byte header from every rank,
- * then amr_gather_wire_bytes(records) from every rank that has any.  Non-root ranks return at once; the root returns
- * when every rank's header has arrived (it needs the counts to post its receives), i.e. it runs at most one gather
- * ahead of the slowest rank.  The library orders the kernel that reads the batch's result against the later reuse of
- * its slot by itself. */
+ * receives the gather's sequence number.  Slots of up to 256 KiB (amr_gather_two_phase(cap) == 0: the capacities of
+ * validated hit lists) travel whole in one message and every rank returns at once.  Larger ones (raw hit lists) are
+ * sized by the hit count: a 128-byte header from every rank, then amr_gather_wire_bytes(records) from every rank that
+ * has any; non-root ranks return at once, the root returns when every rank's header has arrived (it needs the counts to
+ * post its receives), i.e. it runs at most one gather ahead of the slowest rank.  The library orders the kernel that
+ * reads the batch's result against the later reuse of its slot by itself. */
 amr_status amr_gather_hits(amr_handle *h, uint64_t *seq);
 amr_status amr_gather_wait(amr_handle *h);    /* block until every gather enqueued so far has completed */
 /* Root only: the records rank src_rank contributed to gather `seq`.  Waits for the arrival of that gather's records in
@@ -350,6 +351,9 @@ amr_status amr_gather_fetch(amr_handle *h, uint64_t seq, int32_t src_rank, amr_g
 size_t amr_gather_slot_bytes(uint64_t cap_hits);
 /* bytes of records that travel behind the header for n_sent records: 12 * n_sent rounded up to 4 KiB (0 for none) */
 size_t amr_gather_wire_bytes(uint64_t n_sent);
+/* 1: a communicator of this capacity sends header and count-sized records separately (slots above 256 KiB: raw hit
+ * lists); 0: its slots are small enough to travel whole in one message and nobody waits for anybody (validated hits) */
+int32_t amr_gather_two_phase(uint64_t cap_hits);
 amr_status amr_gather_pack_host(const amr_result *res, uint64_t cap_hits, uint64_t seq, void *slot, size_t slot_bytes);
 amr_status amr_gather_unpack(const void *slot, size_t slot_bytes, amr_gathered *out);
 

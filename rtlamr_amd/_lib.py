@@ -20,7 +20,7 @@ SYMBOLS = [
     "amr_last_error", "amr_describe", "amr_dev_alloc", "amr_dev_free", "amr_dev_upload", "amr_dev_download",
     "amr_dev_sync", "amr_synth_noise", "amr_synth_uniform", "amr_synth_plant",
     "amr_comm_unique_id", "amr_comm_init", "amr_comm_destroy", "amr_comm_ranks", "amr_gather_hits", "amr_gather_wait", "amr_gather_fetch",
-    "amr_gather_slot_bytes", "amr_gather_wire_bytes", "amr_gather_pack_host", "amr_gather_unpack",
+    "amr_gather_slot_bytes", "amr_gather_wire_bytes", "amr_gather_two_phase", "amr_gather_pack_host", "amr_gather_unpack",
 ]
 
 
@@ -150,12 +150,14 @@ def lib() -> C.CDLL:
     L.amr_gather_wire_bytes.argtypes = [C.c_uint64]
     L.amr_gather_wire_bytes.restype = C.c_size_t
     L.amr_device_count.argtypes = [C.POINTER(C.c_int32)]
+    L.amr_gather_two_phase.argtypes = [C.c_uint64]
+    L.amr_gather_two_phase.restype = C.c_int32
     L.amr_gather_pack_host.argtypes = [C.POINTER(AmrResult), C.c_uint64, C.c_uint64, vp, C.c_size_t]
     L.amr_gather_unpack.argtypes = [vp, C.c_size_t, C.POINTER(AmrGathered)]
     for name in SYMBOLS:
         fn = getattr(L, name)
         if name not in ("amr_preamble_id", "amr_halo_bytes", "amr_prime_blocks", "amr_strerror", "amr_last_error",
-                        "amr_gather_slot_bytes", "amr_gather_wire_bytes"):
+                        "amr_gather_slot_bytes", "amr_gather_wire_bytes", "amr_gather_two_phase"):
             fn.restype = C.c_int
     _lib = L
     return L

@@ -1498,8 +1498,10 @@ amr_status amr_synth_plant(int32_t device_id, void *d_iq, uint64_t n_samples, ui
 // instead of a timing assumption.  The send buffer of set k is reused by the pack of gather seq + 2 on the same stream,
 // i.e. in order behind the send that read it.
 //
-// What travels is sized by the hit count, not by the capacity (round 4; a fixed 1.5 x capacity slot was 5.2 MB per rank
-// and step for raw hits whatever the batch held).  Two phases per gather, both on the communicator's stream:
+// What travels is sized by the hit count, not by the capacity, once the capacity is large (round 4; a fixed 1.5 x
+// capacity slot was 5.2 MB per rank and step for raw hits whatever the batch held; slots of up to kGatherWholeSlotMax
+// -- validated hits -- still travel whole in one message, with no host wait at all).  For the large ones, two phases
+// per gather, both on the communicator's stream:
 //   1. every rank sends its 128-byte slot header (true count, records sent, per-preamble offsets, sequence number);
 //   2. every rank with records sends exactly gather_wire_bytes(n_sent) = 12 * n_sent bytes rounded up to 4 KiB.
 // A sender knows its count on the host (amr_collect returned it) and never waits.  The ROOT has to know every peer's
@@ -1581,6 +1583,13 @@ __host__ __device__ inline size_t gather_wire_bytes(uint64_t n_sent)
     return ((size_t)n_sent * 12 + 4095) & ~(size_t)4095;
 }
 
+// Slots up to this size travel whole, in ONE message per rank and gather, and nobody waits for anybody (round 3's
+// protocol): at 12 bytes per record that is a capacity of 21 000 validated hits -- what `bench.py --gpus N` and any
+// deployment with amr_set_validation gather.  Only larger slots (raw hit lists: MBs) are worth the two phases, whose
+// price is the root's wait for the headers.
+constexpr size_t kGatherWholeSlotMax = 256 * 1024;
+__host__ __device__ inline bool gather_two_phase(size_t slot_bytes) { return slot_bytes > kGatherWholeSlotMax; }
+
 // a slot in memory: header + room for the wire bytes of `cap` records
 __host__ __device__ inline size_t gather_slot_bytes(uint64_t cap)
 {
@@ -1608,10 +1617,11 @@ __global__ void k_gather_pack(const uint8_t *packed, const uint64_t *offs, uint3
 
 // Root: headers (received contiguously, phase 1) and records (phase 2, in place behind each rank's header slot) of all
 // ranks -> the pinned host mirror, laid out as slots again.  grid (x, world): the x blocks of rank p share its records.
+// (d_hdr null: the slots arrived whole, every header sits in front of its records)
 __global__ void k_gather_mirror(const uint8_t *d_hdr, const uint8_t *d_recv, uint8_t *h_recv, size_t slot_bytes)
 {
     const uint32_t p = blockIdx.y;
-    const uint4 *hdr = reinterpret_cast<const uint4 *>(d_hdr + (size_t)p * kGatherHdr * 8);
+    const uint4 *hdr = reinterpret_cast<const uint4 *>(d_hdr ? d_hdr + (size_t)p * kGatherHdr * 8 : d_recv + (size_t)p * slot_bytes);
     const uint64_t m = reinterpret_cast<const uint64_t *>(hdr)[1];
     uint4 *dst = reinterpret_cast<uint4 *>(h_recv + (size_t)p * slot_bytes);
     const uint4 *src = reinterpret_cast<const uint4 *>(d_recv + (size_t)p * slot_bytes);
@@ -1660,6 +1670,7 @@ extern "C" {
 
 size_t amr_gather_slot_bytes(uint64_t cap_hits) { return gather_slot_bytes(cap_hits); }
 size_t amr_gather_wire_bytes(uint64_t n_sent) { return gather_wire_bytes(n_sent); }
+int32_t amr_gather_two_phase(uint64_t cap_hits) { return gather_two_phase(gather_slot_bytes(cap_hits)) ? 1 : 0; }
 
 amr_status amr_device_count(int32_t *n_devices)
 {
@@ -1796,6 +1807,23 @@ amr_status amr_gather_hits(amr_handle *h, uint64_t *seq_out)
         s->pack_pending = true;
     }
     const size_t hdr_bytes = (size_t)kGatherHdr * 8;
+    if (!gather_two_phase(c->slot_bytes)) {
+        // ---- small slots: the whole slot in one message, no host wait anywhere ----
+        NCCL_TRY(r->GroupStart());
+        NCCL_TRY(r->Send(c->d_send[k], c->slot_bytes, kNcclUint8, c->root, c->comm, c->stream));
+        if (c->rank == c->root)
+            for (int p = 0; p < c->world; ++p)
+                NCCL_TRY(r->Recv(c->d_recv[k] + (size_t)p * c->slot_bytes, c->slot_bytes, kNcclUint8, p, c->comm, c->stream));
+        NCCL_TRY(r->GroupEnd());
+        if (c->rank == c->root) {
+            hipLaunchKernelGGL(k_gather_mirror, dim3(8, (unsigned)c->world), dim3(256), 0, c->stream, (const uint8_t *)nullptr, c->d_recv[k], c->h_recv[k], c->slot_bytes);
+            HIP_TRY(hipGetLastError());
+            HIP_TRY(hipEventRecord(c->ev_host[k], c->stream));
+        }
+        c->seq_of[k] = seq;
+        if (seq_out) *seq_out = seq;
+        return AMR_OK;
+    }
     // ---- phase 1: the headers ----
     NCCL_TRY(r->GroupStart());
     NCCL_TRY(r->Send(c->d_send[k], hdr_bytes, kNcclUint8, c->root, c->comm, c->stream));

@@ -98,10 +98,11 @@ def rows_from_gathered(off, blk, idx) -> np.ndarray:
 class HitGatherer:
     """The hit gather for hosts WITHOUT RCCL (CPU ranks, gloo): the same slot -- header, call indices, idx, laid out by
     the C library's amr_gather_pack_host / amr_gather_unpack, the very code the device pack kernel and amr_gather_fetch
-    are built from -- and the same two-phase protocol as amr_gather_hits, moved by torch.distributed instead of
-    ncclSend/ncclRecv: every rank sends its 128-byte header, the root reads the counts, then every rank with records
-    sends exactly amr_gather_wire_bytes(n_sent) bytes.  Fixed capacity agreed up front, two buffer sets, a sequence
-    number per gather; a batch with more records than the capacity arrives truncated with its true count."""
+    are built from -- and the same protocol as amr_gather_hits, moved by torch.distributed instead of ncclSend/ncclRecv:
+    slots of up to 256 KiB (amr_gather_two_phase(cap) == 0) travel whole in one collective; for larger ones every rank
+    sends its 128-byte header, the root reads the counts, then every rank with records sends exactly
+    amr_gather_wire_bytes(n_sent) bytes.  Fixed capacity agreed up front, two buffer sets, a sequence number per gather;
+    a batch with more records than the capacity arrives truncated with its true count."""
 
     HDR = 128
 
@@ -114,6 +115,7 @@ class HitGatherer:
         self.world, self.rank = dist.get_world_size(group), dist.get_rank(group)
         self.n_pre, self.cap = n_preambles, cap_hits
         self.slot_bytes = int(self.L.amr_gather_slot_bytes(cap_hits))
+        self.two_phase = bool(self.L.amr_gather_two_phase(cap_hits))      # large slots only; small ones travel whole
         self.send = [torch.zeros(self.slot_bytes, dtype=torch.uint8) for _ in range(2)]
         self.recv = [[torch.zeros(self.slot_bytes, dtype=torch.uint8) for _ in range(self.world)]
                      if self.rank == root else None for _ in range(2)]
@@ -142,6 +144,11 @@ class HitGatherer:
         r, keep = _result_struct(br, self.n_pre)
         _lib.check(self.L.amr_gather_pack_host(r, self.cap, seq, self.send[k].data_ptr(), self.slot_bytes), "amr_gather_pack_host")
         n_sent = min(int(r.n_hits), self.cap)
+        if not self.two_phase:      # small slots: the whole slot in one collective, nobody waits (amr_gather_hits does the same)
+            self.sent_bytes.append(self.slot_bytes)
+            self.work[k].append(dist.gather(self.send[k], self.recv[k], dst=self.root, group=self.group, async_op=True))
+            self.seq_of[k] = seq
+            return seq
         wire = self.wire_bytes(n_sent)
         self.sent_bytes.append(self.HDR + wire)
         # phase 1: the headers

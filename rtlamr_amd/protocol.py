@@ -250,8 +250,13 @@ class Decoder:
 
     @staticmethod
     def gather_wire_bytes(n_sent: int) -> int:
-        """Bytes of records a rank with n_sent of them sends behind its 128-byte header."""
+        """Bytes of records a rank with n_sent of them sends behind its 128-byte header (two-phase communicators)."""
         return int(_lib.lib().amr_gather_wire_bytes(n_sent))
+
+    @staticmethod
+    def gather_two_phase(cap_hits: int) -> bool:
+        """True: a communicator of this capacity sends header + count-sized records; False: whole small slots, no wait."""
+        return bool(_lib.lib().amr_gather_two_phase(cap_hits))
 
     def comm_ranks(self) -> int:
         """Ranks the RCCL communicator spans (ncclCommCount)."""

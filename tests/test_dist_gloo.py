@@ -96,16 +96,17 @@ def test_gather_handles_empty_rank(tmp_path):
     assert np.load(os.path.join(str(tmp_path), "g.npy")).tolist() == [[0, 5, 7], [1, 6, 8]]
 
 
-def _w_gatherer(rank, world, port, out):
+def _w_gatherer(rank, world, port, out, cap, scale):
     sys.path.insert(0, ROOT)
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     tdist.init_process_group("gloo", rank=rank, world_size=world)
     from rtlamr_amd import dist
     from rtlamr_amd.protocol import BatchResult
-    g = dist.HitGatherer(2, cap_hits=2000)
+    g = dist.HitGatherer(2, cap_hits=cap)
+    assert g.two_phase == (cap * 12 + 128 > 256 * 1024)
     got, trunc = [], []
     for step in range(5):   # more steps than buffer sets, different data every step; the last one overflows rank 1's slot
-        n0, n1 = 3 + step * (rank + 1) * 300, 2 + step
+        n0, n1 = 3 + step * (rank + 1) * 300 * scale, 2 + step
         blk = np.arange(n0 + n1, dtype=np.uint64) + 1000 * rank + step
         idx = (np.arange(n0 + n1, dtype=np.uint32) * 7 + rank) % 4096
         br = BatchResult(8, 0, np.array([0, n0, n0 + n1], np.uint64), blk, idx, np.zeros((n0 + n1, 12), np.uint8))
@@ -118,17 +119,19 @@ def _w_gatherer(rank, world, port, out):
             for r in range(world):
                 n_true, off, b, i = g.fetch(step - 1, r)
                 (trunc if n_true > len(b) else got).append((step - 1, r, n_true, dist.rows_from_gathered(off, b, i)))
-    # what went over the wire follows the hit count (header + 12 bytes per record sent, rounded up to 4 KiB), not the capacity
+    # large slots: what went over the wire follows the hit count (header + 12 bytes per record sent, rounded up to 4 KiB),
+    # not the capacity; small slots travel whole
     for step in range(5):
-        n = min(2000, 3 + step * (rank + 1) * 300 + 2 + step)
-        assert g.sent_bytes[step] == 128 + ((12 * n + 4095) // 4096) * 4096, (step, g.sent_bytes)
+        n = min(cap, 3 + step * (rank + 1) * 300 * scale + 2 + step)
+        want = 128 + ((12 * n + 4095) // 4096) * 4096 if g.two_phase else g.slot_bytes
+        assert g.sent_bytes[step] == want, (step, g.sent_bytes)
     # unequal remainders at the end of a stream: rank 1's amr_flush had nothing deferred (an EMPTY result), rank 0's had
     # hits -- every rank still posts one gather per result, and the empty one carries zero records, not the batch before
     n5 = 4 if rank == 0 else 0
     br = BatchResult(8, 0, np.array([0, n5, n5], np.uint64), np.arange(n5, dtype=np.uint64) + 77, np.arange(n5, dtype=np.uint32),
                      np.zeros((n5, 12), np.uint8))
     assert g.post(br) == 5
-    assert g.sent_bytes[5] == (128 + 4096 if rank == 0 else 128)
+    assert g.sent_bytes[5] == ((128 + 4096 if rank == 0 else 128) if g.two_phase else g.slot_bytes)
     if rank == 0:
         for r in range(world):
             n_true, off, b, i = g.fetch(4, r)
@@ -144,21 +147,22 @@ def _w_gatherer(rank, world, port, out):
     tdist.destroy_process_group()
 
 
-def test_hit_gatherer_drives_the_c_slot_layout(tmp_path):
+@pytest.mark.parametrize("cap,scale", [(2000, 1), (30000, 15)], ids=["whole-slots", "two-phase"])
+def test_hit_gatherer_drives_the_c_slot_layout(tmp_path, cap, scale):
     """rtlamr_amd.dist.HitGatherer on gloo: the slot every rank sends is packed by amr_gather_pack_host and read by
     amr_gather_unpack -- the code the device pack kernel and amr_gather_fetch are built from -- across buffer-set
     reuse, a lagging rank, different data per gather, a slot that overflows (truncated, true count kept), an empty result
     on one rank only, and the two-phase wire rule (header, then records sized by their count)."""
-    port = 33500 + (os.getpid() % 2000)
-    mp.spawn(_w_gatherer, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    port = 33500 + (os.getpid() % 2000) + (7 if scale > 1 else 0)
+    mp.spawn(_w_gatherer, args=(2, port, str(tmp_path), cap, scale), nprocs=2, join=True)
     got = np.load(os.path.join(str(tmp_path), "hg.npy"))
     trunc = np.load(os.path.join(str(tmp_path), "trunc.npy"))
     want = []
     for step in range(5):
         for rank in range(2):
-            n0, n1 = 3 + step * (rank + 1) * 300, 2 + step
-            if n0 + n1 > 2000:
-                assert [step, rank, n0 + n1, 2000] in trunc.tolist()
+            n0, n1 = 3 + step * (rank + 1) * 300 * scale, 2 + step
+            if n0 + n1 > cap:
+                assert [step, rank, n0 + n1, cap] in trunc.tolist()
                 continue
             blk = np.arange(n0 + n1, dtype=np.int64) + 1000 * rank + step
             idx = (np.arange(n0 + n1, dtype=np.int64) * 7 + rank) % 4096
