@@ -24,7 +24,6 @@
 #include "launch.h"
 #include "k3_slice.h"
 #include "k4_r900.h"
-#include "k5_validate.h"
 #include "synth.h"
 
 namespace {
@@ -92,7 +91,7 @@ struct Slot {
     uint8_t *h_out = nullptr; uint64_t host_cap = 0;
     uint8_t *d_r900 = nullptr; uint8_t *h_r900 = nullptr; uint64_t r900_host_cap = 0;   // [out_cap][42] digits (r900 enabled)
     // validation (amr_set_validation): the surviving hits, packed like d_out, and the scratch of the compaction
-    uint8_t *d_val = nullptr; uint8_t *d_keep = nullptr; uint32_t *d_chunk = nullptr;
+    uint8_t *d_val = nullptr; uint8_t *d_keep = nullptr; uint64_t *d_listoff = nullptr;   // K5: see k5_validate.h
     uint64_t *d_offs_val = nullptr; uint64_t *h_offv = nullptr;   // [AMR_MAX_PREAMBLES+1] each
     uint8_t *d_iq_stage = nullptr; size_t iq_stage_cap = 0;   // device copy of a host-resident batch (amr_submit_host)
     hipEvent_t ev_h2d = nullptr;
@@ -271,7 +270,6 @@ amr_status alloc_hit_buffers(amr_handle *h, Slot &s)
     if (h->validate) {
         AMR_TRY(dev_realloc(s.d_val, s.out_cap * (12 + h->sg.pkt_bytes)));
         AMR_TRY(dev_realloc(s.d_keep, s.out_cap));
-        AMR_TRY(dev_realloc(s.d_chunk, s.out_cap / amr::kValChunk + 2));
     }
     return AMR_OK;
 }
@@ -282,19 +280,21 @@ amr_status ensure_capacity(amr_handle *h, Slot &s, Slot &other, size_t n_blocks)
     const size_t st = bt + 1;                 // tiles searched
     {   // hipMalloc / hipFree wait for the whole device: with batches in flight, launch their pending K3.. first (see
         // sync_compute) -- this happens on the first use of each slot and when a batch is larger than any before
-        const uint32_t gw0 = (uint32_t)(amr::k2_groups((uint32_t)st) * h->sg.n_pre);
+        const uint32_t gw0 = 2 * (uint32_t)(amr::k2_groups((uint32_t)st) * h->sg.n_pre);
         const bool grows = bt + 2 > s.qt_tiles || !other.d_qt || st > s.cnt_tiles || gw0 > s.gcnt_words || gw0 > other.gcnt_words ||
                            st > s.staging_tiles || !s.d_out || (h->validate && !s.d_val);
         if (grows && h->n_pending) AMR_TRY(sync_compute(h));
     }
     AMR_TRY(ensure_qt(h, s, other, bt + 2));
-    if (st > s.cnt_tiles) {
-        AMR_TRY(dev_realloc(s.d_counts, st * h->sg.n_pre));
+    if (st > s.cnt_tiles) {     // per list: hits (K2), then survivors of K5's test and the list's slot (K3)
+        AMR_TRY(dev_realloc(s.d_counts, 2 * st * h->sg.n_pre));
+        AMR_TRY(dev_realloc(s.d_listoff, st * h->sg.n_pre));
         s.cnt_tiles = st;
     }
     // group sums: this slot and the next one (the hist kernel of this batch zeroes those of the next), kept zero between
     // uses.  Neither holds a batch in flight; the slots that do keep what their own batch was sized for.
-    const uint32_t gw = (uint32_t)(amr::k2_groups((uint32_t)st) * h->sg.n_pre);
+    // (two halves: the hits K2 counts, the survivors K3's last stage counts when validation is on)
+    const uint32_t gw = 2 * (uint32_t)(amr::k2_groups((uint32_t)st) * h->sg.n_pre);
     Slot *both[2] = {&s, &other};
     for (Slot *slp : both) {
         Slot &sl = *slp;
@@ -406,12 +406,20 @@ amr_status enqueue_tail(amr_handle *h, Slot &s, hipStream_t st, bool split)
     k3.out = s.d_out; k3.offs_pre = s.d_offs_pre; k3.h_offs_pre = s.h_off; k3.h_overflow = s.h_ovf;
     k3.out_cap = s.out_cap; k3.overflow = s.d_overflow;
     k3.block_base = s.calls_base; k3.n_tiles = s.n_tiles; k3.cap = s.stage_cap; k3.g = h->sg;
+    if (h->validate) {   // the checksum test + repeated-packet removal of every hit, as the last stage of K3's workgroups
+        k3.keep = s.d_keep;
+        k3.listcnt = s.d_counts + s.cnt_tiles * n_pre;
+        k3.listoff = s.d_listoff;
+        k3.vgcnt = s.d_gcnt + s.gcnt_words / 2;
+        for (uint32_t q = 0; q < n_pre; ++q) k3.rule[q] = h->rules[q];
+    }
     hipEvent_t k3e0 = (t2 && split) ? s.ev_t : nullptr, k3e1 = t2 ? s.ev2 : nullptr;
-    const size_t k3lds = amr::k3_lds_bytes(h->sg);
+    const size_t k3lds = amr::k3_lds_bytes(h->sg, h->validate);
+    k3.lds_bytes = (uint32_t)k3lds;
     HIP_TRY(hipFuncSetAttribute((const void *)amr::k3_slice_words, hipFuncAttributeMaxDynamicSharedMemorySize, (int)k3lds));
     // one workgroup per (tile, preamble) list; the kernel also takes a grid of (n_tiles, 1) = every list of a tile in one
     // workgroup with shared row staging, which measured slower on the four-preamble decoder (188 against 173 us per 4 GiB)
-    hipExtLaunchKernelGGL(amr::k3_slice_words, dim3(s.n_tiles, n_pre), dim3(256), k3lds, st, k3e0, k3e1, 0, k3);
+    hipExtLaunchKernelGGL(amr::k3_slice_words, dim3(s.n_tiles - 1, n_pre), dim3(256), k3lds, st, k3e0, k3e1, 0, k3);
     HIP_TRY(hipGetLastError());
     AMR_DBG(st, "k3_slice");
     if (h->r900_pid >= 0) {
@@ -427,17 +435,15 @@ amr_status enqueue_tail(amr_handle *h, Slot &s, hipStream_t st, bool split)
         HIP_TRY(hipGetLastError());
         AMR_DBG(st, "k4_r900_digits");
     }
-    if (h->validate) {   // checksum test + repeated-packet removal, ordered compaction into d_val
+    if (h->validate) {   // ordered compaction of the hits K3's last stage kept into d_val
         amr::K5Args k5{};
         k5.in = s.d_out; k5.out = s.d_val; k5.offs_pre = s.d_offs_pre; k5.offs_val = s.d_offs_val; k5.h_offs_val = s.h_offv;
-        k5.chunk = s.d_chunk; k5.keep = s.d_keep; k5.overflow = s.d_overflow; k5.cap = s.out_cap;
-        k5.n_pre = n_pre; k5.pkt_bytes = h->sg.pkt_bytes;
-        for (uint32_t q = 0; q < n_pre; ++q) k5.rule[q] = h->rules[q];
-        const unsigned nb = (unsigned)((s.out_cap + amr::kValChunk - 1) / amr::kValChunk);   // surplus groups exit at once
-        hipLaunchKernelGGL(amr::k5_flag, dim3(nb), dim3(amr::kValChunk), 0, st, k5);
-        hipLaunchKernelGGL(amr::k5_compact, dim3(nb), dim3(amr::kValChunk), 0, st, k5);
+        k5.keep = s.d_keep; k5.counts = s.d_counts; k5.listcnt = k3.listcnt; k5.listoff = s.d_listoff; k5.vgcnt = k3.vgcnt;
+        k5.overflow = s.d_overflow; k5.cap = s.out_cap;
+        k5.n_pre = n_pre; k5.n_tiles = s.n_tiles; k5.pkt_bytes = h->sg.pkt_bytes;
+        hipLaunchKernelGGL(amr::k5_compact, dim3(s.n_tiles - 1, n_pre), dim3(256), 0, st, k5);
         HIP_TRY(hipGetLastError());
-        AMR_DBG(st, "k5_validate");
+        AMR_DBG(st, "k5_compact");
     }
     return AMR_OK;
 }
@@ -1058,6 +1064,27 @@ amr_status amr_destroy(amr_handle *h)
 {
     if (!h) return AMR_OK;
     (void)hipSetDevice(h->device);
+#if AMR_K3_DBG
+    {   // diagnostic build: phases of the last K3 launch's workgroups
+        (void)hipDeviceSynchronize();
+        static unsigned long long hc[4096 * 8];
+        if (hipMemcpyFromSymbol(hc, HIP_SYMBOL(amr::k3_dbg), sizeof hc) == hipSuccess) {
+            unsigned long long t0 = ~0ull, t1 = 0; int n = 0;
+            for (int i = 1; i < 4096; ++i) if (hc[8 * i]) { t0 = std::min(t0, hc[8 * i]); for (int k = 0; k < 7; ++k) t1 = std::max(t1, hc[8 * i + k]); ++n; }
+            double ph[7] = {}, mx[7] = {}, st_mx = 0, st_sum = 0;
+            for (int i = 1; i < 4096; ++i) if (hc[8 * i]) {
+                st_sum += (double)(hc[8 * i] - t0); st_mx = std::max(st_mx, (double)(hc[8 * i] - t0));
+                for (int k = 1; k < 7; ++k) if (hc[8 * i + k] >= hc[8 * i + k - 1]) { const double d = (double)(hc[8 * i + k] - hc[8 * i + k - 1]); ph[k] += d; mx[k] = std::max(mx[k], d); }
+            }
+            if (n) {
+                fprintf(stderr, "AMR_K3_DBG: %d workgroups, span %.2f us, start mean %.2f max %.2f us;", n, (double)(t1 - t0) * 0.01, st_sum / n * 0.01, st_mx * 0.01);
+                const char *nm[7] = {"", "prologue", "slice", "barrier", "tables+edge", "rounds", "reduce"};
+                for (int k = 1; k < 7; ++k) fprintf(stderr, " %s %.2f/%.2f", nm[k], ph[k] / n * 0.01, mx[k] * 0.01);
+                fprintf(stderr, " (mean/max us)\n");
+            }
+        }
+    }
+#endif
 #if AMR_GATE_CLK
     {   // diagnostic build: shader clock seen by the gate kernels (they sleep through the first rounds of the following K1)
         (void)hipDeviceSynchronize();
@@ -1080,7 +1107,7 @@ amr_status amr_destroy(amr_handle *h)
     if (h->h_flags) (void)hipHostFree(h->h_flags);
     for (Slot &sl : h->slot) {
         void *dp[] = {sl.d_qt, sl.d_counts, sl.d_gcnt, sl.d_offs_pre, sl.d_overflow, sl.d_staging, sl.d_out, sl.d_iq_stage, sl.d_r900,
-                      sl.d_val, sl.d_keep, sl.d_chunk, sl.d_offs_val};
+                      sl.d_val, sl.d_keep, sl.d_listoff, sl.d_offs_val};
         if (sl.h_r900) (void)hipHostFree(sl.h_r900);
         if (sl.ev_h2d) (void)hipEventDestroy(sl.ev_h2d);
         for (void *p : dp) if (p) (void)hipFree(p);

@@ -216,10 +216,12 @@ inline size_t k2_walk_lds_bytes(uint32_t hist_words)
 
 // K3: dynamic LDS = the rows of the bitstream the windows of one hit-word can touch (its own row + the packet's reach
 // + one word of funnel shift), in words
-inline size_t k3_lds_bytes(const SearchGeom &g)
+// + (validation on) room for the packets of 256 hits and the one before them, which K5's test reads from LDS
+inline size_t k3_lds_bytes(const SearchGeom &g, bool validate = false)
 {
     const size_t n_rows = 1 + (((size_t)g.packet_symbols * g.symbol_length + 32 + g.block_size - 1) >> g.lg_block_size);
-    return (n_rows * g.wpb + 4) * 4;
+    const size_t rows = (n_rows * g.wpb + 4) * 4, pk = validate && g.packet_symbols <= 128 ? 257 * (size_t)g.pkt_bytes : 0;
+    return rows > pk ? rows : pk;
 }
 
 constexpr int kListCap = 448;  // k2_search_fast: (key, mask) entries per wave

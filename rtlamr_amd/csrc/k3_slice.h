@@ -2,6 +2,7 @@
 // as a kernel of its own (callers that do not pipeline), the completion ticket, the test helper that untiles the bitstream.
 #pragma once
 #include "k2_common.h"
+#include "k5_validate.h"
 
 namespace amr {
 
@@ -35,6 +36,13 @@ struct K3Args {
     uint32_t n_tiles;
     uint32_t cap;
     SearchGeom g;
+    // K5 (k5_validate.h) as the last stage of the workgroup: keep == nullptr = off
+    uint8_t *keep;              // [out_cap] 1 = the hit passes its preamble's rule
+    uint32_t *listcnt;          // [n_pre][n_tiles] survivors of every list
+    uint64_t *listoff;          // [n_pre][n_tiles] slot of every non-empty list in the packed result
+    uint32_t *vgcnt;            // [n_pre][n_groups] survivors summed over groups of 64 tiles (atomicAdd; zero before K3 runs)
+    uint32_t lds_bytes;         // dynamic LDS of the launch (k3_lds_bytes)
+    ValRule rule[AMR_MAX_PREAMBLES];
 };
 
 // K3 slices by bitstream word, not by hit, out of LDS copies of the few rows a run of hits needs.
@@ -56,10 +64,10 @@ struct K3Args {
 // LDS ONCE, in stream order (16-byte pieces, neighbouring rows share their lines), and the windows of every hit that
 // starts in row l are taken from there.
 //
-// One workgroup per (tile, preamble) list (grid (n_tiles, n_pre); with a grid of (n_tiles, 1) a workgroup takes all lists
-// of its tile and stages a row once for all of them: measured slower, see enqueue_tail).  Its prologue: the slot of
-// a list in the packed result = the hits of all lists before it (preamble-major), and the layout needs the grand total.  No scan kernel between K2 and K3 (a dispatch costs the stream
-// ~5 us): K2 left sums over groups of 64 tiles; the workgroup scans them (32-bit DPP scan inside a wave -- a wave's 64
+// One workgroup per (tile, preamble) list, grid (n_tiles, n_pre) (a workgroup that took all lists of its tile and staged
+// a row once for all of them measured slower: 188 against 173 us per 4 GiB of the four-preamble decoder).  Its prologue:
+// the slot of a list in the packed result = the hits of all lists before it (preamble-major), and the layout needs the
+// grand total.  No scan kernel between K2 and K3 (a dispatch costs the stream ~5 us): K2 left sums over groups of 64 tiles; the workgroup scans them (32-bit DPP scan inside a wave -- a wave's 64
 // group sums stay below 2^31 -- the few wave totals in 64 bits) and adds the <= 63 counts before it inside its group.
 // Tile 0's workgroup publishes the per-preamble bases, the total and K2's overflow word.
 // Input: positions in the staging slots, ascending; output: the packed result (K3Args).  Dynamic LDS: k3_lds_bytes().
@@ -87,19 +95,40 @@ __device__ __forceinline__ uint32_t k3_wave_scan(uint32_t x)
     return x;
 }
 
+#ifndef AMR_K3_DBG
+#define AMR_K3_DBG 0        // diagnostic builds: 100 MHz time stamps of every workgroup's phases, printed by amr_destroy
+#endif
+#if AMR_K3_DBG
+__device__ unsigned long long k3_dbg[4096 * 8];
+#define K3_STAMP(i) do { if (tid == 0 && blockIdx.x < 4096 && blockIdx.y == 0) k3_dbg[blockIdx.x * 8 + (i)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#else
+#define K3_STAMP(i) do { } while (0)
+#endif
+
+// Workgroup barrier that orders LDS traffic only.  __syncthreads() also waits for every global store of the wave to be
+// acknowledged (vmcnt(0)): behind the slicing that is the drain of all packet stores of the chip's workgroups at once,
+// 15 us that a workgroup which only goes on to read LDS does not owe.
+__device__ __forceinline__ void k3_lds_barrier()
+{
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+
 constexpr int kK3Batch = 4;    // words (entries) a wave works on together
 constexpr int kK3List = 512;   // positions of a list held in LDS at a time (long packets): 2 KiB, eight workgroups still fit a CU
 
 // 64 hits of one list (src[i0 .. i0 + 64) below i_hi) by one wave: their (call, idx) records and the packets of every word
 // that holds some of them.  STAGED: the windows come from rows_lds (stream order, bit 31 of word 0 = tile-local bit
-// base_bit), else from the tiled bitstream at tbase.  Symbols [p_first, PS) in steps of 128 (p_step).
+// base_bit), else from the tiled bitstream at tbase.  Symbols [p_first, PS) in steps of 128 (p_step).  pk_lds (not
+// STAGED, packets of whole dwords): a second copy of the packets of list entries below pk_hits, entry i at pk_lds + i * PB,
+// and of their positions in pos_lds.
 template <bool STAGED>
 __device__ __forceinline__ void k3_chunk(const K3Args &a, const SearchGeom &g, uint32_t T, const uint32_t *src, uint32_t i0, uint32_t i_hi,
                                          uint32_t i_lo, uint32_t wv, uint64_t off, uint64_t total, uint32_t (&tab)[kK3Batch][32],
                                          const uint32_t *rows_lds, const uint32_t *__restrict__ tbase, uint32_t base_bit,
-                                         uint32_t p_first, bool by_symbols, uint32_t i_out0)
+                                         uint32_t p_first, bool by_symbols, uint32_t i_out0, uint32_t tid, uint8_t *pk_lds = nullptr, uint32_t pk_hits = 0,
+                                         uint32_t *pos_lds = nullptr)
 {
-    const uint32_t lane = threadIdx.x & 63, l32 = lane & 31, half = lane >> 5;
+    const uint32_t lane = tid & 63, l32 = lane & 31, half = lane >> 5;
     const uint32_t lg_bs = g.lg_block_size, bs_mask = g.block_size - 1, lg_tw = 6 + g.lg_wpb;
     const uint32_t PS = g.packet_symbols, SL = g.symbol_length, PB = g.pkt_bytes;
     const bool dword_ok = (PB & 3) == 0 && (PS & 7) == 0;
@@ -118,6 +147,7 @@ __device__ __forceinline__ void k3_chunk(const K3Args &a, const SearchGeom &g, u
     const bool have = i < i_hi;
     const uint32_t local = have ? src[i] : 0xffffffffu;
     const bool ok = have && local < bad;
+    if (!STAGED && have && i < pk_hits) pos_lds[i] = local;           // K5's test wants the positions again
     if (ok && (!by_symbols || wv == (((i0 - i_lo) >> 6) & 3u))) {      // by symbols: four waves see the chunk, one writes
         const int64_t n = ((int64_t)T * 64 - 64) * (int64_t)g.block_size + local;
         const uint64_t pos = (uint64_t)(n + g.packet_length);
@@ -172,6 +202,8 @@ __device__ __forceinline__ void k3_chunk(const K3Args &a, const SearchGeom &g, u
                         uint8_t *out = pkt + (off + slot[e]) * (uint64_t)PB;
                         if (b0 + 4 <= PB && dword_ok) {
                             *reinterpret_cast<uint32_t *>(out + b0) = Y;
+                            // K5's test follows in this workgroup: it reads the packets of the list's first pk_hits hits here
+                            if (!STAGED && slot[e] < pk_hits) *reinterpret_cast<uint32_t *>(pk_lds + slot[e] * PB + b0) = Y;
                         } else {
 #pragma unroll
                             for (uint32_t j = 0; j < 4; ++j) {
@@ -190,82 +222,215 @@ __device__ __forceinline__ void k3_chunk(const K3Args &a, const SearchGeom &g, u
     }
 }
 
-__global__ __launch_bounds__(256, 8) void k3_slice_words(const K3Args a)   // 8 workgroups per CU: 64 VGPRs (65 without the hint: 7)
+// Where the list (tile T, preamble q) lies among all lists, preamble-major, from per-list counts [n_pre][n_tiles] and
+// their sums over groups of 64 tiles [n_pre][n_groups]: S.off[q] = the counts of every list in front of q's group of T
+// (S.off[n_pre] = the grand total), S.in[q] = the counts of T's group in front of T, S.cnt[q] = the list's own count,
+// for every preamble q.  By a workgroup of 256 threads; ends with a barrier.
+struct K3Scan {
+    static constexpr uint32_t kRounds = 16;      // rounds whose totals are kept in LDS at a time (1024 sums)
+    uint64_t off[kMaxPre + 1];
+    uint32_t cnt[kMaxPre], in[kMaxPre], prev[kMaxPre];   // prev: the count of tile T-1's list
+    uint32_t round[kRounds], excl[kMaxPre], excl_round[kMaxPre];
+};
+
+__device__ __forceinline__ void k3_list_scan(K3Scan &S, const uint32_t *counts, const uint32_t *gcnt, uint32_t n_tiles, uint32_t n_pre, uint32_t T, uint32_t tid)
 {
-    const SearchGeom &g = a.g;
-    const uint32_t T = blockIdx.x;
-    const uint32_t n_pre = g.n_pre;
-    const uint32_t lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    __shared__ uint64_t s_off[kMaxPre + 1];     // slot of this tile's list per preamble; [n_pre] = the grand total
-    __shared__ uint32_t s_cnt[kMaxPre];
-    __shared__ uint32_t s_in[kMaxPre];          // hits of the tile's group in front of the tile, per preamble
-    __shared__ uint32_t tab[4][kK3Batch][32];   // per wave and entry: staging index of the hit at bit b of the word, or ~0
-    __shared__ uint32_t s_list[kK3List];        // long packets: the segment of the list being sliced
-    extern __shared__ __attribute__((aligned(16))) uint32_t rows_lds[];          // [n_rows][wpb] words, stream order
-
-    // one list per workgroup and the list is empty (three of four in "all", where only scm+ finds hits in noise): nothing to
-    // place, nothing to slice -- leave before the prologue's loads and barriers.  Tile 0's first workgroup stays: it
-    // publishes the bases, the total and the overflow word.
-    if (gridDim.y > 1 && a.counts[blockIdx.y * a.n_tiles + T] == 0 && !(T == 0 && blockIdx.y == 0)) return;
-
-    // ---- prologue ----
-    const uint32_t n_groups = k2_groups(a.n_tiles), n_sums = n_pre * n_groups;
-    const uint32_t ovf = *a.overflow;
+    const uint32_t lane = tid & 63, wv = tid >> 6;
+    const uint32_t n_groups = k2_groups(n_tiles), n_sums = n_pre * n_groups;
+    const uint32_t v_first = wv * 64 + lane < n_sums ? gcnt[wv * 64 + lane] : 0u;   // this wave's first round, in flight with the counts
     for (uint32_t q = wv; q < n_pre; q += 4) {           // wave q: the counts of preamble q in this tile's group, up to the tile
         const uint32_t t = lane;
-        const uint32_t c = t < (T & 63) ? a.counts[q * a.n_tiles + (T & ~63u) + t] : 0u;
-        const uint32_t mine = a.counts[q * a.n_tiles + T];
+        const uint32_t c = t < (T & 63) ? counts[q * n_tiles + (T & ~63u) + t] : 0u;
+        const uint32_t mine = counts[q * n_tiles + T], before = T ? counts[q * n_tiles + T - 1] : 0u;
         const uint32_t inc = k3_wave_scan(c);
-        if (lane == 63) { s_in[q] = inc; s_cnt[q] = mine; }
+        if (lane == 63) { S.in[q] = inc; S.cnt[q] = mine; S.prev[q] = before; }
     }
     // exclusive scan over the flattened group sums [n_pre][n_groups] in rounds of 64, dealt to the four waves so that
     // their loads are in flight together; round totals meet in LDS
-    constexpr uint32_t kRounds = 16;                     // rounds whose totals are kept in LDS at a time (1024 sums)
-    __shared__ uint32_t s_round[kRounds];
-    __shared__ uint32_t s_excl[kMaxPre], s_excl_round[kMaxPre];
     const uint32_t n_rounds = (n_sums + 63) >> 6;
     uint64_t carry = 0;                                  // workgroup-uniform: sums of the passes before this one
-    if (threadIdx.x < kMaxPre) s_excl_round[threadIdx.x] = 0xffffffffu;
-    for (uint32_t r0 = 0; r0 < n_rounds; r0 += kRounds) {          // one pass unless a batch has more than 1024 group sums
+    if (tid < kMaxPre) S.excl_round[tid] = 0xffffffffu;
+    for (uint32_t r0 = 0; r0 < n_rounds; r0 += K3Scan::kRounds) {  // one pass unless a batch has more than 1024 group sums
         __syncthreads();
-        for (uint32_t r = r0 + wv; r < n_rounds && r < r0 + kRounds; r += 4) {
+        for (uint32_t r = r0 + wv; r < n_rounds && r < r0 + K3Scan::kRounds; r += 4) {
             const uint32_t i = r * 64 + lane;
-            const uint32_t v = i < n_sums ? a.gcnt[i] : 0u;
+            const uint32_t v = r == wv ? v_first : i < n_sums ? gcnt[i] : 0u;
             const uint32_t inc = k3_wave_scan(v);
             for (uint32_t q = 0; q < n_pre; ++q)         // the sums of this round before (q, this tile's group)
-                if (q * n_groups + (T >> 6) == i) { s_excl[q] = inc - v; s_excl_round[q] = r; }
-            if (lane == 63) s_round[r - r0] = inc;
+                if (q * n_groups + (T >> 6) == i) { S.excl[q] = inc - v; S.excl_round[q] = r; }
+            if (lane == 63) S.round[r - r0] = inc;
         }
         __syncthreads();
-        if (threadIdx.x <= n_pre) {                      // thread q: the rounds in front of its round, 64 bits from here on
-            const uint32_t q = threadIdx.x;
-            const uint32_t my_r = q < n_pre ? s_excl_round[q] : 0xffffffffu;
+        if (tid <= n_pre) {                      // thread q: the rounds in front of its round, 64 bits from here on
+            const uint32_t q = tid;
+            const uint32_t my_r = q < n_pre ? S.excl_round[q] : 0xffffffffu;
             uint64_t run = carry;
-            for (uint32_t r = r0; r < n_rounds && r < r0 + kRounds; ++r) {
-                if (r == my_r) s_off[q] = run + s_excl[q];
-                run += s_round[r - r0];
+            for (uint32_t r = r0; r < n_rounds && r < r0 + K3Scan::kRounds; ++r) {
+                if (r == my_r) S.off[q] = run + S.excl[q];
+                run += S.round[r - r0];
             }
-            if (q == n_pre) s_off[n_pre] = run;          // the total so far
+            if (q == n_pre) S.off[n_pre] = run;          // the total so far
         }
         __syncthreads();
-        carry = s_off[n_pre];
+        carry = S.off[n_pre];
     }
     __syncthreads();
-    const uint64_t total = s_off[n_pre];
-    if (T == 0 && blockIdx.y == 0 && threadIdx.x <= n_pre) {
-        const uint64_t v = threadIdx.x < n_pre ? s_off[threadIdx.x] : total;      // tile 0: nothing of its group in front of it
-        a.offs_pre[threadIdx.x] = v;
-        a.h_offs_pre[threadIdx.x] = v;
-        if (threadIdx.x == 0) *a.h_overflow = ovf;
+}
+
+// K5's test (k5_validate.h) of the `cnt` hits of list (T, q), which this workgroup has just written to slots off.. of the
+// packed result: keep[] per hit, the number of survivors to listcnt / vgcnt, the list's slot to listoff (k5_compact
+// works from those).  tbl: 1 KiB of LDS nobody else uses any more, pk_lds: the launch's dynamic LDS (same).  Ends in no
+// barrier; call with all 256 threads.
+//
+// "The hit right before it in the same (preamble, block) list" of the list's FIRST hit is the last hit of tile T-1's
+// list -- written by another workgroup, maybe not yet.  Two hits share a Decode call only if they are less than a block
+// apart, so only that one hit can matter, and only when both map to the same call; then the two packets are compared
+// where they come from, symbol by symbol in the bitstream (equal first dedupe_bytes bytes = equal first 8 x
+// dedupe_bytes symbols: Decoder.Slice fills bytes with consecutive symbols, decode.go:363-366).
+__device__ __forceinline__ void k5_flag_list(const K3Args &a, const ValRule &r, const SearchGeom &g, uint32_t T, uint32_t q, uint32_t cnt, uint64_t off,
+                                             uint64_t total, uint16_t (*tbl)[256], uint32_t *s_red, uint8_t *pk_lds, const uint32_t *pos_lds, bool direct, bool edge, uint32_t lp, uint32_t lm, uint32_t tid)
+{
+    const uint32_t lane = tid & 63, wv = tid >> 6;
+    const uint32_t PB = g.pkt_bytes, lg_bs = g.lg_block_size, lg_tw = 6 + g.lg_wpb;
+    k5_tables(r, tbl, tid);
+    int first_same = 0;                                   // workgroup-uniform
+    if (edge) {     // lp, lm: the last position of tile T-1's list, the first of this one (loaded before the slicing)
+        {
+            const uint32_t bad = 64u << lg_bs;
+            // same Decode call: (n + PacketLength) >> lg BS agree; n = (64 T - 64) BS + local
+            const int64_t pp = ((int64_t)T * 64 - 128) * (int64_t)g.block_size + lp + g.packet_length;
+            const int64_t pm = ((int64_t)T * 64 - 64) * (int64_t)g.block_size + lm + g.packet_length;
+            if (lp < bad && lm < bad && (pp >> lg_bs) == (pm >> lg_bs)) {
+                const uint32_t n_sym = (uint32_t)r.dedupe_bytes * 8 < g.packet_symbols ? (uint32_t)r.dedupe_bytes * 8 : g.packet_symbols;
+                auto bit_at = [&](uint32_t tile, uint32_t v) {            // stream bit v counted from row 0 of `tile`
+                    const uint32_t *tb = a.qt + ((size_t)tile << lg_tw);
+                    const uint32_t row = v >> lg_bs, w = (v & (g.block_size - 1)) >> 5;
+                    return (tb[((size_t)(row >> 6) << lg_tw) + ((w >> 2) << 8) + ((row & 63) << 2) + (w & 3)] >> (31 - (v & 31))) & 1u;
+                };
+                int differ = 0;
+#pragma clang loop vectorize(disable) interleave(disable) unroll(disable)
+                for (uint32_t p = tid; p < n_sym; p += 256)
+                    differ |= (int)(bit_at(T - 1, lp + p * g.symbol_length) ^ bit_at(T, lm + p * g.symbol_length));
+                if (tid == 0) s_red[0] = 0;
+                k3_lds_barrier();
+                if (differ) s_red[0] = 1;
+                k3_lds_barrier();
+                first_same = !s_red[0];
+            }
+        }
+    }
+    K3_STAMP(4);
+    // The packets come through LDS, a round of up to 256 hits (and the hit in front of them) at a time: the first round
+    // of a short-packet list as the slicing left them there (`direct`), the others in one coalesced copy with every load
+    // in flight; the byte reads of the checks then run at LDS latency.
+    const uint8_t *pkts = a.out + total * 12;
+    const uint32_t *src = a.staging + ((size_t)T * g.n_pre + q) * a.cap;
+    const uint32_t room = a.lds_bytes / PB - 1, per = room < 256u ? room : 256u;
+    const bool words = (PB & 3) == 0;
+    uint32_t kept = 0;
+    // hit j of the list, packet at pkt (the one before it at pkt - PB), position sj (the one before it: sjm)
+    auto test = [&](uint32_t j, const uint8_t *pkt, uint32_t sj, uint32_t sjm) {
+        bool keep = k5_checks(r, tbl, pkt);
+        if (keep && r.dedupe_bytes > 0) {
+            if (j == 0) keep = !first_same;
+            else {
+                // same Decode call as the hit before it: (n + PacketLength) >> lg BS agree (the tile's base is a multiple of BS)
+                const uint32_t c0 = (sjm + g.packet_length) >> lg_bs, c1 = (sj + g.packet_length) >> lg_bs;
+                if (c0 == c1) {
+                    const uint8_t *prev = pkt - PB;
+                    bool same = true;
+#pragma clang loop vectorize(disable) interleave(disable)
+                    for (int i = 0; i < r.dedupe_bytes; ++i) same = same && prev[i] == pkt[i];
+                    keep = !same;
+                }
+            }
+        }
+        a.keep[off + j] = keep ? 1 : 0;
+        kept += keep ? 1u : 0u;
+    };
+    uint32_t j0 = 0;
+    if (direct) {
+        // No global load anywhere on this path: one would wait (vmcnt counts in order) until every packet store of the
+        // wave has been acknowledged -- with all workgroups of the chip storing at once, 5 to 15 us.
+        const uint32_t n = cnt < per ? cnt : per;
+        k3_lds_barrier();                                 // the tables
+        if (tid < n) test(tid, pk_lds + tid * PB, pos_lds[tid], tid ? pos_lds[tid - 1] : 0u);
+        j0 = n;
+        if (j0 >= cnt) goto counted;
+    }
+    __syncthreads();                                      // the four waves' packet stores have landed (and: the tables)
+#pragma clang loop vectorize(disable) interleave(disable) unroll(disable)
+    for (; j0 < cnt; j0 += per) {
+        const uint32_t n = cnt - j0 < per ? cnt - j0 : per, lo = j0 ? j0 - 1 : 0u;
+        const uint32_t n_bytes = (j0 + n - lo) * PB;
+        const uint8_t *from = pkts + (off + lo) * PB;
+        uint32_t sj = 0, sjm = 0;                         // this hit's position and the one before it, in flight during the copy
+        if (tid < n && r.dedupe_bytes > 0) { sj = src[j0 + tid]; sjm = j0 + tid ? src[j0 + tid - 1] : 0u; }
+        k3_lds_barrier();                                 // the previous round has been read
+        if (words) {
+#pragma clang loop vectorize(disable) interleave(disable) unroll(disable)
+            for (uint32_t t = tid; t < n_bytes / 4; t += 256) reinterpret_cast<uint32_t *>(pk_lds)[t] = reinterpret_cast<const uint32_t *>(from)[t];
+        } else {
+#pragma clang loop vectorize(disable) interleave(disable) unroll(disable)
+            for (uint32_t t = tid; t < n_bytes; t += 256) pk_lds[t] = from[t];
+        }
+        k3_lds_barrier();
+        if (tid < n) test(j0 + tid, pk_lds + (j0 + tid - lo) * PB, sj, sjm);
+    }
+counted:
+    for (int d = 32; d; d >>= 1) kept += __shfl_down(kept, d);
+    K3_STAMP(5);
+    k3_lds_barrier();                                     // first_same has been read
+    if (lane == 0) s_red[wv] = kept;
+    k3_lds_barrier();
+    if (tid == 0) {
+        const uint32_t n = s_red[0] + s_red[1] + s_red[2] + s_red[3];
+        a.listcnt[q * a.n_tiles + T] = n;
+        a.listoff[q * a.n_tiles + T] = off;
+        if (n) atomicAdd(&a.vgcnt[q * k2_groups(a.n_tiles) + (T >> 6)], n);
+    }
+}
+
+// one list = (tile T, preamble q), by a workgroup of 256 threads
+__device__ __forceinline__ void k3_one_list(const K3Args &a, uint32_t T, uint32_t q, K3Scan &S, uint32_t (&tab)[4][kK3Batch][32],
+                                            uint32_t *s_list, uint32_t *s_red, uint32_t *rows_lds, ValRule *s_rule, uint32_t tid)
+{
+    const SearchGeom &g = a.g;
+    const uint32_t n_pre = g.n_pre;
+    const uint32_t wv = tid >> 6;
+
+    // the list is empty (three of four in "all", where only scm+ finds hits in noise): nothing to place, nothing to slice
+    // -- leave before the prologue's loads and barriers.  Tile 0's first workgroup stays: it publishes the bases, the
+    // total and the overflow word.
+    if (a.counts[q * a.n_tiles + T] == 0 && !(T == 0 && q == 0)) {
+        if (a.keep && tid == 0) a.listcnt[q * a.n_tiles + T] = 0;
+        return;
+    }
+
+    K3_STAMP(0);
+    // ---- prologue ----
+    // K5's rule for this preamble, out of the kernel arguments into LDS NOW: indexed by q the compiler fetches its fields with
+    // vector loads, and a vector load behind the slicing waits for every packet store of the wave to drain first
+    static_assert(sizeof(ValRule) == 40, "ten words");
+    if (a.keep && tid < 10) reinterpret_cast<uint32_t *>(s_rule)[tid] = reinterpret_cast<const uint32_t *>(&a.rule[q])[tid];
+    const uint32_t ovf = *a.overflow;
+    k3_list_scan(S, a.counts, a.gcnt, a.n_tiles, n_pre, T, tid);
+    const uint64_t total = S.off[n_pre];
+    if (T == 0 && q == 0 && tid <= n_pre) {
+        const uint64_t v = tid < n_pre ? S.off[tid] : total;      // tile 0: nothing of its group in front of it
+        a.offs_pre[tid] = v;
+        a.h_offs_pre[tid] = v;
+        if (tid == 0) *a.h_overflow = ovf;
     }
     // After an overflow the staging slots are incomplete (a wave whose sparse list overflowed counted hits it never
     // emitted): their contents must not be used as positions; the host re-runs the search anyway.
     if (ovf || total > a.out_cap) return;                // ... or grows the buffer and searches again
-    // gridDim.y == 1: this workgroup takes every preamble's list of the tile; == n_pre: one list per workgroup (A/B)
-    const uint32_t q_lo = gridDim.y > 1 ? blockIdx.y : 0u, q_hi = gridDim.y > 1 ? blockIdx.y + 1u : n_pre;
-    uint32_t any = 0;
-    for (uint32_t q = q_lo; q < q_hi; ++q) any |= s_cnt[q];
-    if (!any) return;
+    K3_STAMP(1);
+    const uint32_t cnt = S.cnt[q];
+    if (!cnt) {
+        if (a.keep && tid == 0) a.listcnt[q * a.n_tiles + T] = 0;
+        return;
+    }
 
     const uint32_t *__restrict__ tbase = a.qt + ((size_t)T << (6 + g.lg_wpb));
     const uint32_t lg_bs = g.lg_block_size, lg_tw = 6 + g.lg_wpb;
@@ -274,36 +439,41 @@ __global__ __launch_bounds__(256, 8) void k3_slice_words(const K3Args a)   // 8 
     const uint32_t wpb = g.wpb, cpr = wpb >> 2;
     const uint32_t n_rows = 1 + ((PS * SL + 32 + g.block_size - 1) >> lg_bs);     // rows a hit-word's windows can touch
     const bool by_symbols = PS > 128;                  // long packets (idm, netidm, "all"): rows staged in LDS
-
-    // ---- short packets (scm, scm+, r900 geometries: at most 128 symbols): the windows straight from the tiled bitstream.
-    // A packet's reach is a few KB of stream; staging rows for it costs more than the line fetches it saves (1 GiB of scm:
-    // 32 us staged against 16-25 us direct).
-    if (!by_symbols) {
-#pragma unroll 1
-        for (uint32_t q = q_lo; q < q_hi; ++q) {
-            const uint32_t cnt = s_cnt[q];
-            const uint32_t *src = a.staging + ((size_t)T * n_pre + q) * a.cap;
-            const uint64_t off = s_off[q] + s_in[q];
-            for (uint32_t i0 = wv * 64; i0 < cnt; i0 += 256)
-                k3_chunk<false>(a, g, T, src, i0, cnt, 0u, wv, off, total, tab[wv], nullptr, tbase, 0u, 0u, false, 0u);
-        }
-        return;
+    const uint32_t *src = a.staging + ((size_t)T * n_pre + q) * a.cap;
+    const uint64_t off = S.off[q] + S.in[q];
+    // K5's look across the tile boundary (k5_flag_list): the two positions it needs are on their way during the slicing
+    const bool edge = a.keep && T > 0 && S.prev[q] && s_rule->dedupe_bytes > 0;
+    // short packets of whole dwords: the slicing leaves a copy of the first 256 packets in LDS for K5's test
+    const uint32_t pk_hits = a.keep && !by_symbols && (g.pkt_bytes & 3) == 0 && (PS & 7) == 0 ? 256u : 0u;
+    uint32_t edge_lp = 0, edge_lm = 0;
+    if (edge) {
+        const uint32_t c_prev = S.prev[q] < a.cap ? S.prev[q] : a.cap;
+        edge_lp = a.staging[((size_t)(T - 1) * n_pre + q) * a.cap + c_prev - 1];
+        edge_lm = src[0];
     }
 
-    // ---- long packets, row by row.  The list comes into LDS first, a segment of kK3List positions at a time: what row
-    // to stage next and where the hits of that row end are then LDS reads.  (Taken from global memory, every such
-    // decision was a dependent load in front of the next row set -- the staging slot's first unsliced entry, then a
-    // binary search -- 4 to 5 us per row set next to 2 us of staging and 1 us of slicing; "all" has 8 lone scm+ noise
-    // hits per tile, each a row set of its own: K3 184 us per 4 GiB, most of it these loads.) ----
-    for (uint32_t q = q_lo; q < q_hi; ++q) {
-        const uint32_t cnt = s_cnt[q];
-        const uint32_t *src = a.staging + ((size_t)T * n_pre + q) * a.cap;
-        const uint64_t off = s_off[q] + s_in[q];
+    if (!by_symbols) {
+        // ---- short packets (scm, scm+, r900 geometries: at most 128 symbols): the windows straight from the tiled
+        // bitstream.  A packet's reach is a few KB of stream; staging rows for it costs more than the line fetches it
+        // saves (1 GiB of scm: 32 us staged against 16-25 us direct).
+        // The list in equal shares for the four waves (at most 64 hits at a time): a wave slices word by word, four words
+        // per round of dependent loads, and noise hits sit one to a word -- 142 hits (1 GiB of scm: the average list) dealt
+        // as 64 + 64 + 14 + 0 took 16 rounds, as 36 + 36 + 36 + 34 they take 9.
+        const uint32_t share = cnt >= 256 ? 64u : (cnt + 3) >> 2;
+        for (uint32_t i0 = wv * share; i0 < cnt; i0 += 4 * share)
+            k3_chunk<false>(a, g, T, src, i0, i0 + share < cnt ? i0 + share : cnt, 0u, wv, off, total, tab[wv], nullptr, tbase, 0u, 0u, false, 0u, tid,
+                            reinterpret_cast<uint8_t *>(rows_lds), pk_hits, s_list);
+    } else {
+        // ---- long packets, row by row.  The list comes into LDS first, a segment of kK3List positions at a time: what
+        // row to stage next and where the hits of that row end are then LDS reads.  (Taken from global memory, every such
+        // decision was a dependent load in front of the next row set -- the staging slot's first unsliced entry, then a
+        // binary search -- 4 to 5 us per row set next to 2 us of staging and 1 us of slicing; "all" has 8 lone scm+ noise
+        // hits per tile, each a row set of its own: K3 184 us per 4 GiB, most of it these loads.) ----
         for (uint32_t seg0 = 0; seg0 < cnt; seg0 += kK3List) {
             const uint32_t seg_n = cnt - seg0 < (uint32_t)kK3List ? cnt - seg0 : (uint32_t)kK3List;
-            __syncthreads();                                                    // the previous segment has been consumed
-            for (uint32_t t = threadIdx.x; t < seg_n; t += 256) s_list[t] = src[seg0 + t];
-            __syncthreads();
+            k3_lds_barrier();                                                    // the previous segment has been consumed
+            for (uint32_t t = tid; t < seg_n; t += 256) s_list[t] = src[seg0 + t];
+            k3_lds_barrier();
             uint32_t cur = 0;                                                   // workgroup-uniform: first entry not sliced yet
             while (cur < seg_n) {
                 const uint32_t first = s_list[cur];
@@ -316,24 +486,135 @@ __global__ __launch_bounds__(256, 8) void k3_slice_words(const K3Args a)   // 8 
                     if (s_list[mid] < lim) lo = mid + 1; else hi = mid;
                 }
                 const uint32_t i_hi = lo;
-                __syncthreads();                                                // the previous row set has been consumed
-                for (uint32_t t = threadIdx.x; t < n_rows * cpr; t += 256) {
+                k3_lds_barrier();                                                // the previous row set has been consumed
+                for (uint32_t t = tid; t < n_rows * cpr; t += 256) {
                     const uint32_t c = t / n_rows, r = t - c * n_rows, row = l0 + r;     // neighbouring threads: neighbouring rows of one chunk
                     const uint4 x = *reinterpret_cast<const uint4 *>(tbase + ((size_t)(row >> 6) << lg_tw) + ((size_t)c << 8) + ((row & 63) << 2));
                     *reinterpret_cast<uint4 *>(rows_lds + r * wpb + c * 4) = x;
                 }
-                __syncthreads();
+                k3_lds_barrier();
                 const uint32_t base_bit = l0 << lg_bs;                          // stream bit (tile-local) of rows_lds[0], bit 31
                 // the four waves share a 64-hit chunk by SYMBOLS: the hits of a packet are one run of ~70 positions, i.e. one
                 // wave's worth, and 736 symbols in one wave are six rounds one after the other while three waves watch
                 for (uint32_t i0 = cur; i0 < i_hi; i0 += 64)
-                    k3_chunk<true>(a, g, T, s_list, i0, i_hi, cur, wv, off, total, tab[wv], rows_lds, tbase, base_bit, wv * 128, true, seg0);
+                    k3_chunk<true>(a, g, T, s_list, i0, i_hi, cur, wv, off, total, tab[wv], rows_lds, tbase, base_bit, wv * 128, true, seg0, tid);
                 cur = i_hi;
             }
         }
     }
+    K3_STAMP(2);
+    if (!a.keep) return;
+    // ---- K5's test of the list, on the packets just written; the CRC tables take the place of the slicing tables
+    k3_lds_barrier();
+    K3_STAMP(3);
+    k5_flag_list(a, *s_rule, g, T, q, cnt, off, total, reinterpret_cast<uint16_t (*)[256]>(&tab[0][0][0]), s_red, reinterpret_cast<uint8_t *>(rows_lds), s_list,
+                 pk_hits != 0, edge, edge_lp, edge_lm, tid);
+    K3_STAMP(6);
 }
 
+// grid (n_tiles - 1, n_pre): workgroup x takes the list of tile x + 1, workgroup 0 afterwards that of tile 0 as well -- the
+// history tile, whose only hits are packets that START in the previous batch's last rows: a short list.  (A chip holds
+// 2048 of these workgroups; 1 GiB of scm is 2048 tiles + the history tile, and a 2049th workgroup of its own waited for
+// the first of the others to end: K3 took twice a workgroup's life.)
+__global__ __launch_bounds__(256, 8) void k3_slice_words(const K3Args a)   // 8 workgroups per CU: 64 VGPRs (65 without the hint: 7)
+{
+    __shared__ K3Scan S;
+    __shared__ uint32_t tab[4][kK3Batch][32];   // per wave and entry: staging index of the hit at bit b of the word, or ~0
+    __shared__ uint32_t s_list[kK3List];        // long packets: the segment of the list being sliced
+    __shared__ uint32_t s_red[4];
+    __shared__ ValRule s_rule;
+    extern __shared__ __attribute__((aligned(16))) uint32_t rows_lds[];          // [n_rows][wpb] words, stream order; K5: packets
+    const uint32_t passes = blockIdx.x == 0 ? 2u : 1u;
+#pragma clang loop unroll(disable)
+    for (uint32_t pass = 0; pass < passes; ++pass) {
+        if (pass) __syncthreads();
+        // the thread index through an opaque move: whatever the list code derives from it is computed per pass, in place,
+        // instead of being hoisted out of this loop to live (and spill) across all of it
+        uint32_t tid = threadIdx.x;
+        asm volatile("" : "+v"(tid));
+        k3_one_list(a, pass ? 0u : blockIdx.x + 1u, blockIdx.y, S, tab, s_list, s_red, rows_lds, &s_rule, tid);
+    }
+}
+
+// K5, second half: the survivors of every list move to their slot in a second packed buffer of K3's layout, in order.
+// Same grid as K3, one workgroup per list (workgroup 0: two); the slot = the survivors of all lists in front (k3_list_scan over listcnt /
+// vgcnt, as K3 places the hits themselves).
+struct K5Args {
+    const uint8_t *in;          // K3's packed result [hit_block u64 x n | hit_idx u32 x n | pkt x n]
+    uint8_t *out;               // same layout, n' = surviving hits
+    const uint64_t *offs_pre;   // [n_pre+1] from k3_slice
+    uint64_t *offs_val;         // [n_pre+1] offsets into the validated list (device)
+    uint64_t *h_offs_val;       // the same in pinned host memory
+    const uint8_t *keep;        // [cap] from K3's last stage
+    const uint32_t *counts;     // [n_pre][n_tiles] hits per list (K2)
+    const uint32_t *listcnt;    // [n_pre][n_tiles] survivors per list
+    const uint64_t *listoff;    // [n_pre][n_tiles] slot of the list in `in`
+    const uint32_t *vgcnt;      // [n_pre][n_groups] survivors per group of 64 tiles
+    const uint32_t *overflow;   // K2's overflow word: the host searches again, nothing here is used
+    uint64_t cap;               // hits the buffers hold
+    uint32_t n_pre, n_tiles, pkt_bytes;
+};
+
+__device__ __forceinline__ void k5_compact_list(const K5Args &a, uint32_t T, uint32_t q, K3Scan &S, uint32_t *wcnt)
+{
+    const uint32_t n_pre = a.n_pre;
+    const uint32_t lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const bool first = T == 0 && q == 0;
+    const uint64_t total = a.offs_pre[n_pre];
+    if (*a.overflow != 0 || total > a.cap || total == 0) {
+        if (first && threadIdx.x <= n_pre) { a.offs_val[threadIdx.x] = 0; a.h_offs_val[threadIdx.x] = 0; }
+        return;
+    }
+    const uint32_t cnt = a.counts[q * a.n_tiles + T];
+    if (cnt == 0 && !first) return;
+    k3_list_scan(S, a.listcnt, a.vgcnt, a.n_tiles, n_pre, T, threadIdx.x);
+    const uint64_t kept = S.off[n_pre];
+    if (first && threadIdx.x <= n_pre) {                 // tile 0: nothing of its group in front of it
+        const uint64_t v = threadIdx.x < n_pre ? S.off[threadIdx.x] : kept;
+        a.offs_val[threadIdx.x] = v;
+        a.h_offs_val[threadIdx.x] = v;
+    }
+    if (cnt == 0 || S.cnt[q] == 0) return;
+    const uint64_t off = a.listoff[q * a.n_tiles + T];
+    uint64_t slot = S.off[q] + S.in[q];                  // of the list's next survivor
+    const uint64_t *ib = reinterpret_cast<const uint64_t *>(a.in);
+    const uint32_t *ii = reinterpret_cast<const uint32_t *>(a.in + total * 8);
+    uint64_t *ob = reinterpret_cast<uint64_t *>(a.out);
+    uint32_t *oi = reinterpret_cast<uint32_t *>(a.out + kept * 8);
+    for (uint32_t j0 = 0; j0 < cnt; j0 += 256) {
+        const uint32_t j = j0 + threadIdx.x;
+        const bool keep = j < cnt && a.keep[off + j] != 0;
+        const uint64_t m = __ballot(keep);
+        __syncthreads();                                  // wcnt of the previous round has been read
+        if (lane == 0) wcnt[wv] = (uint32_t)__popcll(m);
+        __syncthreads();
+        uint32_t before = 0, all = 0;
+        for (uint32_t i = 0; i < 4; ++i) { before += i < wv ? wcnt[i] : 0u; all += wcnt[i]; }
+        if (keep) {
+            const uint64_t rank = slot + before + (uint32_t)__popcll(m & ((1ull << lane) - 1));
+            const uint64_t gi = off + j;
+            const uint8_t *ip = a.in + total * 12 + gi * a.pkt_bytes;
+            uint8_t *op = a.out + kept * 12 + rank * a.pkt_bytes;
+            ob[rank] = ib[gi];
+            oi[rank] = ii[gi];
+            for (uint32_t i = 0; i < a.pkt_bytes; ++i) op[i] = ip[i];
+        }
+        slot += all;
+    }
+}
+
+// grid (n_tiles - 1, n_pre), tiles dealt to the workgroups as in k3_slice_words
+__global__ __launch_bounds__(256) void k5_compact(const K5Args a)
+{
+    __shared__ K3Scan S;
+    __shared__ uint32_t wcnt[4];
+    const uint32_t passes = blockIdx.x == 0 ? 2u : 1u;
+#pragma clang loop unroll(disable)
+    for (uint32_t pass = 0; pass < passes; ++pass) {
+        if (pass) __syncthreads();
+        k5_compact_list(a, pass ? 0u : blockIdx.x + 1u, blockIdx.y, S, wcnt);
+    }
+}
 
 // last kernel of a batch whose K3 (K4, K5) ran on the second stream: publishes the batch ticket
 __global__ void k_done(uint64_t *flag, uint64_t value, uint64_t *dev_flag)
