@@ -280,7 +280,7 @@ amr_status ensure_capacity(amr_handle *h, Slot &s, Slot &other, size_t n_blocks)
     const size_t st = bt + 1;                 // tiles searched
     {   // hipMalloc / hipFree wait for the whole device: with batches in flight, launch their pending K3.. first (see
         // sync_compute) -- this happens on the first use of each slot and when a batch is larger than any before
-        const uint32_t gw0 = 2 * (uint32_t)(amr::k2_groups((uint32_t)st) * h->sg.n_pre);
+        const uint32_t gw0 = 2 * amr::kGroupStride * (uint32_t)(amr::k2_groups((uint32_t)st) * h->sg.n_pre);
         const bool grows = bt + 2 > s.qt_tiles || !other.d_qt || st > s.cnt_tiles || gw0 > s.gcnt_words || gw0 > other.gcnt_words ||
                            st > s.staging_tiles || !s.d_out || (h->validate && !s.d_val);
         if (grows && h->n_pending) AMR_TRY(sync_compute(h));
@@ -294,7 +294,7 @@ amr_status ensure_capacity(amr_handle *h, Slot &s, Slot &other, size_t n_blocks)
     // group sums: this slot and the next one (the hist kernel of this batch zeroes those of the next), kept zero between
     // uses.  Neither holds a batch in flight; the slots that do keep what their own batch was sized for.
     // (two halves: the hits K2 counts, the survivors K3's last stage counts when validation is on)
-    const uint32_t gw = 2 * (uint32_t)(amr::k2_groups((uint32_t)st) * h->sg.n_pre);
+    const uint32_t gw = 2 * amr::kGroupStride * (uint32_t)(amr::k2_groups((uint32_t)st) * h->sg.n_pre);
     Slot *both[2] = {&s, &other};
     for (Slot *slp : both) {
         Slot &sl = *slp;
@@ -416,6 +416,9 @@ amr_status enqueue_tail(amr_handle *h, Slot &s, hipStream_t st, bool split)
     hipEvent_t k3e0 = (t2 && split) ? s.ev_t : nullptr, k3e1 = t2 ? s.ev2 : nullptr;
     const size_t k3lds = amr::k3_lds_bytes(h->sg, h->validate);
     k3.lds_bytes = (uint32_t)k3lds;
+#if AMR_K3_DBG
+    if (const char *e = getenv("AMR_K3_DBGF")) k3.dbg = (uint32_t)atoi(e);
+#endif
     HIP_TRY(hipFuncSetAttribute((const void *)amr::k3_slice_words, hipFuncAttributeMaxDynamicSharedMemorySize, (int)k3lds));
     // one workgroup per (tile, preamble) list; the kernel also takes a grid of (n_tiles, 1) = every list of a tile in one
     // workgroup with shared row staging, which measured slower on the four-preamble decoder (188 against 173 us per 4 GiB)
@@ -1069,6 +1072,7 @@ amr_status amr_destroy(amr_handle *h)
         (void)hipDeviceSynchronize();
         static unsigned long long hc[4096 * 8];
         if (hipMemcpyFromSymbol(hc, HIP_SYMBOL(amr::k3_dbg), sizeof hc) == hipSuccess) {
+            if (const char *fn = getenv("AMR_K3_DBG_FILE")) { if (FILE *f = fopen(fn, "wb")) { fwrite(hc, 1, sizeof hc, f); fclose(f); } }
             unsigned long long t0 = ~0ull, t1 = 0; int n = 0;
             for (int i = 1; i < 4096; ++i) if (hc[8 * i]) { t0 = std::min(t0, hc[8 * i]); for (int k = 0; k < 7; ++k) t1 = std::max(t1, hc[8 * i + k]); ++n; }
             double ph[7] = {}, mx[7] = {}, st_mx = 0, st_sum = 0;
@@ -1081,6 +1085,15 @@ amr_status amr_destroy(amr_handle *h)
                 const char *nm[7] = {"", "prologue", "slice", "barrier", "tables+edge", "rounds", "reduce"};
                 for (int k = 1; k < 7; ++k) fprintf(stderr, " %s %.2f/%.2f", nm[k], ph[k] / n * 0.01, mx[k] * 0.01);
                 fprintf(stderr, " (mean/max us)\n");
+                for (int rep = 0; rep < 8; ++rep) {      // the slowest workgroups
+                    int best = -1; unsigned long long bt = 0;
+                    for (int i = 1; i < 4096; ++i) if (hc[8 * i]) { unsigned long long e = 0; for (int k = 0; k < 7; ++k) e = std::max(e, hc[8 * i + k]); if (e - hc[8 * i] > bt) { bt = e - hc[8 * i]; best = i; } }
+                    if (best < 0) break;
+                    fprintf(stderr, "  wg %4d hits %4llu start %.2f:", best, hc[8 * best + 7], (double)(hc[8 * best] - t0) * 0.01);
+                    for (int k = 1; k < 7; ++k) fprintf(stderr, " %.2f", hc[8 * best + k] >= hc[8 * best + k - 1] ? (double)(hc[8 * best + k] - hc[8 * best + k - 1]) * 0.01 : -1.0);
+                    fprintf(stderr, "\n");
+                    hc[8 * best] = 0;
+                }
             }
         }
     }

@@ -134,7 +134,7 @@ __device__ __forceinline__ void hist_publish(const HistArgs &a)
 struct K2Args {
     const uint32_t *qt;    // tiled bitstream, tile 0 = history tile
     uint32_t *counts;      // [n_pre][n_tiles]
-    uint32_t *gcnt;        // [n_pre][n_groups] sums of counts over groups of 64 tiles (atomicAdd; zero before K2 runs)
+    uint32_t *gcnt;        // [n_pre][n_groups] sums of counts over groups of 64 tiles, kGroupStride words apart (atomicAdd; zero before K2 runs)
     uint32_t *staging;     // [n_tiles][n_pre][cap] tile-local positions (row*BS + bit), ascending
     uint32_t *overflow;    // set to 1 when a tile found more than cap hits for a preamble
     uint32_t n_tiles;      // tiles searched: ceil(n_blocks/64) + 1 (history tile first)
@@ -196,6 +196,14 @@ __device__ __forceinline__ uint32_t k2_word(const uint32_t *lds, uint32_t x, uin
 // The per-(preamble, tile) hit counts are also summed per group of 64 tiles, so that K3 finds the slot of a list in
 // the packed result from <= n_pre * n_groups + 63 values instead of a scan over all of them.
 __host__ __device__ __forceinline__ uint32_t k2_groups(uint32_t n_tiles) { return (n_tiles + 63) >> 6; }
+// Every group sum in a cache line of its own: sum i lives at word i * kGroupStride.  They are the targets of one
+// atomicAdd per list from workgroups that all finish at about the same time; packed (round 3: the 33 sums of 1 GiB of
+// scm in two lines) the 2048 additions queue up at one memory channel -- 12 us during which the stores of everybody
+// else's packets wait behind them (measured on K3's survivor sums, profiles/r04/k3_phases.txt).
+#ifndef AMR_GSTRIDE
+#define AMR_GSTRIDE 32
+#endif
+constexpr uint32_t kGroupStride = AMR_GSTRIDE;
 
 // k2_walk.h
 constexpr int kK2WTaps = 16;              // taps applied to every position

@@ -411,7 +411,7 @@ __global__ __launch_bounds__(64 * kK2WWaves, AMR_K2R_WPE) void k2_search_row(con
         if (h2 == 0) {
             const uint32_t c = tile_total < a.cap ? tile_total : a.cap;
             a.counts[T] = c;
-            if (c) atomicAdd(&a.gcnt[T >> 6], c);
+            if (c) atomicAdd(&a.gcnt[(T >> 6) * kGroupStride], c);
             if (tile_total > a.cap) atomicOr(a.overflow, 1u);
         }
         if (list_n > (uint32_t)kK2WList) atomicOr(a.overflow, 2u);

@@ -97,7 +97,7 @@ __global__ __launch_bounds__(256) void k2_search_dense(const K2Args a)
         if (q < (int)g.n_pre && tid == 0) {
             const uint32_t c = running[q] < a.cap ? running[q] : a.cap;
             a.counts[q * a.n_tiles + T] = c;
-            if (c) atomicAdd(&a.gcnt[q * k2_groups(a.n_tiles) + (T >> 6)], c);
+            if (c) atomicAdd(&a.gcnt[(q * k2_groups(a.n_tiles) + (T >> 6)) * kGroupStride], c);
             if (running[q] > a.cap) atomicOr(a.overflow, 1u);
         }
     }
@@ -350,7 +350,7 @@ __global__ __launch_bounds__(64 * NWV) void k2_search_fast(const K2Args a)
         for (int q = 0; q < NPRE; ++q) {
             const uint32_t c = total[q] < a.cap ? total[q] : a.cap;
             a.counts[q * a.n_tiles + T] = c;
-            if (c) atomicAdd(&a.gcnt[q * k2_groups(a.n_tiles) + (T >> 6)], c);
+            if (c) atomicAdd(&a.gcnt[(q * k2_groups(a.n_tiles) + (T >> 6)) * kGroupStride], c);
             if (total[q] > a.cap) atomicOr(a.overflow, 1u);
         }
     }

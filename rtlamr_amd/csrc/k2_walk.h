@@ -545,7 +545,7 @@ __global__ __launch_bounds__(64 * kK2WWaves) void k2_search_walk(const K2Args a)
             if (q >= (int)n_pre) break;
             const uint32_t c = total[q] < a.cap ? total[q] : a.cap;
             a.counts[q * a.n_tiles + T] = c;
-            if (c) atomicAdd(&a.gcnt[q * k2_groups(a.n_tiles) + (T >> 6)], c);
+            if (c) atomicAdd(&a.gcnt[(q * k2_groups(a.n_tiles) + (T >> 6)) * kGroupStride], c);
             if (total[q] > a.cap) atomicOr(a.overflow, 1u);
         }
         if (list_n > (uint32_t)kK2WList) atomicOr(a.overflow, 2u);

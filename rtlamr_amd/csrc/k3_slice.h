@@ -42,6 +42,7 @@ struct K3Args {
     uint64_t *listoff;          // [n_pre][n_tiles] slot of every non-empty list in the packed result
     uint32_t *vgcnt;            // [n_pre][n_groups] survivors summed over groups of 64 tiles (atomicAdd; zero before K3 runs)
     uint32_t lds_bytes;         // dynamic LDS of the launch (k3_lds_bytes)
+    uint32_t dbg;               // diagnostic builds (AMR_K3_DBG): switches for timing experiments
     ValRule rule[AMR_MAX_PREAMBLES];
 };
 
@@ -237,7 +238,7 @@ __device__ __forceinline__ void k3_list_scan(K3Scan &S, const uint32_t *counts, 
 {
     const uint32_t lane = tid & 63, wv = tid >> 6;
     const uint32_t n_groups = k2_groups(n_tiles), n_sums = n_pre * n_groups;
-    const uint32_t v_first = wv * 64 + lane < n_sums ? gcnt[wv * 64 + lane] : 0u;   // this wave's first round, in flight with the counts
+    const uint32_t v_first = wv * 64 + lane < n_sums ? gcnt[(wv * 64 + lane) * kGroupStride] : 0u;   // this wave's first round, in flight with the counts
     for (uint32_t q = wv; q < n_pre; q += 4) {           // wave q: the counts of preamble q in this tile's group, up to the tile
         const uint32_t t = lane;
         const uint32_t c = t < (T & 63) ? counts[q * n_tiles + (T & ~63u) + t] : 0u;
@@ -254,7 +255,7 @@ __device__ __forceinline__ void k3_list_scan(K3Scan &S, const uint32_t *counts, 
         __syncthreads();
         for (uint32_t r = r0 + wv; r < n_rounds && r < r0 + K3Scan::kRounds; r += 4) {
             const uint32_t i = r * 64 + lane;
-            const uint32_t v = r == wv ? v_first : i < n_sums ? gcnt[i] : 0u;
+            const uint32_t v = r == wv ? v_first : i < n_sums ? gcnt[i * kGroupStride] : 0u;
             const uint32_t inc = k3_wave_scan(v);
             for (uint32_t q = 0; q < n_pre; ++q)         // the sums of this round before (q, this tile's group)
                 if (q * n_groups + (T >> 6) == i) { S.excl[q] = inc - v; S.excl_round[q] = r; }
@@ -330,7 +331,11 @@ __device__ __forceinline__ void k5_flag_list(const K3Args &a, const ValRule &r, 
     uint32_t kept = 0;
     // hit j of the list, packet at pkt (the one before it at pkt - PB), position sj (the one before it: sjm)
     auto test = [&](uint32_t j, const uint8_t *pkt, uint32_t sj, uint32_t sjm) {
+#if AMR_K3_DBG
+        bool keep = (a.dbg & 8) ? true : k5_checks(r, tbl, pkt);
+#else
         bool keep = k5_checks(r, tbl, pkt);
+#endif
         if (keep && r.dedupe_bytes > 0) {
             if (j == 0) keep = !first_same;
             else {
@@ -387,7 +392,10 @@ counted:
         const uint32_t n = s_red[0] + s_red[1] + s_red[2] + s_red[3];
         a.listcnt[q * a.n_tiles + T] = n;
         a.listoff[q * a.n_tiles + T] = off;
-        if (n) atomicAdd(&a.vgcnt[q * k2_groups(a.n_tiles) + (T >> 6)], n);
+#if AMR_K3_DBG
+        if (a.dbg & 16) return;
+#endif
+        if (n) atomicAdd(&a.vgcnt[(q * k2_groups(a.n_tiles) + (T >> 6)) * kGroupStride], n);
     }
 }
 
@@ -425,8 +433,14 @@ __device__ __forceinline__ void k3_one_list(const K3Args &a, uint32_t T, uint32_
     // After an overflow the staging slots are incomplete (a wave whose sparse list overflowed counted hits it never
     // emitted): their contents must not be used as positions; the host re-runs the search anyway.
     if (ovf || total > a.out_cap) return;                // ... or grows the buffer and searches again
+#if AMR_K3_DBG
+    if (a.dbg & 32) __builtin_amdgcn_s_setprio(3);
+#endif
     K3_STAMP(1);
     const uint32_t cnt = S.cnt[q];
+#if AMR_K3_DBG
+    if (tid == 0 && blockIdx.x < 4096 && blockIdx.y == 0) k3_dbg[blockIdx.x * 8 + 7] = cnt;
+#endif
     if (!cnt) {
         if (a.keep && tid == 0) a.listcnt[q * a.n_tiles + T] = 0;
         return;
@@ -442,9 +456,17 @@ __device__ __forceinline__ void k3_one_list(const K3Args &a, uint32_t T, uint32_
     const uint32_t *src = a.staging + ((size_t)T * n_pre + q) * a.cap;
     const uint64_t off = S.off[q] + S.in[q];
     // K5's look across the tile boundary (k5_flag_list): the two positions it needs are on their way during the slicing
+#if AMR_K3_DBG
+    const bool edge = a.keep && !(a.dbg & 2) && T > 0 && S.prev[q] && s_rule->dedupe_bytes > 0;
+#else
     const bool edge = a.keep && T > 0 && S.prev[q] && s_rule->dedupe_bytes > 0;
+#endif
     // short packets of whole dwords: the slicing leaves a copy of the first 256 packets in LDS for K5's test
+#if AMR_K3_DBG
+    const uint32_t pk_hits = a.keep && !(a.dbg & 1) && !by_symbols && (g.pkt_bytes & 3) == 0 && (PS & 7) == 0 ? 256u : 0u;
+#else
     const uint32_t pk_hits = a.keep && !by_symbols && (g.pkt_bytes & 3) == 0 && (PS & 7) == 0 ? 256u : 0u;
+#endif
     uint32_t edge_lp = 0, edge_lm = 0;
     if (edge) {
         const uint32_t c_prev = S.prev[q] < a.cap ? S.prev[q] : a.cap;
@@ -502,8 +524,14 @@ __device__ __forceinline__ void k3_one_list(const K3Args &a, uint32_t T, uint32_
             }
         }
     }
+#if AMR_K3_DBG
+    if (a.dbg & 32) __builtin_amdgcn_s_setprio(0);
+#endif
     K3_STAMP(2);
     if (!a.keep) return;
+#if AMR_K3_DBG
+    if (a.dbg & 4) return;
+#endif
     // ---- K5's test of the list, on the packets just written; the CRC tables take the place of the slicing tables
     k3_lds_barrier();
     K3_STAMP(3);

@@ -78,7 +78,7 @@ static void run_row(const char *name, amr::K2Args a, uint32_t n_tiles, int reps,
     std::vector<float> ms;
     const uint32_t groups = k2_groups(n_tiles);
     for (int r = 0; r < reps + 30; ++r) {
-        CK(hipMemsetAsync(a.gcnt, 0, (size_t)groups * a.g.n_pre * 4, 0));
+        CK(hipMemsetAsync(a.gcnt, 0, (size_t)groups * a.g.n_pre * 4 * kGroupStride, 0));
         CK(hipMemsetAsync(a.overflow, 0, 4, 0));
         cold_pass();
         a.dbg = (r == reps + 29) ? d_dbg : nullptr;
@@ -132,7 +132,7 @@ static void run(const char *name, amr::K2Args a, uint32_t n_tiles, int reps, uns
     std::vector<float> ms;
     const uint32_t groups = k2_groups(n_tiles);
     for (int r = 0; r < reps + 30; ++r) {
-        CK(hipMemsetAsync(a.gcnt, 0, (size_t)groups * a.g.n_pre * 4, 0));
+        CK(hipMemsetAsync(a.gcnt, 0, (size_t)groups * a.g.n_pre * 4 * kGroupStride, 0));
         CK(hipMemsetAsync(a.overflow, 0, 4, 0));
         cold_pass();
         a.dbg = (r == reps + 29) ? d_dbg : nullptr;
@@ -230,7 +230,7 @@ int main(int argc, char **argv)
     }
     a.qt = d_qt; a.n_tiles = n_tiles; a.cap = 1024;
     CK(hipMalloc((void **)&a.counts, (size_t)n_tiles * g.n_pre * 4));
-    CK(hipMalloc((void **)&a.gcnt, (size_t)k2_groups(n_tiles) * g.n_pre * 4));
+    CK(hipMalloc((void **)&a.gcnt, (size_t)k2_groups(n_tiles) * g.n_pre * 4 * kGroupStride));
     CK(hipMalloc((void **)&a.staging, (size_t)n_tiles * g.n_pre * a.cap * 4));
     CK(hipMalloc((void **)&a.overflow, 4));
     unsigned long long *d_dbg; CK(hipMalloc((void **)&d_dbg, (size_t)n_tiles * 16 * 8));
