@@ -416,9 +416,6 @@ amr_status enqueue_tail(amr_handle *h, Slot &s, hipStream_t st, bool split)
     hipEvent_t k3e0 = (t2 && split) ? s.ev_t : nullptr, k3e1 = t2 ? s.ev2 : nullptr;
     const size_t k3lds = amr::k3_lds_bytes(h->sg, h->validate);
     k3.lds_bytes = (uint32_t)k3lds;
-#if AMR_K3_DBG
-    if (const char *e = getenv("AMR_K3_DBGF")) k3.dbg = (uint32_t)atoi(e);
-#endif
     HIP_TRY(hipFuncSetAttribute((const void *)amr::k3_slice_words, hipFuncAttributeMaxDynamicSharedMemorySize, (int)k3lds));
     // one workgroup per (tile, preamble) list; the kernel also takes a grid of (n_tiles, 1) = every list of a tile in one
     // workgroup with shared row staging, which measured slower on the four-preamble decoder (188 against 173 us per 4 GiB)

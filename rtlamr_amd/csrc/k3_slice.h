@@ -42,7 +42,6 @@ struct K3Args {
     uint64_t *listoff;          // [n_pre][n_tiles] slot of every non-empty list in the packed result
     uint32_t *vgcnt;            // [n_pre][n_groups] survivors summed over groups of 64 tiles (atomicAdd; zero before K3 runs)
     uint32_t lds_bytes;         // dynamic LDS of the launch (k3_lds_bytes)
-    uint32_t dbg;               // diagnostic builds (AMR_K3_DBG): switches for timing experiments
     ValRule rule[AMR_MAX_PREAMBLES];
 };
 
@@ -101,7 +100,7 @@ __device__ __forceinline__ uint32_t k3_wave_scan(uint32_t x)
 #endif
 #if AMR_K3_DBG
 __device__ unsigned long long k3_dbg[4096 * 8];
-#define K3_STAMP(i) do { if (tid == 0 && blockIdx.x < 4096 && blockIdx.y == 0) k3_dbg[blockIdx.x * 8 + (i)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#define K3_STAMP(i) do { if (tid == 0 && blockIdx.x < 4096) k3_dbg[blockIdx.x * 8 + (i)] = __builtin_amdgcn_s_memrealtime(); } while (0)
 #else
 #define K3_STAMP(i) do { } while (0)
 #endif
@@ -118,16 +117,16 @@ constexpr int kK3Batch = 4;    // words (entries) a wave works on together
 constexpr int kK3List = 512;   // positions of a list held in LDS at a time (long packets): 2 KiB, eight workgroups still fit a CU
 
 // 64 hits of one list (src[i0 .. i0 + 64) below i_hi) by one wave: their (call, idx) records and the packets of every word
-// that holds some of them.  STAGED: the windows come from rows_lds (stream order, bit 31 of word 0 = tile-local bit
-// base_bit), else from the tiled bitstream at tbase.  Symbols [p_first, PS) in steps of 128 (p_step).  pk_lds (not
-// STAGED, packets of whole dwords): a second copy of the packets of list entries below pk_hits, entry i at pk_lds + i * PB,
+// that holds some of them.  LONG (long packets) and `staged`: the windows come from rows_lds (stream order, bit 31 of word
+// 0 = tile-local bit base_bit), else from the tiled bitstream at tbase.  Symbols [p_first, PS) in steps of 128
+// (p_step).  pk_lds (short packets of whole dwords): a second copy of the packets of list entries below pk_hits, entry i at pk_lds + i * PB,
 // and of their positions in pos_lds.
-template <bool STAGED>
+template <bool LONG>
 __device__ __forceinline__ void k3_chunk(const K3Args &a, const SearchGeom &g, uint32_t T, const uint32_t *src, uint32_t i0, uint32_t i_hi,
                                          uint32_t i_lo, uint32_t wv, uint64_t off, uint64_t total, uint32_t (&tab)[kK3Batch][32],
                                          const uint32_t *rows_lds, const uint32_t *__restrict__ tbase, uint32_t base_bit,
                                          uint32_t p_first, bool by_symbols, uint32_t i_out0, uint32_t tid, uint8_t *pk_lds = nullptr, uint32_t pk_hits = 0,
-                                         uint32_t *pos_lds = nullptr)
+                                         uint32_t *pos_lds = nullptr, bool staged = false)
 {
     const uint32_t lane = tid & 63, l32 = lane & 31, half = lane >> 5;
     const uint32_t lg_bs = g.lg_block_size, bs_mask = g.block_size - 1, lg_tw = 6 + g.lg_wpb;
@@ -148,7 +147,7 @@ __device__ __forceinline__ void k3_chunk(const K3Args &a, const SearchGeom &g, u
     const bool have = i < i_hi;
     const uint32_t local = have ? src[i] : 0xffffffffu;
     const bool ok = have && local < bad;
-    if (!STAGED && have && i < pk_hits) pos_lds[i] = local;           // K5's test wants the positions again
+    if (!LONG && have && i < pk_hits) pos_lds[i] = local;           // K5's test wants the positions again
     if (ok && (!by_symbols || wv == (((i0 - i_lo) >> 6) & 3u))) {      // by symbols: four waves see the chunk, one writes
         const int64_t n = ((int64_t)T * 64 - 64) * (int64_t)g.block_size + local;
         const uint64_t pos = (uint64_t)(n + g.packet_length);
@@ -171,7 +170,7 @@ __device__ __forceinline__ void k3_chunk(const K3Args &a, const SearchGeom &g, u
                 if (lane < 32) tab[e][lane] = 0xffffffffu;
                 if (ok && key == key_s) tab[e][local & 31] = i_out0 + i;   // same wave: LDS operations execute in order
                 slot[e] = tab[e][31 - l32];                        // lane c of a block ends up with position 31-c
-                v0[e] = (key_s << 5) - base_bit;                   // first bit of the word (STAGED: counted from the staged rows)
+                v0[e] = (key_s << 5) - base_bit;                   // first bit of the word (staged: counted from the staged rows)
                 nb = e + 1;
             }
         }
@@ -186,7 +185,7 @@ __device__ __forceinline__ void k3_chunk(const K3Args &a, const SearchGeom &g, u
                     if (e < nb && p0 + 64 * k < PS) {
                         const uint32_t sy = p0 + 64 * k + sym_lane;
                         const uint32_t v = v0[e] + (sy < PS ? sy : PS - 1) * SL;   // window = 32 stream bits from bit v
-                        if (STAGED) { A[e][k] = rows_lds[v >> 5]; B[e][k] = rows_lds[(v >> 5) + 1]; }
+                        if (LONG && staged) { A[e][k] = rows_lds[v >> 5]; B[e][k] = rows_lds[(v >> 5) + 1]; }
                         else { A[e][k] = word_at(v); B[e][k] = word_at(v + 32); }
                     }
                 }
@@ -204,7 +203,7 @@ __device__ __forceinline__ void k3_chunk(const K3Args &a, const SearchGeom &g, u
                         if (b0 + 4 <= PB && dword_ok) {
                             *reinterpret_cast<uint32_t *>(out + b0) = Y;
                             // K5's test follows in this workgroup: it reads the packets of the list's first pk_hits hits here
-                            if (!STAGED && slot[e] < pk_hits) *reinterpret_cast<uint32_t *>(pk_lds + slot[e] * PB + b0) = Y;
+                            if (!LONG && slot[e] < pk_hits) *reinterpret_cast<uint32_t *>(pk_lds + slot[e] * PB + b0) = Y;
                         } else {
 #pragma unroll
                             for (uint32_t j = 0; j < 4; ++j) {
@@ -331,11 +330,7 @@ __device__ __forceinline__ void k5_flag_list(const K3Args &a, const ValRule &r, 
     uint32_t kept = 0;
     // hit j of the list, packet at pkt (the one before it at pkt - PB), position sj (the one before it: sjm)
     auto test = [&](uint32_t j, const uint8_t *pkt, uint32_t sj, uint32_t sjm) {
-#if AMR_K3_DBG
-        bool keep = (a.dbg & 8) ? true : k5_checks(r, tbl, pkt);
-#else
         bool keep = k5_checks(r, tbl, pkt);
-#endif
         if (keep && r.dedupe_bytes > 0) {
             if (j == 0) keep = !first_same;
             else {
@@ -392,9 +387,6 @@ counted:
         const uint32_t n = s_red[0] + s_red[1] + s_red[2] + s_red[3];
         a.listcnt[q * a.n_tiles + T] = n;
         a.listoff[q * a.n_tiles + T] = off;
-#if AMR_K3_DBG
-        if (a.dbg & 16) return;
-#endif
         if (n) atomicAdd(&a.vgcnt[(q * k2_groups(a.n_tiles) + (T >> 6)) * kGroupStride], n);
     }
 }
@@ -433,13 +425,10 @@ __device__ __forceinline__ void k3_one_list(const K3Args &a, uint32_t T, uint32_
     // After an overflow the staging slots are incomplete (a wave whose sparse list overflowed counted hits it never
     // emitted): their contents must not be used as positions; the host re-runs the search anyway.
     if (ovf || total > a.out_cap) return;                // ... or grows the buffer and searches again
-#if AMR_K3_DBG
-    if (a.dbg & 32) __builtin_amdgcn_s_setprio(3);
-#endif
     K3_STAMP(1);
     const uint32_t cnt = S.cnt[q];
 #if AMR_K3_DBG
-    if (tid == 0 && blockIdx.x < 4096 && blockIdx.y == 0) k3_dbg[blockIdx.x * 8 + 7] = cnt;
+    if (tid == 0 && blockIdx.x < 4096) k3_dbg[blockIdx.x * 8 + 7] = cnt;
 #endif
     if (!cnt) {
         if (a.keep && tid == 0) a.listcnt[q * a.n_tiles + T] = 0;
@@ -456,17 +445,9 @@ __device__ __forceinline__ void k3_one_list(const K3Args &a, uint32_t T, uint32_
     const uint32_t *src = a.staging + ((size_t)T * n_pre + q) * a.cap;
     const uint64_t off = S.off[q] + S.in[q];
     // K5's look across the tile boundary (k5_flag_list): the two positions it needs are on their way during the slicing
-#if AMR_K3_DBG
-    const bool edge = a.keep && !(a.dbg & 2) && T > 0 && S.prev[q] && s_rule->dedupe_bytes > 0;
-#else
     const bool edge = a.keep && T > 0 && S.prev[q] && s_rule->dedupe_bytes > 0;
-#endif
     // short packets of whole dwords: the slicing leaves a copy of the first 256 packets in LDS for K5's test
-#if AMR_K3_DBG
-    const uint32_t pk_hits = a.keep && !(a.dbg & 1) && !by_symbols && (g.pkt_bytes & 3) == 0 && (PS & 7) == 0 ? 256u : 0u;
-#else
     const uint32_t pk_hits = a.keep && !by_symbols && (g.pkt_bytes & 3) == 0 && (PS & 7) == 0 ? 256u : 0u;
-#endif
     uint32_t edge_lp = 0, edge_lm = 0;
     if (edge) {
         const uint32_t c_prev = S.prev[q] < a.cap ? S.prev[q] : a.cap;
@@ -501,37 +482,42 @@ __device__ __forceinline__ void k3_one_list(const K3Args &a, uint32_t T, uint32_
                 const uint32_t first = s_list[cur];
                 if (first >= bad) { cur += 1; continue; }                       // defensive
                 const uint32_t l0 = first >> lg_bs;                             // the row this round stages from
-                const uint32_t lim = (l0 + 1) << lg_bs;
-                uint32_t lo = cur + 1, hi = seg_n;                              // end of the hits that start in row l0 (positions ascend)
-                while (lo < hi) {
-                    const uint32_t mid = (lo + hi) >> 1;
-                    if (s_list[mid] < lim) lo = mid + 1; else hi = mid;
+                // A sparse stretch -- the next (up to) 64 entries lie two or fewer to a row: lone noise hits, eight to a
+                // tile in "all" (scm+'s 16-bit preamble), each of which would have a row set of n_rows KiB staged for its one
+                // word (4 GiB of "all": 8 x 14 KB per tile, K3 150 us).  Their windows come straight from the bitstream
+                // instead, four words to a round of loads, the symbols still shared out over the four waves.
+                const uint32_t w_end = cur + 64 < seg_n ? cur + 64 : seg_n;
+                const uint32_t w_last = s_list[w_end - 1];
+                const bool sparse = w_last < bad && w_end - cur <= 2 * ((w_last >> lg_bs) - l0 + 1);
+                uint32_t i_hi = w_end, base_bit = 0;
+                if (!sparse) {
+                    const uint32_t lim = (l0 + 1) << lg_bs;
+                    uint32_t lo = cur + 1, hi = seg_n;                          // end of the hits that start in row l0 (positions ascend)
+                    while (lo < hi) {
+                        const uint32_t mid = (lo + hi) >> 1;
+                        if (s_list[mid] < lim) lo = mid + 1; else hi = mid;
+                    }
+                    i_hi = lo;
+                    k3_lds_barrier();                                            // the previous row set has been consumed
+                    for (uint32_t t = tid; t < n_rows * cpr; t += 256) {
+                        const uint32_t c = t / n_rows, r = t - c * n_rows, row = l0 + r;     // neighbouring threads: neighbouring rows of one chunk
+                        const uint4 x = *reinterpret_cast<const uint4 *>(tbase + ((size_t)(row >> 6) << lg_tw) + ((size_t)c << 8) + ((row & 63) << 2));
+                        *reinterpret_cast<uint4 *>(rows_lds + r * wpb + c * 4) = x;
+                    }
+                    k3_lds_barrier();
+                    base_bit = l0 << lg_bs;                                     // stream bit (tile-local) of rows_lds[0], bit 31
                 }
-                const uint32_t i_hi = lo;
-                k3_lds_barrier();                                                // the previous row set has been consumed
-                for (uint32_t t = tid; t < n_rows * cpr; t += 256) {
-                    const uint32_t c = t / n_rows, r = t - c * n_rows, row = l0 + r;     // neighbouring threads: neighbouring rows of one chunk
-                    const uint4 x = *reinterpret_cast<const uint4 *>(tbase + ((size_t)(row >> 6) << lg_tw) + ((size_t)c << 8) + ((row & 63) << 2));
-                    *reinterpret_cast<uint4 *>(rows_lds + r * wpb + c * 4) = x;
-                }
-                k3_lds_barrier();
-                const uint32_t base_bit = l0 << lg_bs;                          // stream bit (tile-local) of rows_lds[0], bit 31
                 // the four waves share a 64-hit chunk by SYMBOLS: the hits of a packet are one run of ~70 positions, i.e. one
                 // wave's worth, and 736 symbols in one wave are six rounds one after the other while three waves watch
                 for (uint32_t i0 = cur; i0 < i_hi; i0 += 64)
-                    k3_chunk<true>(a, g, T, s_list, i0, i_hi, cur, wv, off, total, tab[wv], rows_lds, tbase, base_bit, wv * 128, true, seg0, tid);
+                    k3_chunk<true>(a, g, T, s_list, i0, i_hi, cur, wv, off, total, tab[wv], rows_lds, tbase, base_bit, wv * 128, true, seg0, tid,
+                                   nullptr, 0u, nullptr, !sparse);
                 cur = i_hi;
             }
         }
     }
-#if AMR_K3_DBG
-    if (a.dbg & 32) __builtin_amdgcn_s_setprio(0);
-#endif
     K3_STAMP(2);
     if (!a.keep) return;
-#if AMR_K3_DBG
-    if (a.dbg & 4) return;
-#endif
     // ---- K5's test of the list, on the packets just written; the CRC tables take the place of the slicing tables
     k3_lds_barrier();
     K3_STAMP(3);
