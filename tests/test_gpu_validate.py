@@ -82,6 +82,62 @@ def test_validated_hits_equal_filtered_oracle(protos, chip, n_blocks, n_packets,
         val.close()
 
 
+@pytest.mark.parametrize("protos,kind,chip,batches", [
+    (["scm"], "scm", 72, [192]),
+    (["scm"], "scm", 72, [70, 122]),              # the boundary of the second batch's tiles lies elsewhere in the stream
+    (["idm"], "idm", 72, [192]),
+    (["scm", "scm+", "idm"], "scm+", 72, [192]),
+])
+def test_repeats_across_a_wave_tile_boundary(protos, kind, chip, batches):
+    """K5's test runs per (wave-tile, preamble) list; the hit before a list's first one belongs to the previous tile's
+    list.  Packets planted so that the run of hits of ONE packet (same bytes, same Decode call) straddles the
+    boundary between two wave-tiles of the launch: the repeats on the far side must go like all the others."""
+    val = util.make_decoder(protos, chip)
+    try:
+        val.EnableValidation()
+        bs, bs2 = val.Cfg.BlockSize, val.Cfg.BlockSize2
+        n_blocks = sum(batches)
+        iq = synth.noise(n_blocks * bs, seed=41)
+        fn, nbits = util.PKT_BUILDERS[kind]
+        # wave-tile t of a launch starts at block 64 t of that launch (the history tile in front of block 0)
+        bounds, first = [], 0
+        for nb in batches:
+            bounds += [first + 64 * t for t in range(1, (nb + 63) // 64)]
+            first += nb
+        assert len(bounds) >= 2
+        # hit position n (bitstream index = Signal index, SymbolLength of history in front) = packet start + SymbolLength,
+        # +- about half a chip of neighbours that slice to the same bytes
+        pkts = [synth.Packet(b * bs - 2 * chip + (10 if i % 2 else -10), fn(50 + i), nbits, 31 if i % 2 else -31, -27 if i % 2 else 27)
+                for i, b in enumerate(bounds)]
+        synth.plant(iq, pkts, chip)
+        want_h, want_p, n_searched = _expected(protos, chip, iq, val)
+        # the premise: of every planted packet there are hits on both sides of its boundary with the same bytes
+        _, _, oh, op = util.oracle_run(protos, chip, iq)
+        PL = val.Cfg.PacketLength
+        n_of = oh[:, 1] * bs + oh[:, 2] - PL
+        pid = val._pid_of_preamble[PROTOCOLS[kind][0]]
+        for b, p in zip(bounds, pkts):
+            nb_ = (len(p.data))
+            same = (oh[:, 0] == pid) & (np.abs(n_of - b * bs) < 4 * chip) & np.all(op[:, :nb_] == np.frombuffer(p.data, np.uint8), axis=1)
+            assert np.any(same & (n_of < b * bs)) and np.any(same & (n_of >= b * bs)), "the run does not straddle the tile boundary"
+        got_h, got_p, pos = [], [], 0
+        per_batch = []
+        for nb in batches:
+            per_batch.append(val.decode_batch(iq[pos * bs2:(pos + nb) * bs2]))
+            pos += nb
+        for q in range(val.n_preambles):
+            for br in per_batch:
+                blk, idx, pk = br.for_preamble(q)
+                got_h.append(np.stack([np.full(len(blk), q, np.int64), blk.astype(np.int64), idx.astype(np.int64)], axis=1))
+                got_p.append(pk)
+        got_h, got_p = np.concatenate(got_h), np.concatenate(got_p)
+        assert sum(br.n_hits_searched for br in per_batch) == n_searched
+        assert np.array_equal(got_h, want_h), f"{len(got_h)} validated hits, oracle filter keeps {len(want_h)}"
+        assert np.array_equal(got_p, want_p)
+    finally:
+        val.close()
+
+
 def test_validation_with_r900_digits_and_pipeline():
     """'all' geometry: scm / scm+ / idm validated, r900 hits all kept and still aligned with their digits;
     submit/collect pipeline; result_device describes the validated list."""
