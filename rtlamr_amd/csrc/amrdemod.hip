@@ -417,9 +417,11 @@ amr_status enqueue_tail(amr_handle *h, Slot &s, hipStream_t st, bool split)
     const size_t k3lds = amr::k3_lds_bytes(h->sg, h->validate);
     k3.lds_bytes = (uint32_t)k3lds;
     HIP_TRY(hipFuncSetAttribute((const void *)amr::k3_slice_words, hipFuncAttributeMaxDynamicSharedMemorySize, (int)k3lds));
-    // one workgroup per (tile, preamble) list; the kernel also takes a grid of (n_tiles, 1) = every list of a tile in one
-    // workgroup with shared row staging, which measured slower on the four-preamble decoder (188 against 173 us per 4 GiB)
-    hipExtLaunchKernelGGL(amr::k3_slice_words, dim3(s.n_tiles - 1, n_pre), dim3(256), k3lds, st, k3e0, k3e1, 0, k3);
+    // one workgroup per (tile, preamble) list (every list of a tile in one workgroup with shared row staging measured slower
+    // on the four-preamble decoder: 188 against 173 us per 4 GiB); k3_fold: when the history tile's workgroup would be the
+    // one too many for whole rounds of the chip, workgroup 0 takes its list as well
+    k3.fold = amr::k3_fold(s.n_tiles, n_pre, (uint32_t)h->n_cus * 8u) ? 1u : 0u;
+    hipExtLaunchKernelGGL(amr::k3_slice_words, dim3(s.n_tiles - k3.fold, n_pre), dim3(256), k3lds, st, k3e0, k3e1, 0, k3);
     HIP_TRY(hipGetLastError());
     AMR_DBG(st, "k3_slice");
     if (h->r900_pid >= 0) {
@@ -441,7 +443,8 @@ amr_status enqueue_tail(amr_handle *h, Slot &s, hipStream_t st, bool split)
         k5.keep = s.d_keep; k5.counts = s.d_counts; k5.listcnt = k3.listcnt; k5.listoff = s.d_listoff; k5.vgcnt = k3.vgcnt;
         k5.overflow = s.d_overflow; k5.cap = s.out_cap;
         k5.n_pre = n_pre; k5.n_tiles = s.n_tiles; k5.pkt_bytes = h->sg.pkt_bytes;
-        hipLaunchKernelGGL(amr::k5_compact, dim3(s.n_tiles - 1, n_pre), dim3(256), 0, st, k5);
+        k5.fold = k3.fold;
+        hipLaunchKernelGGL(amr::k5_compact, dim3(s.n_tiles - k5.fold, n_pre), dim3(256), 0, st, k5);
         HIP_TRY(hipGetLastError());
         AMR_DBG(st, "k5_compact");
     }

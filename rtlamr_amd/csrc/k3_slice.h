@@ -42,6 +42,7 @@ struct K3Args {
     uint64_t *listoff;          // [n_pre][n_tiles] slot of every non-empty list in the packed result
     uint32_t *vgcnt;            // [n_pre][n_groups] survivors summed over groups of 64 tiles (atomicAdd; zero before K3 runs)
     uint32_t lds_bytes;         // dynamic LDS of the launch (k3_lds_bytes)
+    uint32_t fold;              // 1: grid (n_tiles - 1, n_pre), workgroup 0 also takes the history tile (k3_fold)
     ValRule rule[AMR_MAX_PREAMBLES];
 };
 
@@ -220,6 +221,16 @@ __device__ __forceinline__ void k3_chunk(const K3Args &a, const SearchGeom &g, u
                 }
         }
     }
+}
+
+// Grid of K3 / k5_compact.  One workgroup per list = n_tiles per preamble; when that is one more than fills whole rounds
+// of the chip's slots (a GiB of scm: 2048 tiles + the history tile, 2048 slots of 256 threads), workgroup 0 takes the
+// history tile's short list after its own instead -- the straggler would otherwise wait for the first of the others
+// to end.  Small launches keep one list per workgroup (a lone block: two lists side by side, not one after the other).
+__host__ __device__ __forceinline__ bool k3_fold(uint32_t n_tiles, uint32_t n_pre, uint32_t slots)
+{
+    const uint64_t all = (uint64_t)n_tiles * n_pre, less = (uint64_t)(n_tiles - 1) * n_pre;
+    return n_tiles > 1 && (all + slots - 1) / slots > (less + slots - 1) / slots;
 }
 
 // Where the list (tile T, preamble q) lies among all lists, preamble-major, from per-list counts [n_pre][n_tiles] and
@@ -526,10 +537,9 @@ __device__ __forceinline__ void k3_one_list(const K3Args &a, uint32_t T, uint32_
     K3_STAMP(6);
 }
 
-// grid (n_tiles - 1, n_pre): workgroup x takes the list of tile x + 1, workgroup 0 afterwards that of tile 0 as well -- the
-// history tile, whose only hits are packets that START in the previous batch's last rows: a short list.  (A chip holds
-// 2048 of these workgroups; 1 GiB of scm is 2048 tiles + the history tile, and a 2049th workgroup of its own waited for
-// the first of the others to end: K3 took twice a workgroup's life.)
+// grid (n_tiles, n_pre), one list per workgroup -- or, `fold` (k3_fold): (n_tiles - 1, n_pre), workgroup x takes the list of
+// tile x + 1 and workgroup 0 afterwards that of tile 0 as well: the history tile, whose only hits are packets that START
+// in the previous batch's last rows, a short list.
 __global__ __launch_bounds__(256, 8) void k3_slice_words(const K3Args a)   // 8 workgroups per CU: 64 VGPRs (65 without the hint: 7)
 {
     __shared__ K3Scan S;
@@ -538,7 +548,7 @@ __global__ __launch_bounds__(256, 8) void k3_slice_words(const K3Args a)   // 8 
     __shared__ uint32_t s_red[4];
     __shared__ ValRule s_rule;
     extern __shared__ __attribute__((aligned(16))) uint32_t rows_lds[];          // [n_rows][wpb] words, stream order; K5: packets
-    const uint32_t passes = blockIdx.x == 0 ? 2u : 1u;
+    const uint32_t passes = a.fold && blockIdx.x == 0 ? 2u : 1u;
 #pragma clang loop unroll(disable)
     for (uint32_t pass = 0; pass < passes; ++pass) {
         if (pass) __syncthreads();
@@ -546,7 +556,7 @@ __global__ __launch_bounds__(256, 8) void k3_slice_words(const K3Args a)   // 8 
         // instead of being hoisted out of this loop to live (and spill) across all of it
         uint32_t tid = threadIdx.x;
         asm volatile("" : "+v"(tid));
-        k3_one_list(a, pass ? 0u : blockIdx.x + 1u, blockIdx.y, S, tab, s_list, s_red, rows_lds, &s_rule, tid);
+        k3_one_list(a, pass ? 0u : blockIdx.x + a.fold, blockIdx.y, S, tab, s_list, s_red, rows_lds, &s_rule, tid);
     }
 }
 
@@ -567,6 +577,7 @@ struct K5Args {
     const uint32_t *overflow;   // K2's overflow word: the host searches again, nothing here is used
     uint64_t cap;               // hits the buffers hold
     uint32_t n_pre, n_tiles, pkt_bytes;
+    uint32_t fold;              // as K3Args::fold
 };
 
 __device__ __forceinline__ void k5_compact_list(const K5Args &a, uint32_t T, uint32_t q, K3Scan &S, uint32_t *wcnt)
@@ -617,16 +628,16 @@ __device__ __forceinline__ void k5_compact_list(const K5Args &a, uint32_t T, uin
     }
 }
 
-// grid (n_tiles - 1, n_pre), tiles dealt to the workgroups as in k3_slice_words
+// grid and tiles as k3_slice_words
 __global__ __launch_bounds__(256) void k5_compact(const K5Args a)
 {
     __shared__ K3Scan S;
     __shared__ uint32_t wcnt[4];
-    const uint32_t passes = blockIdx.x == 0 ? 2u : 1u;
+    const uint32_t passes = a.fold && blockIdx.x == 0 ? 2u : 1u;
 #pragma clang loop unroll(disable)
     for (uint32_t pass = 0; pass < passes; ++pass) {
         if (pass) __syncthreads();
-        k5_compact_list(a, pass ? 0u : blockIdx.x + 1u, blockIdx.y, S, wcnt);
+        k5_compact_list(a, pass ? 0u : blockIdx.x + a.fold, blockIdx.y, S, wcnt);
     }
 }
 
