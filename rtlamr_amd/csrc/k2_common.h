@@ -30,6 +30,15 @@ namespace amr {
 
 constexpr int kMaxPre = 8;
 
+// Every group sum in a cache line of its own: sum i lives at word i * kGroupStride.  They are the targets of one
+// atomicAdd per list from workgroups that all finish at about the same time; packed (round 3: the 33 sums of 1 GiB of
+// scm in two lines) the 2048 additions queue up at one memory channel -- 12 us during which the stores of everybody
+// else's packets wait behind them (measured on K3's survivor sums, profiles/r04/k3_phases.txt).
+#ifndef AMR_GSTRIDE
+#define AMR_GSTRIDE 32
+#endif
+constexpr uint32_t kGroupStride = AMR_GSTRIDE;
+
 struct SearchGeom {
     uint32_t block_size;     // BS
     uint32_t lg_block_size;
@@ -92,7 +101,7 @@ __device__ __forceinline__ void hist_body(const HistArgs &a, uint32_t *tmp, uint
     for (uint32_t i = tid; i < a.carry_bytes / 16; i += nt)
         reinterpret_cast<uint4 *>(a.carry_dst)[i] = reinterpret_cast<const uint4 *>(a.carry_src)[i];
     if (tid == nt - 1) *a.ovf_next = 0;
-    for (uint32_t i = tid; i < a.gcnt_words; i += nt) a.gcnt_next[i] = 0;
+    for (uint32_t i = tid; i < a.gcnt_words / kGroupStride; i += nt) a.gcnt_next[i * kGroupStride] = 0;   // the sums, not the padding
     const uint32_t n = a.hr << a.lg_wpb;
     for (uint32_t i = tid; i < n; i += nt) {
         const uint32_t j = i >> a.lg_wpb, w = i & (a.wpb - 1);
@@ -196,14 +205,6 @@ __device__ __forceinline__ uint32_t k2_word(const uint32_t *lds, uint32_t x, uin
 // The per-(preamble, tile) hit counts are also summed per group of 64 tiles, so that K3 finds the slot of a list in
 // the packed result from <= n_pre * n_groups + 63 values instead of a scan over all of them.
 __host__ __device__ __forceinline__ uint32_t k2_groups(uint32_t n_tiles) { return (n_tiles + 63) >> 6; }
-// Every group sum in a cache line of its own: sum i lives at word i * kGroupStride.  They are the targets of one
-// atomicAdd per list from workgroups that all finish at about the same time; packed (round 3: the 33 sums of 1 GiB of
-// scm in two lines) the 2048 additions queue up at one memory channel -- 12 us during which the stores of everybody
-// else's packets wait behind them (measured on K3's survivor sums, profiles/r04/k3_phases.txt).
-#ifndef AMR_GSTRIDE
-#define AMR_GSTRIDE 32
-#endif
-constexpr uint32_t kGroupStride = AMR_GSTRIDE;
 
 // k2_walk.h
 constexpr int kK2WTaps = 16;              // taps applied to every position
