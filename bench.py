@@ -173,6 +173,28 @@ def cpu_baseline(wl, dec, d_iq, bs2, seconds=12.0):
                       "C restatement of protocol/decode.go (gcc -O2 -ffp-contract=off), one stream per thread"}
 
 
+def single_block_latency(ra, wl, local_rank, d_iq, bs, bs2, n=300, warm=50):
+    """The latency case, the unchanged main.go loop (main.go:235): ONE block per Decode call, from host memory, results back
+    on the host before the next call.  Not what the GPU is for -- reported so that nobody has to guess (us per call)."""
+    import numpy as np
+    from rtlamr_amd import _lib
+    iq = np.empty((n + warm) * bs2, np.uint8)
+    _lib.check(_lib.lib().amr_dev_download(local_rank, iq.ctypes.data, C.c_void_p(d_iq), iq.size), "download")
+    dec = ra.new_decoder(local_rank)
+    try:
+        for p in wl["protos"]:
+            dec.RegisterProtocol(ra.new_parser(p, wl["chip"]))
+        dec.Allocate()
+        for k in range(warm):
+            dec.decode_batch(iq[k * bs2:(k + 1) * bs2])
+        t0 = time.perf_counter()
+        for k in range(warm, warm + n):
+            dec.decode_batch(iq[k * bs2:(k + 1) * bs2])
+        return (time.perf_counter() - t0) / n * 1e6
+    finally:
+        dec.close()
+
+
 def verify_batch(ra, wl, local_rank, d_iq, n_blocks, pk, bs, n_samples):
     """A second, validating decoder turns the batch into messages: exactly the planted meters must come out."""
     dec = ra.new_decoder(local_rank)
@@ -641,6 +663,10 @@ def main():
                                   "gather_records": "validated hits (K5)" if validating else "raw hits (--gather raw)"})
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(wl, dec, d_iq.value, bs2)
+            # the other end of the scale: one block per call on the GPU, next to the CPU port's time per block
+            nlat = min(300, n_blocks - 50)
+            out["latency_us_per_block"] = round(single_block_latency(ra, wl, local_rank, d_iq.value, bs, bs2, n=nlat), 1) if nlat > 0 else None
+            out["cpu_baseline"]["single_thread_us_per_block"] = round(bs / out["cpu_baseline"]["single_thread"], 2)
     else:
         out = None
     if distributed:
