@@ -142,7 +142,7 @@ int main(int argc, char **argv)
         } else CK(hipMalloc(&iqs[ai], iq_bytes));
         const uint64_t n_samples = (uint64_t)n_blocks * bs;
         if (input == 0)
-            hipLaunchKernelGGL(amr::k_synth_noise, dim3((unsigned)((n_samples / 8 + 255) / 256)), dim3(256), 0, 0, iqs[ai], n_samples, 1ull, 0ull);
+            hipLaunchKernelGGL(amr::k_synth_noise<false>, dim3((unsigned)((n_samples / 8 + 255) / 256)), dim3(256), 0, 0, iqs[ai], n_samples, 1ull, 0ull);
         else
             hipLaunchKernelGGL(k_uniform, dim3((unsigned)((iq_bytes / 16 + 255) / 256)), dim3(256), 0, 0, iqs[ai], iq_bytes / 16, 7ull);
         CK(hipDeviceSynchronize());
