@@ -345,7 +345,8 @@ amr_status amr_gather_wait(amr_handle *h);    /* block until every gather enqueu
 amr_status amr_gather_fetch(amr_handle *h, uint64_t seq, int32_t src_rank, amr_gathered *out);
 /* The slot every rank sends, as ONE description shared by the device pack kernel, CPU hosts and the tests:
  * [header AMR_GATHER_HEADER_BYTES | n_hits call indices u64 | n_hits idx u32], amr_gather_slot_bytes(cap) bytes in
- * memory; on the wire the header and amr_gather_wire_bytes(n_hits) bytes of records (two messages per rank).
+ * memory; on the wire the whole slot, or (amr_gather_two_phase) the header and amr_gather_wire_bytes(n_hits) bytes of
+ * records as two messages per rank.
  * amr_gather_pack_host builds it from a host-side result (a transport other than RCCL, e.g. the gloo tests),
  * amr_gather_unpack reads one (pointers into `slot`).  Neither needs a device. */
 size_t amr_gather_slot_bytes(uint64_t cap_hits);
