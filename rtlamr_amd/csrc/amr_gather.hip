@@ -1,0 +1,393 @@
+// amr_gather.hip -- multi-GPU: the RCCL gather of hit records (include/amrdemod.h, amr_comm_* / amr_gather_*).
+#include <dlfcn.h>
+
+#include "amr_host.h"
+
+using namespace amr_host;
+
+// =====================================================================================================================
+// Multi-GPU: gather of the hit records on one rank.  One process per GPU; independent shards of whole
+// blocks need no data-path collective, the only exchange is this gather.  It runs on its own stream through RCCL
+// point-to-point calls (every peer sends its records to the root over its own xGMI link; no ring) and is enqueued from
+// the host without any synchronisation, so that it overlaps the kernels of the following batches.
+//
+// Ordering.  amr_collect has seen the batch complete, so its packed result is there; it stays there until K3 / K5 of the
+// batch that REUSES the slot (the fourth submit after this one) overwrite it.  The pack kernel that reads it runs on the
+// communicator's stream, behind the previous gather's send -- which completes only when the root has posted its
+// receive, i.e. a lagging root or peer can hold it back for any length of time.  So the pack kernel is followed by an
+// event (Slot::ev_pack) and enqueue_tail() makes the stream that is about to overwrite the slot wait for it: back-pressure
+// instead of a timing assumption.  The send buffer of set k is reused by the pack of gather seq + 2 on the same stream,
+// i.e. in order behind the send that read it.
+//
+// What travels is sized by the hit count, not by the capacity, once the capacity is large (round 4; a fixed 1.5 x
+// capacity slot was 5.2 MB per rank and step for raw hits whatever the batch held; slots of up to kGatherWholeSlotMax
+// -- validated hits -- still travel whole in one message, with no host wait at all).  For the large ones, two phases
+// per gather, both on the communicator's stream:
+//   1. every rank sends its 128-byte slot header (true count, records sent, per-preamble offsets, sequence number);
+//   2. every rank with records sends exactly gather_wire_bytes(n_sent) = 12 * n_sent bytes rounded up to 4 KiB.
+// A sender knows its count on the host (amr_collect returned it) and never waits.  The ROOT has to know every peer's
+// count before it can post the receives of phase 2 (RCCL point-to-point needs matching sizes): it copies the received
+// headers to pinned memory and waits for that copy -- the one host wait of the protocol, 128 bytes per rank, on the
+// root only, and only as long as the slowest peer takes to post the same gather.
+//
+// Root side.  Behind the receives of a gather, on the same stream, one kernel mirrors every rank's slot (header + the
+// records it holds) into pinned host memory and an event marks its arrival:
+// amr_gather_fetch(seq, rank) waits for that event only -- no stream synchronisation, no blocking copy -- and returns
+// pointers into the mirror.  Two sets alternate: the records of gather `seq` stay valid until gather seq + 2 is posted.
+//
+// RCCL is bound at run time (dlopen): libamrdemod.so has no link-time dependency on it, and a process that already
+// carries a copy (PyTorch ships one) keeps using that one.
+// =====================================================================================================================
+#include <mutex>
+
+namespace {
+
+struct Id128 { char b[128]; };   // ncclUniqueId (rccl.h: char internal[128]), passed by value
+
+struct Rccl {
+    void *so = nullptr;
+    int (*GetUniqueId)(void *) = nullptr;
+    int (*CommInitRank)(void **, int, Id128, int) = nullptr;
+    int (*CommDestroy)(void *) = nullptr;
+    int (*CommCount)(void *, int *) = nullptr;
+    int (*GroupStart)() = nullptr;
+    int (*GroupEnd)() = nullptr;
+    int (*Send)(const void *, size_t, int, int, void *, hipStream_t) = nullptr;
+    int (*Recv)(void *, size_t, int, int, void *, hipStream_t) = nullptr;
+    const char *(*GetErrorString)(int) = nullptr;
+};
+
+Rccl *rccl()
+{
+    static Rccl r;
+    static std::once_flag once;
+    std::call_once(once, [] {
+        // a copy already in the process first (torch's librccl.so), then the ROCm one
+        const char *names[] = {"librccl.so", "librccl.so.1"};
+        for (const char *n : names) if (!r.so) r.so = dlopen(n, RTLD_NOW | RTLD_NOLOAD | RTLD_GLOBAL);
+        for (const char *n : names) if (!r.so) r.so = dlopen(n, RTLD_NOW | RTLD_GLOBAL);
+        if (!r.so) r.so = dlopen("/opt/rocm/lib/librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
+        if (!r.so) return;
+#define AMR_SYM(field, name) *(void **)(&r.field) = dlsym(r.so, name)
+        AMR_SYM(GetUniqueId, "ncclGetUniqueId"); AMR_SYM(CommInitRank, "ncclCommInitRank"); AMR_SYM(CommDestroy, "ncclCommDestroy");
+        AMR_SYM(CommCount, "ncclCommCount");
+        AMR_SYM(GroupStart, "ncclGroupStart"); AMR_SYM(GroupEnd, "ncclGroupEnd"); AMR_SYM(Send, "ncclSend"); AMR_SYM(Recv, "ncclRecv");
+        AMR_SYM(GetErrorString, "ncclGetErrorString");
+#undef AMR_SYM
+        if (!r.GetUniqueId || !r.CommInitRank || !r.CommDestroy || !r.GroupStart || !r.GroupEnd || !r.Send || !r.Recv) r.so = nullptr;
+    });
+    return r.so ? &r : nullptr;
+}
+
+constexpr int kNcclUint8 = 1;              // ncclDataType_t: ncclInt8 0, ncclUint8 1 (rccl.h)
+
+amr_status nccl_fail(const char *what, int rc)
+{
+    Rccl *r = rccl();
+    char buf[256];
+    snprintf(buf, sizeof buf, "%s: %s", what, (r && r->GetErrorString) ? r->GetErrorString(rc) : "RCCL error");
+    return fail(AMR_EHIP, buf);
+}
+#define NCCL_TRY(expr) do { int rc_ = (expr); if (rc_ != 0) return nccl_fail(#expr, rc_); } while (0)
+
+// ---- the gather slot: ONE description of its layout, used by the device pack kernel, by amr_gather_pack_host (CPU
+// hosts and the gloo tests) and by amr_gather_unpack / amr_gather_fetch --------------------------------------------------
+//   u64 words [0] n_true  [1] n_sent = min(n_true, cap)  [2] n_pre  [3 .. 3+n_pre] per-preamble offsets into the
+//   source rank's (untruncated) hit arrays  [12] gather sequence number  -- header of kGatherHdr words, then
+//   n_sent call indices (u64), then n_sent idx (u32).
+constexpr uint32_t kGatherHdr = AMR_GATHER_HEADER_BYTES / 8;
+static_assert(3 + AMR_MAX_PREAMBLES + 1 <= 12 && kGatherHdr >= 13, "gather header layout");
+
+// bytes of records that travel for n_sent of them: [n_sent call indices u64 | n_sent idx u32], rounded up to 4 KiB
+__host__ __device__ inline size_t gather_wire_bytes(uint64_t n_sent)
+{
+    return ((size_t)n_sent * 12 + 4095) & ~(size_t)4095;
+}
+
+// Slots up to this size travel whole, in ONE message per rank and gather, and nobody waits for anybody (round 3's
+// protocol): at 12 bytes per record that is a capacity of 21 000 validated hits -- what `bench.py --gpus N` and any
+// deployment with amr_set_validation gather.  Only larger slots (raw hit lists: MBs) are worth the two phases, whose
+// price is the root's wait for the headers.
+constexpr size_t kGatherWholeSlotMax = 256 * 1024;
+__host__ __device__ inline bool gather_two_phase(size_t slot_bytes) { return slot_bytes > kGatherWholeSlotMax; }
+
+// a slot in memory: header + room for the wire bytes of `cap` records
+__host__ __device__ inline size_t gather_slot_bytes(uint64_t cap)
+{
+    return ((size_t)kGatherHdr * 8 + gather_wire_bytes(cap) + 255) & ~(size_t)255;
+}
+
+// element i of `stride` workers: header words and records of a packed result [blk u64 x n | idx u32 x n | ...]
+__host__ __device__ inline void gather_pack_part(const uint64_t *blk, const uint32_t *idx, const uint64_t *offs, uint32_t n_pre,
+                                                 uint64_t cap, uint64_t seq, uint64_t *slot, uint64_t t, uint64_t stride)
+{
+    const uint64_t n = offs[n_pre], m = n < cap ? n : cap;
+    uint64_t *rb = slot + kGatherHdr;
+    uint32_t *ri = reinterpret_cast<uint32_t *>(rb + m);
+    if (t == 0) { slot[0] = n; slot[1] = m; slot[2] = n_pre; slot[12] = seq; }
+    for (uint64_t i = t; i <= n_pre; i += stride) slot[3 + i] = offs[i];
+    for (uint64_t i = t; i < m; i += stride) { rb[i] = blk[i]; ri[i] = idx[i]; }
+}
+
+__global__ void k_gather_pack(const uint8_t *packed, const uint64_t *offs, uint32_t n_pre, uint64_t cap, uint64_t seq, uint64_t *slot)
+{
+    const uint64_t n = offs[n_pre];
+    gather_pack_part(reinterpret_cast<const uint64_t *>(packed), reinterpret_cast<const uint32_t *>(packed + n * 8), offs, n_pre,
+                     cap, seq, slot, (uint64_t)blockIdx.x * blockDim.x + threadIdx.x, (uint64_t)gridDim.x * blockDim.x);
+}
+
+// Root: headers (received contiguously, phase 1) and records (phase 2, in place behind each rank's header slot) of all
+// ranks -> the pinned host mirror, laid out as slots again.  grid (x, world): the x blocks of rank p share its records.
+// (d_hdr null: the slots arrived whole, every header sits in front of its records)
+__global__ void k_gather_mirror(const uint8_t *d_hdr, const uint8_t *d_recv, uint8_t *h_recv, size_t slot_bytes)
+{
+    const uint32_t p = blockIdx.y;
+    const uint4 *hdr = reinterpret_cast<const uint4 *>(d_hdr ? d_hdr + (size_t)p * kGatherHdr * 8 : d_recv + (size_t)p * slot_bytes);
+    const uint64_t m = reinterpret_cast<const uint64_t *>(hdr)[1];
+    uint4 *dst = reinterpret_cast<uint4 *>(h_recv + (size_t)p * slot_bytes);
+    const uint4 *src = reinterpret_cast<const uint4 *>(d_recv + (size_t)p * slot_bytes);
+    const uint64_t n16 = kGatherHdr * 8 / 16 + (m * 12 + 15) / 16;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n16; i += (uint64_t)gridDim.x * blockDim.x)
+        dst[i] = i < kGatherHdr * 8 / 16 ? hdr[i] : src[i];
+}
+
+amr_status gather_unpack(const void *slot, size_t slot_bytes, amr_gathered *out)
+{
+    const uint64_t *hdr = reinterpret_cast<const uint64_t *>(slot);
+    if (slot_bytes < (size_t)kGatherHdr * 8) return fail(AMR_EINVAL, "gather slot shorter than its header");
+    if (hdr[2] > AMR_MAX_PREAMBLES || hdr[1] > hdr[0] || (size_t)kGatherHdr * 8 + hdr[1] * 12 > slot_bytes)
+        return fail(AMR_EINVAL, "gather slot header inconsistent");
+    out->n_true = hdr[0];
+    out->n_hits = hdr[1];
+    out->n_preambles = (uint32_t)hdr[2];
+    out->seq = hdr[12];
+    out->preamble_offset = hdr + 3;
+    out->hit_block = hdr + kGatherHdr;
+    out->hit_idx = reinterpret_cast<const uint32_t *>(hdr + kGatherHdr + hdr[1]);
+    return AMR_OK;
+}
+
+}  // namespace
+
+struct Comm {
+    void *comm = nullptr;
+    int rank = 0, world = 1, root = 0;
+    uint64_t cap = 0;            // records a slot holds
+    size_t slot_bytes = 0;
+    hipStream_t stream = nullptr;
+    uint8_t *d_send[2] = {nullptr, nullptr};
+    uint8_t *d_recv[2] = {nullptr, nullptr};   // root: world slots each (records land behind each slot's header bytes)
+    uint8_t *h_recv[2] = {nullptr, nullptr};   // root: pinned mirror of d_recv
+    uint8_t *d_hdr[2] = {nullptr, nullptr};    // root: world headers, contiguous (phase 1)
+    uint8_t *h_hdr[2] = {nullptr, nullptr};    // root: pinned copy of d_hdr -- the counts that size phase 2
+    uint64_t *d_zero = nullptr;                // AMR_MAX_PREAMBLES + 1 zero offsets: the packed form of an empty result
+    hipEvent_t ev_hdr = nullptr;               // root: the headers of the gather being posted are in h_hdr
+    hipEvent_t ev_host[2] = {nullptr, nullptr};   // root: the mirror of set k has arrived
+    uint64_t seq_of[2] = {~0ull, ~0ull};       // gather sequence number each set holds
+    uint64_t next_seq = 0;
+};
+
+extern "C" {
+
+size_t amr_gather_slot_bytes(uint64_t cap_hits) { return gather_slot_bytes(cap_hits); }
+size_t amr_gather_wire_bytes(uint64_t n_sent) { return gather_wire_bytes(n_sent); }
+int32_t amr_gather_two_phase(uint64_t cap_hits) { return gather_two_phase(gather_slot_bytes(cap_hits)) ? 1 : 0; }
+
+
+amr_status amr_gather_pack_host(const amr_result *res, uint64_t cap_hits, uint64_t seq, void *slot, size_t slot_bytes)
+{
+    if (!res || !slot || !res->preamble_offset || res->n_preambles > AMR_MAX_PREAMBLES) return fail(AMR_EINVAL, "null argument");
+    if (slot_bytes < gather_slot_bytes(cap_hits)) return fail(AMR_EINVAL, "amr_gather_pack_host: slot too small for the capacity");
+    if (res->preamble_offset[res->n_preambles] != res->n_hits) return fail(AMR_EINVAL, "amr_gather_pack_host: offsets do not end at n_hits");
+    gather_pack_part(res->hit_block, res->hit_idx, res->preamble_offset, res->n_preambles, cap_hits, seq,
+                     reinterpret_cast<uint64_t *>(slot), 0, 1);
+    return AMR_OK;
+}
+
+amr_status amr_gather_unpack(const void *slot, size_t slot_bytes, amr_gathered *out)
+{
+    if (!slot || !out) return fail(AMR_EINVAL, "null argument");
+    return gather_unpack(slot, slot_bytes, out);
+}
+
+amr_status amr_comm_unique_id(void *id128)
+{
+    if (!id128) return fail(AMR_EINVAL, "null argument");
+    Rccl *r = rccl();
+    if (!r) return fail(AMR_ENODEV, "RCCL (librccl.so) not found");
+    NCCL_TRY(r->GetUniqueId(id128));
+    return AMR_OK;
+}
+
+amr_status amr_comm_init(amr_handle *h, const void *id128, int32_t rank, int32_t world, int32_t root, uint64_t cap_hits)
+{
+    if (!h || !id128) return fail(AMR_EINVAL, "null argument");
+    if (world < 1 || world > 65535 || rank < 0 || rank >= world || root < 0 || root >= world || cap_hits == 0) return fail(AMR_EINVAL, "amr_comm_init: bad rank / world / capacity");
+    if (h->comm) return fail(AMR_EINVAL, "amr_comm_init: communicator exists already");
+    Rccl *r = rccl();
+    if (!r) return fail(AMR_ENODEV, "RCCL (librccl.so) not found");
+    HIP_TRY(hipSetDevice(h->device));
+    Comm *c = new (std::nothrow) Comm();
+    if (!c) return fail(AMR_ENOMEM, "Comm");
+    c->rank = rank; c->world = world; c->root = root; c->cap = cap_hits;
+    c->slot_bytes = gather_slot_bytes(cap_hits);
+    Id128 id;
+    memcpy(id.b, id128, 128);
+    int rc = r->CommInitRank(&c->comm, world, id, rank);
+    if (rc != 0) { delete c; return nccl_fail("ncclCommInitRank", rc); }
+    hipError_t e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
+    for (int k = 0; k < 2 && e == hipSuccess; ++k) {
+        e = hipMalloc((void **)&c->d_send[k], c->slot_bytes);
+        if (e == hipSuccess && rank == root) e = hipMalloc((void **)&c->d_recv[k], c->slot_bytes * (size_t)world);
+        if (e == hipSuccess && rank == root) e = hipHostMalloc((void **)&c->h_recv[k], c->slot_bytes * (size_t)world, hipHostMallocDefault);
+        if (e == hipSuccess && rank == root) e = hipEventCreateWithFlags(&c->ev_host[k], hipEventDisableTiming);
+        if (e == hipSuccess && rank == root) e = hipMalloc((void **)&c->d_hdr[k], (size_t)world * kGatherHdr * 8);
+        if (e == hipSuccess && rank == root) e = hipHostMalloc((void **)&c->h_hdr[k], (size_t)world * kGatherHdr * 8, hipHostMallocDefault);
+    }
+    if (e == hipSuccess && rank == root) e = hipEventCreateWithFlags(&c->ev_hdr, hipEventDisableTiming);
+    if (e == hipSuccess) e = hipMalloc((void **)&c->d_zero, (AMR_MAX_PREAMBLES + 1) * 8);
+    if (e == hipSuccess) e = hipMemsetAsync(c->d_zero, 0, (AMR_MAX_PREAMBLES + 1) * 8, c->stream);
+    h->comm = c;
+    if (e != hipSuccess) { (void)amr_comm_destroy(h); return fail(AMR_ENOMEM, "amr_comm_init: buffers", e); }
+    return AMR_OK;
+}
+
+amr_status amr_comm_ranks(const amr_handle *h, int32_t *n_ranks)
+{
+    if (!h || !h->comm || !n_ranks) return fail(AMR_EINVAL, "amr_comm_ranks: amr_comm_init first");
+    Rccl *r = rccl();
+    if (!r || !r->CommCount) return fail(AMR_ENODEV, "ncclCommCount not available");
+    int n = 0;
+    NCCL_TRY(r->CommCount(h->comm->comm, &n));
+    *n_ranks = n;
+    return AMR_OK;
+}
+
+amr_status amr_comm_destroy(amr_handle *h)
+{
+    if (!h || !h->comm) return AMR_OK;
+    Comm *c = h->comm;
+    (void)hipSetDevice(h->device);
+    if (c->stream) (void)hipStreamSynchronize(c->stream);
+    for (Slot &sl : h->slot) sl.pack_pending = false;
+    Rccl *r = rccl();
+    if (r && c->comm) (void)r->CommDestroy(c->comm);
+    for (int k = 0; k < 2; ++k) {
+        if (c->d_send[k]) (void)hipFree(c->d_send[k]);
+        if (c->d_recv[k]) (void)hipFree(c->d_recv[k]);
+        if (c->h_recv[k]) (void)hipHostFree(c->h_recv[k]);
+        if (c->ev_host[k]) (void)hipEventDestroy(c->ev_host[k]);
+        if (c->d_hdr[k]) (void)hipFree(c->d_hdr[k]);
+        if (c->h_hdr[k]) (void)hipHostFree(c->h_hdr[k]);
+    }
+    if (c->ev_hdr) (void)hipEventDestroy(c->ev_hdr);
+    if (c->d_zero) (void)hipFree(c->d_zero);
+    if (c->stream) (void)hipStreamDestroy(c->stream);
+    delete c;
+    h->comm = nullptr;
+    return AMR_OK;
+}
+
+amr_status amr_gather_hits(amr_handle *h, uint64_t *seq_out)
+{
+    if (!h || !h->comm) return fail(AMR_EINVAL, "amr_gather_hits: amr_comm_init first");
+    if (h->last_slot < 0 && !h->last_empty) return fail(AMR_EINVAL, "amr_gather_hits: no batch collected yet");
+    Rccl *r = rccl();
+    Comm *c = h->comm;
+    HIP_TRY(hipSetDevice(h->device));
+    // the result amr_collect / amr_flush returned last; an amr_flush with nothing deferred returned an EMPTY one: zero
+    // records travel (the slot of the batch before it still holds that batch's hits)
+    const bool empty = h->last_empty;
+    Slot *s = empty ? nullptr : &h->slot[h->last_slot];
+    const uint8_t *packed = empty ? reinterpret_cast<const uint8_t *>(c->d_zero) : (h->validate ? s->d_val : s->d_out);
+    const uint64_t *offs = empty ? c->d_zero : (h->validate ? s->d_offs_val : s->d_offs_pre);
+    const uint64_t n_host = empty ? 0 : h->last_total;                 // = offs[n_pre] on the device
+    const uint64_t m_host = n_host < c->cap ? n_host : c->cap;         // records this rank sends
+    const uint64_t seq = c->next_seq++;
+    const int k = (int)(seq & 1);
+    // on the communicator's stream: behind the sends (and the root's mirror kernel) that last used buffer set k
+    hipLaunchKernelGGL(k_gather_pack, dim3(64), dim3(256), 0, c->stream, packed, offs, h->sg.n_pre, c->cap, seq,
+                       reinterpret_cast<uint64_t *>(c->d_send[k]));
+    HIP_TRY(hipGetLastError());
+    if (s) {   // whoever overwrites this slot's result next waits for the pack kernel (enqueue_tail)
+        HIP_TRY(hipEventRecord(s->ev_pack, c->stream));
+        s->pack_pending = true;
+    }
+    const size_t hdr_bytes = (size_t)kGatherHdr * 8;
+    if (!gather_two_phase(c->slot_bytes)) {
+        // ---- small slots: the whole slot in one message, no host wait anywhere ----
+        NCCL_TRY(r->GroupStart());
+        NCCL_TRY(r->Send(c->d_send[k], c->slot_bytes, kNcclUint8, c->root, c->comm, c->stream));
+        if (c->rank == c->root)
+            for (int p = 0; p < c->world; ++p)
+                NCCL_TRY(r->Recv(c->d_recv[k] + (size_t)p * c->slot_bytes, c->slot_bytes, kNcclUint8, p, c->comm, c->stream));
+        NCCL_TRY(r->GroupEnd());
+        if (c->rank == c->root) {
+            hipLaunchKernelGGL(k_gather_mirror, dim3(8, (unsigned)c->world), dim3(256), 0, c->stream, (const uint8_t *)nullptr, c->d_recv[k], c->h_recv[k], c->slot_bytes);
+            HIP_TRY(hipGetLastError());
+            HIP_TRY(hipEventRecord(c->ev_host[k], c->stream));
+        }
+        c->seq_of[k] = seq;
+        if (seq_out) *seq_out = seq;
+        return AMR_OK;
+    }
+    // ---- phase 1: the headers ----
+    NCCL_TRY(r->GroupStart());
+    NCCL_TRY(r->Send(c->d_send[k], hdr_bytes, kNcclUint8, c->root, c->comm, c->stream));
+    if (c->rank == c->root)
+        for (int p = 0; p < c->world; ++p)
+            NCCL_TRY(r->Recv(c->d_hdr[k] + (size_t)p * hdr_bytes, hdr_bytes, kNcclUint8, p, c->comm, c->stream));
+    NCCL_TRY(r->GroupEnd());
+    // ---- phase 2: the records, sized by their count ----
+    if (c->rank != c->root) {
+        if (m_host) NCCL_TRY(r->Send(c->d_send[k] + hdr_bytes, gather_wire_bytes(m_host), kNcclUint8, c->root, c->comm, c->stream));
+    } else {
+        HIP_TRY(hipMemcpyAsync(c->h_hdr[k], c->d_hdr[k], (size_t)c->world * hdr_bytes, hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(hipEventRecord(c->ev_hdr, c->stream));
+        HIP_TRY(hipEventSynchronize(c->ev_hdr));        // every rank has posted this gather; 128 bytes each
+        const uint64_t *hh = reinterpret_cast<const uint64_t *>(c->h_hdr[k]);
+        for (int p = 0; p < c->world; ++p) {
+            const uint64_t *hp = hh + (size_t)p * kGatherHdr;
+            if (hp[1] > c->cap || hp[1] > hp[0] || hp[12] != seq)
+                return fail(AMR_EHIP, "amr_gather_hits: a rank's header is inconsistent (ranks out of step, or capacities differ)");
+        }
+        NCCL_TRY(r->GroupStart());
+        if (m_host) NCCL_TRY(r->Send(c->d_send[k] + hdr_bytes, gather_wire_bytes(m_host), kNcclUint8, c->root, c->comm, c->stream));
+        for (int p = 0; p < c->world; ++p) {
+            const uint64_t m_p = hh[(size_t)p * kGatherHdr + 1];
+            if (m_p) NCCL_TRY(r->Recv(c->d_recv[k] + (size_t)p * c->slot_bytes + hdr_bytes, gather_wire_bytes(m_p), kNcclUint8, p, c->comm, c->stream));
+        }
+        NCCL_TRY(r->GroupEnd());
+        hipLaunchKernelGGL(k_gather_mirror, dim3(8, (unsigned)c->world), dim3(256), 0, c->stream, c->d_hdr[k], c->d_recv[k], c->h_recv[k], c->slot_bytes);
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipEventRecord(c->ev_host[k], c->stream));
+    }
+    c->seq_of[k] = seq;
+    if (seq_out) *seq_out = seq;
+    return AMR_OK;
+}
+
+amr_status amr_gather_wait(amr_handle *h)
+{
+    if (!h || !h->comm) return fail(AMR_EINVAL, "amr_gather_wait: amr_comm_init first");
+    HIP_TRY(hipSetDevice(h->device));
+    HIP_TRY(hipStreamSynchronize(h->comm->stream));
+    return AMR_OK;
+}
+
+amr_status amr_gather_fetch(amr_handle *h, uint64_t seq, int32_t src_rank, amr_gathered *out)
+{
+    if (!h || !h->comm || !out) return fail(AMR_EINVAL, "amr_gather_fetch: null argument / no communicator");
+    Comm *c = h->comm;
+    if (c->rank != c->root) return fail(AMR_EINVAL, "amr_gather_fetch: only the root holds the gathered records");
+    if (src_rank < 0 || src_rank >= c->world) return fail(AMR_EINVAL, "amr_gather_fetch: bad rank");
+    const int k = (int)(seq & 1);
+    if (c->seq_of[k] != seq) return fail(AMR_EINVAL, "amr_gather_fetch: that gather was never posted or its records have been overwritten (two sets)");
+    HIP_TRY(hipSetDevice(h->device));
+    HIP_TRY(hipEventSynchronize(c->ev_host[k]));      // the mirror copy of this gather, nothing else
+    AMR_TRY(gather_unpack(c->h_recv[k] + (size_t)src_rank * c->slot_bytes, c->slot_bytes, out));
+    if (out->seq != seq) return fail(AMR_EHIP, "amr_gather_fetch: a rank's slot carries another gather's sequence number (ranks out of step)");
+    return AMR_OK;
+}
+
+}  // extern "C"

@@ -91,9 +91,9 @@ struct K1Args {
     uint32_t wg_first;     // first wave-tile of this launch
     uint32_t zero_halo;    // 1: magnitudes before batch block 0 are 0.0 (fresh Decoder, decode.go:144)
     // 1: wave-tile 0 of the launch lies in the head buffer (blocks deferred from the previous batch in front, the first
-    // blocks of this batch copied in behind them, see submit() in amrdemod.hip); wave-tiles >= 1 are at iq + row * bs2
+    // blocks of this batch copied in behind them, see submit() in amr_pipeline.hip); wave-tiles >= 1 are at iq + row * bs2
     uint32_t head_rows;
-    // Pipelined callers (amrdemod.hip, submit): the LAST workgroup of the batch's last K1 launch stores started_value here
+    // Pipelined callers (amr_pipeline.hip, submit): the LAST workgroup of the batch's last K1 launch stores started_value here
     // when it starts -- by then every wave of the launch has its slot.  A gate kernel on the second stream waits for it and
     // lets the previous batch's K3 in: its workgroups then find room only where K1 waves retire, i.e. they fill the ragged
     // end of this launch instead of standing in front of it.  null: no announcement.

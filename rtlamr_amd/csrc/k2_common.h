@@ -29,6 +29,7 @@
 namespace amr {
 
 constexpr int kMaxPre = 8;
+constexpr int kR900Digits = 42;   // PayloadSymbols, r900.go:30 (K4, k4_r900.h)
 
 // Every group sum in a cache line of its own: sum i lives at word i * kGroupStride.  They are the targets of one
 // atomicAdd per list from workgroups that all finish at about the same time; packed (round 3: the 33 sums of 1 GiB of

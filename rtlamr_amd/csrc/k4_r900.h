@@ -16,9 +16,10 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include "k2_common.h"
+
 namespace amr {
 
-constexpr int kR900Digits = 42;   // PayloadSymbols, r900.go:30
 constexpr uint32_t kK4Split = 4;   // waves per 64-hit chunk, one distinct Decode call each
 
 struct K4Args {

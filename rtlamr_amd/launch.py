@@ -66,14 +66,18 @@ def rank_plan(gpus: int, env: Mapping[str, str], n_devices: int, port: Optional[
 def spawn_ranks(argv: Sequence[str], envs: Sequence[Mapping[str, str]], base_env: Optional[Mapping[str, str]] = None,
                 poll_s: float = 0.05) -> int:
     """Start one process per entry of `envs` (argv identical, environment = base_env + envs[r]), wait for all of them and
-    return the largest exit code.  Rank 0 inherits stdout (its single JSON line is the job's output); the other ranks'
-    stdout goes to stderr.  When a rank fails, the others get SIGTERM (by PID) so that nobody waits in a collective
-    forever."""
+    return the job's exit code: 0 when every rank exited 0, otherwise the code of the FIRST rank seen failing (a negative
+    Popen code = killed by a signal -> 128 + signal).  Rank 0 inherits stdout (its single JSON line is the job's output);
+    the other ranks' stdout goes to stderr.  When a rank fails, the others get SIGTERM (by PID) so that nobody waits in a
+    collective forever; the exit status of a rank this function terminated itself (-SIGTERM, or whatever its handler
+    turned that into) says nothing about the job and is not folded in -- bench.py's refusal / mismatch codes (2, 3 ... 7)
+    reach the caller as they are."""
     base = dict(os.environ if base_env is None else base_env)
     procs: List[subprocess.Popen] = []
     for r, e in enumerate(envs):
         procs.append(subprocess.Popen(list(argv), env={**base, **e}, stdout=None if r == 0 else sys.stderr))
     rc = 0
+    terminated = set()      # ranks that were sent SIGTERM by us
     try:
         live = set(range(len(procs)))
         while live:
@@ -82,10 +86,13 @@ def spawn_ranks(argv: Sequence[str], envs: Sequence[Mapping[str, str]], base_env
                 if code is None:
                     continue
                 live.discard(r)
-                if code != 0:
-                    rc = max(rc, code if code > 0 else 128 - code)
-                    for o in sorted(live):          # a failed rank: the others would hang in the next collective
-                        procs[o].send_signal(signal.SIGTERM)
+                if code == 0 or r in terminated:
+                    continue
+                if rc == 0:
+                    rc = code if code > 0 else 128 - code
+                for o in sorted(live - terminated):     # a failed rank: the others would hang in the next collective
+                    procs[o].send_signal(signal.SIGTERM)
+                    terminated.add(o)
             if live:
                 time.sleep(poll_s)
     finally:
@@ -93,3 +100,4 @@ def spawn_ranks(argv: Sequence[str], envs: Sequence[Mapping[str, str]], base_env
             if p.poll() is None:
                 p.kill()
     return rc
+

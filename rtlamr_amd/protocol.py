@@ -76,10 +76,15 @@ class Message:
     def MeterType(self) -> int: raise NotImplementedError
     def Checksum(self) -> bytes: raise NotImplementedError
 
-    # Message.Record (parse.go:83: the CSV / JSON / XML columns) is output plumbing, out of scope here: the
-    # mirrors keep the four identifying methods the receive loop's dedupe reads (protocol.NewDigest, parse.go:95-101)
+    # csv.Recorder (parse.go:83) and fmt.Stringer: the columns main.go's CSV / JSON / plain encoders print.  Off the hot
+    # path and optional: the formats live in rtlamr_amd/parsers/record.py, loaded on first use
+    def Record(self) -> List[str]:
+        from .parsers import record
+        return record.record(self)
+
     def __str__(self):
-        return f"{{{self.MsgType()} ID:{self.MeterID()} Type:{self.MeterType()} Checksum:0x{bytes(self.Checksum()).hex().upper()}}}"
+        from .parsers import record
+        return record.string(self)
 
 
 class Parser:

@@ -136,3 +136,34 @@ def test_run_parsers_groups_hits_per_block_and_preamble():
         [("SCM", 111)],                              # block 10: two hits, identical bytes -> one message (seen map)
         [("IDM", 333), ("NetIDM", 333)],             # block 11: the shared preamble feeds both parsers
         [("SCM", 222)]]                              # block 12
+
+
+def test_message_records_have_the_reference_columns():
+    """Message.Record / String (parse.go:78-84): idm.IDM (idm/idm.go:176-221): 16 scalar columns + 47
+    intervals; netidm (netidm/netidm.go:186-235): 15 + 27; hex fields zero-padded upper case, byte-slice fields as plain
+    hex, the serial right-aligned in String; scm (scm/scm.go:139-154), scm+ (scmplus/scmplus.go:129-150), r900
+    (r900/r900.go:278-302): Record uses strconv's lower-case unpadded hex, String fmt's padded upper case."""
+    from rtlamr_amd.parsers.idm import IDM, NetIDM, SCMPlus
+    from rtlamr_amd.parsers.r900 import R900
+    from rtlamr_amd.parsers.scm import SCM
+    m = IDM(0x555516A3, 0x1C, 0x5C, 0xC6, 4, 7, 12345678, 3, 0xBC, bytes([1, 2, 3, 4, 5, 6]), 0x12, bytes(6), 99,
+            list(range(47)), 17, 0xABCD, 0x1D0F)
+    r = m.Record()
+    assert len(r) == 16 + 47 and r[0] == "0x555516A3" and r[4] == "0x04" and r[6] == "12345678"
+    assert r[9] == "010203040506" and r[10] == "0x12" and r[13:13 + 47] == [str(i) for i in range(47)]
+    assert r[-3:] == ["17", "0xABCD", "0x1D0F"]
+    s = str(m)
+    assert s.startswith("{Preamble:0x555516A3 PacketTypeID:0x1C ") and "ERTSerialNumber:  12345678 " in s
+    assert "DifferentialConsumptionIntervals:[0 1 2 " in s and s.endswith("PacketCRC:0x1D0F}")
+    n = NetIDM(0x555516A3, 0x1C, 0x5C, 0xC6, 4, 7, 123, 3, 0xBC, 5, 6, 7, list(range(27)), 17, 0xABCD, 0x1D0F)
+    assert len(n.Record()) == 15 + 27 and n.Record()[9:12] == ["5", "6", "7"]
+    assert "LastGeneration:5 LastConsumption:6 LastConsumptionNet:7 " in str(n)
+    c = SCM(ID=17581447, Type=12, TamperPhy=2, TamperEnc=1, Consumption=5810, ChecksumVal=0x0B7E)
+    assert c.Record() == ["17581447", "12", "0x2", "0x1", "5810", "0xb7e"]
+    assert str(c) == "{ID:17581447 Type:12 Tamper:{Phy:02 Enc:01} Consumption:    5810 CRC:0x0B7E}"
+    p = SCMPlus(0x16A3, 0x1E, 0xAB, 42, 1234, 0x0102, 0x00FF)
+    assert p.Record() == ["0x16a3", "0x1e", "0xab", "42", "1234", "0x102", "0xff"]
+    assert str(p) == "{ProtocolID:0x1E EndpointType:0xAB EndpointID:        42 Consumption:      1234 Tamper:0x0102 PacketCRC:0x00FF}"
+    w = R900(ID=1234, Unkn1=0xA3, NoUse=5, BackFlow=1, Consumption=99, Unkn3=2, Leak=3, LeakNow=0, checksum=b"\x01\x02")
+    assert w.Record() == ["1234", "163", "5", "1", "99", "2", "3", "0"]
+    assert str(w) == "{ID:      1234 Unkn1:0xA3 NoUse: 5 BackFlow:1 Consumption:      99 Unkn3:0x02 Leak: 3 LeakNow:0}"

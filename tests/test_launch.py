@@ -54,7 +54,7 @@ def test_a_launchers_rank_is_taken_as_is():
     assert launch.rank_plan(4, env, 8) == ("rank", [])
 
 
-def test_spawner_starts_every_rank_and_reports_the_worst_exit_code(tmp_path):
+def test_spawner_starts_every_rank_and_reports_the_first_failure(tmp_path):
     child = ("import os, sys, json; r = os.environ['RANK'];"
              f"open(os.path.join({str(tmp_path)!r}, 'rank' + r + '.json'), 'w').write(json.dumps(dict("
              "rank=r, local=os.environ['LOCAL_RANK'], world=os.environ['WORLD_SIZE'], port=os.environ['MASTER_PORT'])));"
@@ -73,7 +73,13 @@ def test_spawner_starts_every_rank_and_reports_the_worst_exit_code(tmp_path):
     # one rank fails: the job's exit code is non-zero and the rank that would wait forever is terminated
     bad = "import os, sys, time; sys.exit(3) if os.environ['RANK'] == '1' else time.sleep(60)"
     rc = launch.spawn_ranks([sys.executable, "-c", bad], envs)
-    assert rc != 0
+    assert rc == 3          # the failing rank's own code: not 143 = the SIGTERM this function sent the others
+    # a rank killed by a signal nobody here sent: 128 + signal
+    killed = "import os, signal, time; os.kill(os.getpid(), signal.SIGKILL) if os.environ['RANK'] == '2' else time.sleep(60)"
+    assert launch.spawn_ranks([sys.executable, "-c", killed], envs) == 128 + 9
+    # two ranks fail with different codes: the first one seen failing decides
+    two = "import os, sys, time; r = os.environ['RANK']; time.sleep(0 if r == '0' else 1.5); sys.exit(6 if r == '0' else 7 if r == '1' else 0)"
+    assert launch.spawn_ranks([sys.executable, "-c", two], envs) == 6
 
 
 def test_bench_refuses_instead_of_running_one_rank():

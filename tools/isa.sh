@@ -1,9 +1,9 @@
 #!/bin/bash
-# tools/isa.sh <regex on mangled kernel name> : compile amrdemod.hip with -save-temps into /tmp/k1asm and
+# tools/isa.sh <regex on mangled kernel name> : compile amr_pipeline.hip (K3 .. K5; pass another unit as $2) with -save-temps into /tmp/k1asm and
 # print resource usage of matching kernels; the kernel ISA goes to /tmp/k1asm/<n>.s
 set -e
 mkdir -p /tmp/k1asm && cd /tmp/k1asm
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -fPIC ${EXTRA_FLAGS} -I/root/repo/include -I/root/repo/rtlamr_amd/csrc -save-temps -c /root/repo/rtlamr_amd/csrc/amrdemod.hip -o /tmp/k1asm/a.o
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -fPIC ${EXTRA_FLAGS} -I/root/repo/include -I/root/repo/rtlamr_amd/csrc -save-temps -c /root/repo/rtlamr_amd/csrc/${2:-amr_pipeline.hip} -o /tmp/k1asm/a.o
 S=amrdemod-hip-amdgcn-amd-amdhsa-gfx950.s
 python3 - "$1" <<'PY'
 import re,sys
