@@ -104,12 +104,20 @@ typedef struct amr_result {
     uint64_t n_blocks;
 } amr_result;
 
-/* Timing of the last batch, measured with HIP events on the handle's stream. */
+/*
+ * Timing of the last batch, measured with HIP events on the kernel dispatches.
+ *   Synchronous callers (amr_decode_batch[_device]; one stream): the whole batch -- demod_ms = K1, search_ms = K2 through
+ *   the last kernel of the tail (K3 slice, K4 r900 digits, K5 validation), total_ms = first kernel start to last kernel end.
+ *   Pipelined callers (two or more batches in flight): the tail of a batch runs on a second stream next to
+ *   the FOLLOWING batch's kernels and has no duration that could be added to a step.  The fields then describe what the
+ *   batch cost the compute stream: demod_ms = K1, search_ms = K2 only, total_ms = demod_ms + search_ms -- whether the
+ *   tail was enqueued ahead behind its gate or launched by the host.  A whole-path figure comes from wall-clock time over
+ *   many batches (bench.py: steady_ms_per_step), not from these.
+ */
 typedef struct amr_timing {
     float demod_ms;   /* K1: magnitude + csum matched filter + quantize + pack */
-    float search_ms;  /* K2 + K3: preamble search, compaction, slice (pipelined callers: K2 only -- K3 of a batch runs
-                         on a second stream next to the end of the following batch's K1 and has no duration of its own) */
-    float total_ms;   /* first kernel start to last kernel end (device side) */
+    float search_ms;  /* synchronous: K2 + K3 (+ K4, K5); pipelined: K2 only (see above) */
+    float total_ms;   /* synchronous: first kernel start to last kernel end; pipelined: demod_ms + search_ms */
 } amr_timing;
 
 /* ---- lifecycle -------------------------------------------------------- */

@@ -139,11 +139,14 @@ __global__ void k_gather_pack(const uint8_t *packed, const uint64_t *offs, uint3
 // Root: headers (received contiguously, phase 1) and records (phase 2, in place behind each rank's header slot) of all
 // ranks -> the pinned host mirror, laid out as slots again.  grid (x, world): the x blocks of rank p share its records.
 // (d_hdr null: the slots arrived whole, every header sits in front of its records)
-__global__ void k_gather_mirror(const uint8_t *d_hdr, const uint8_t *d_recv, uint8_t *h_recv, size_t slot_bytes)
+// `cap`: records a slot holds -- a header that claims more (a rank out of step, another capacity) must not make this kernel
+// write past the slot in the mirror: the count is clamped, amr_gather_fetch rejects the header itself.
+__global__ void k_gather_mirror(const uint8_t *d_hdr, const uint8_t *d_recv, uint8_t *h_recv, size_t slot_bytes, uint64_t cap)
 {
     const uint32_t p = blockIdx.y;
     const uint4 *hdr = reinterpret_cast<const uint4 *>(d_hdr ? d_hdr + (size_t)p * kGatherHdr * 8 : d_recv + (size_t)p * slot_bytes);
-    const uint64_t m = reinterpret_cast<const uint64_t *>(hdr)[1];
+    const uint64_t m_hdr = reinterpret_cast<const uint64_t *>(hdr)[1];
+    const uint64_t m = m_hdr < cap ? m_hdr : cap;
     uint4 *dst = reinterpret_cast<uint4 *>(h_recv + (size_t)p * slot_bytes);
     const uint4 *src = reinterpret_cast<const uint4 *>(d_recv + (size_t)p * slot_bytes);
     const uint64_t n16 = kGatherHdr * 8 / 16 + (m * 12 + 15) / 16;
@@ -184,6 +187,7 @@ struct Comm {
     hipEvent_t ev_hdr = nullptr;               // root: the headers of the gather being posted are in h_hdr
     hipEvent_t ev_host[2] = {nullptr, nullptr};   // root: the mirror of set k has arrived
     uint64_t seq_of[2] = {~0ull, ~0ull};       // gather sequence number each set holds
+    bool failed[2] = {false, false};           // root: that gather's headers did not fit; amr_gather_fetch refuses it
     uint64_t next_seq = 0;
 };
 
@@ -305,6 +309,7 @@ amr_status amr_gather_hits(amr_handle *h, uint64_t *seq_out)
     const uint64_t m_host = n_host < c->cap ? n_host : c->cap;         // records this rank sends
     const uint64_t seq = c->next_seq++;
     const int k = (int)(seq & 1);
+    c->failed[k] = false;
     // on the communicator's stream: behind the sends (and the root's mirror kernel) that last used buffer set k
     hipLaunchKernelGGL(k_gather_pack, dim3(64), dim3(256), 0, c->stream, packed, offs, h->sg.n_pre, c->cap, seq,
                        reinterpret_cast<uint64_t *>(c->d_send[k]));
@@ -323,7 +328,7 @@ amr_status amr_gather_hits(amr_handle *h, uint64_t *seq_out)
                 NCCL_TRY(r->Recv(c->d_recv[k] + (size_t)p * c->slot_bytes, c->slot_bytes, kNcclUint8, p, c->comm, c->stream));
         NCCL_TRY(r->GroupEnd());
         if (c->rank == c->root) {
-            hipLaunchKernelGGL(k_gather_mirror, dim3(8, (unsigned)c->world), dim3(256), 0, c->stream, (const uint8_t *)nullptr, c->d_recv[k], c->h_recv[k], c->slot_bytes);
+            hipLaunchKernelGGL(k_gather_mirror, dim3(8, (unsigned)c->world), dim3(256), 0, c->stream, (const uint8_t *)nullptr, c->d_recv[k], c->h_recv[k], c->slot_bytes, c->cap);
             HIP_TRY(hipGetLastError());
             HIP_TRY(hipEventRecord(c->ev_host[k], c->stream));
         }
@@ -346,19 +351,30 @@ amr_status amr_gather_hits(amr_handle *h, uint64_t *seq_out)
         HIP_TRY(hipEventRecord(c->ev_hdr, c->stream));
         HIP_TRY(hipEventSynchronize(c->ev_hdr));        // every rank has posted this gather; 128 bytes each
         const uint64_t *hh = reinterpret_cast<const uint64_t *>(c->h_hdr[k]);
+        // A header that does not fit (a rank out of step, or capacities that differ) fails this gather -- but only AFTER the
+        // receives of phase 2 have been posted: every peer with records has its send enqueued already and would otherwise
+        // block on the communicator's stream for ever.  The sizes it advertised are taken at their word up to
+        // the slot's capacity (a sender cannot have more in its own slot); amr_gather_fetch refuses the gather's records.
+        bool consistent = true;
         for (int p = 0; p < c->world; ++p) {
             const uint64_t *hp = hh + (size_t)p * kGatherHdr;
-            if (hp[1] > c->cap || hp[1] > hp[0] || hp[12] != seq)
-                return fail(AMR_EHIP, "amr_gather_hits: a rank's header is inconsistent (ranks out of step, or capacities differ)");
+            if (hp[1] > c->cap || hp[1] > hp[0] || hp[12] != seq) consistent = false;
         }
         NCCL_TRY(r->GroupStart());
         if (m_host) NCCL_TRY(r->Send(c->d_send[k] + hdr_bytes, gather_wire_bytes(m_host), kNcclUint8, c->root, c->comm, c->stream));
         for (int p = 0; p < c->world; ++p) {
-            const uint64_t m_p = hh[(size_t)p * kGatherHdr + 1];
+            const uint64_t m_adv = hh[(size_t)p * kGatherHdr + 1], m_p = m_adv < c->cap ? m_adv : c->cap;
             if (m_p) NCCL_TRY(r->Recv(c->d_recv[k] + (size_t)p * c->slot_bytes + hdr_bytes, gather_wire_bytes(m_p), kNcclUint8, p, c->comm, c->stream));
         }
         NCCL_TRY(r->GroupEnd());
-        hipLaunchKernelGGL(k_gather_mirror, dim3(8, (unsigned)c->world), dim3(256), 0, c->stream, c->d_hdr[k], c->d_recv[k], c->h_recv[k], c->slot_bytes);
+        if (!consistent) {
+            c->seq_of[k] = seq;
+            c->failed[k] = true;
+            HIP_TRY(hipEventRecord(c->ev_host[k], c->stream));
+            if (seq_out) *seq_out = seq;
+            return fail(AMR_EHIP, "amr_gather_hits: a rank's header is inconsistent (ranks out of step, or capacities differ); the gather's records are refused");
+        }
+        hipLaunchKernelGGL(k_gather_mirror, dim3(8, (unsigned)c->world), dim3(256), 0, c->stream, c->d_hdr[k], c->d_recv[k], c->h_recv[k], c->slot_bytes, c->cap);
         HIP_TRY(hipGetLastError());
         HIP_TRY(hipEventRecord(c->ev_host[k], c->stream));
     }
@@ -383,6 +399,7 @@ amr_status amr_gather_fetch(amr_handle *h, uint64_t seq, int32_t src_rank, amr_g
     if (src_rank < 0 || src_rank >= c->world) return fail(AMR_EINVAL, "amr_gather_fetch: bad rank");
     const int k = (int)(seq & 1);
     if (c->seq_of[k] != seq) return fail(AMR_EINVAL, "amr_gather_fetch: that gather was never posted or its records have been overwritten (two sets)");
+    if (c->failed[k]) return fail(AMR_EHIP, "amr_gather_fetch: that gather failed (a rank's header was inconsistent)");
     HIP_TRY(hipSetDevice(h->device));
     HIP_TRY(hipEventSynchronize(c->ev_host[k]));      // the mirror copy of this gather, nothing else
     AMR_TRY(gather_unpack(c->h_recv[k] + (size_t)src_rank * c->slot_bytes, c->slot_bytes, out));

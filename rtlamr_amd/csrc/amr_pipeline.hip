@@ -630,13 +630,14 @@ amr_status collect(amr_handle *h, amr_result *res)
     float a = 0, b = 0, c = 0;
     h->timing_valid = false;
     if (s.timed && hipEventSynchronize(s.ev1) == hipSuccess && hipEventElapsedTime(&a, s.ev0, s.ev1) == hipSuccess) {
-        float b2 = 0;
-        if (s.timed >= 2 && s.search && s.tail_split && hipEventSynchronize(s.ev2) == hipSuccess &&
-            hipEventElapsedTime(&b, s.ev_s, s.ev_k2) == hipSuccess && hipEventElapsedTime(&b2, s.ev_t, s.ev2) == hipSuccess)
-            // K2 and the tail ran apart: their durations, added up -- unless the tail was let in at the following K1's start
-            // (tail_gated): its workgroups then trickle in where K1 waves retire and its "duration" spans that whole K1;
-            // what the batch cost the compute stream besides K1 is its K2
-            h->timing = s.tail_gated ? amr_timing{a, b, a + b} : amr_timing{a, b + b2, a + b + b2};
+        if (s.timed >= 2 && s.search && s.tail_split && hipEventSynchronize(s.ev_k2) == hipSuccess &&
+            hipEventElapsedTime(&b, s.ev_s, s.ev_k2) == hipSuccess)
+            // K2 and the tail ran apart (pipelined callers): what the batch cost the compute stream besides K1 is its K2.
+            // The tail (K3, K4, K5) runs on the second stream next to the following batch's kernels -- let in behind a gate
+            // at that K1's start, its workgroups trickle in where K1 waves retire and its dispatch spans that whole K1;
+            // launched by the host, it runs next to that batch's search -- and has no duration that could be added to
+            // the step: the same three numbers in either case (include/amrdemod.h, amr_timing)
+            h->timing = amr_timing{a, b, a + b};
         else if (s.timed >= 2 && s.search && !s.tail_split && hipEventSynchronize(s.ev2) == hipSuccess &&
             hipEventElapsedTime(&b, s.ev_s, s.ev2) == hipSuccess && hipEventElapsedTime(&c, s.ev0, s.ev2) == hipSuccess)
             h->timing = amr_timing{a, b, c};
