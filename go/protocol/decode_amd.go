@@ -79,12 +79,23 @@ type Decoder struct {
 	// takes it from the environment: AMR_DEVICE, else LOCAL_RANK (one process per
 	// GPU, the deployment amr_comm_* is made for), else 0.
 	Device int
+	// Devices, when it names more than one HIP device, makes this ONE Decoder drive all of them from this one process
+	// (the reference caller is one process, main.go:59-128): Allocate opens a handle per device and joins them in one
+	// RCCL communicator (amr_comm_init_all: the grouped form a single thread needs), and every Decode call's blocks are
+	// cut into len(Devices) contiguous ranges, range r decoded on Devices[r] after priming it with the blocks in front of
+	// the range (amr_prime) -- the split SURVEY.md 8e describes, results identical to one device's.  Empty: Device alone.  (KeepQuantized reads back handle 0's range only: a
+	// diagnostic, use one device for it.)
+	Devices []int
 
 	st *amdState // shared by the copies Decode's value receiver makes
 }
 
 type amdState struct {
-	h          *C.amr_handle
+	h          *C.amr_handle       // the only handle, or the one on Devices[0]
+	hs         []*C.amr_handle     // Devices: one handle per device, hs[0] == h (nil for a single device)
+	tail       []byte              // Devices: the last prime-blocks + halo bytes of the stream so far (history of range 0)
+	pin        unsafe.Pointer      // Devices: pinned staging of tail ++ input (amr_host_alloc)
+	pinCap     int
 	parsers    []Parser            // in registration order
 	preambles  map[string][]Parser // key: Cfg().Preamble
 	order      []string            // distinct preambles in registration order
@@ -195,8 +206,33 @@ func (d *Decoder) Allocate() {
 	if dev < 0 {
 		dev = deviceFromEnv()
 	}
-	if st := C.amr_create(&protos[0], C.int32_t(len(protos)), C.int32_t(dev), &s.h); st != C.AMR_OK {
-		fatal("amr_create", st)
+	if len(d.Devices) > 1 {
+		// one handle per device, then ONE grouped communicator init for all of them (a loop of amr_comm_init from this
+		// single thread would wait in the first ncclCommInitRank for ever)
+		ords := make([]C.int32_t, len(d.Devices))
+		for i, v := range d.Devices {
+			ords[i] = C.int32_t(v)
+		}
+		if st := C.amr_comm_check_all(nil, &ords[0], C.int32_t(len(ords)), 0, 1<<16); st != C.AMR_OK {
+			fatal("amr_comm_check_all", st)
+		}
+		s.hs = make([]*C.amr_handle, len(d.Devices))
+		for i := range d.Devices {
+			if st := C.amr_create(&protos[0], C.int32_t(len(protos)), ords[i], &s.hs[i]); st != C.AMR_OK {
+				fatal("amr_create", st)
+			}
+		}
+		if st := C.amr_comm_init_all(&s.hs[0], C.int32_t(len(s.hs)), 0, 1<<16); st != C.AMR_OK {
+			fatal("amr_comm_init_all", st)
+		}
+		s.h = s.hs[0]
+	} else {
+		if len(d.Devices) == 1 {
+			dev = d.Devices[0]
+		}
+		if st := C.amr_create(&protos[0], C.int32_t(len(protos)), C.int32_t(dev), &s.h); st != C.AMR_OK {
+			fatal("amr_create", st)
+		}
 	}
 	var g C.amr_geometry
 	if st := C.amr_get_geometry(s.h, &g); st != C.AMR_OK {
@@ -225,43 +261,46 @@ func (d Decoder) Decode(input []byte) chan Message {
 	if nBlocks == 0 {
 		panic("runtime error: index out of range") // what decode.go:222 does with a short block
 	}
-	var res C.amr_result
-	// input is Go memory: the library reads it during the call only (cgo pointer rules)
-	if st := C.amr_decode_batch(s.h, (*C.uint8_t)(unsafe.Pointer(&input[0])), C.size_t(nBlocks*bs2),
-		C.size_t(nBlocks), &res); st != C.AMR_OK {
-		fatal("amr_decode_batch", st)
-	}
-	n := int(res.n_hits)
-	np := int(res.n_preambles)
-	pb := int(res.pkt_bytes)
-	off := unsafe.Slice((*uint64)(unsafe.Pointer(res.preamble_offset)), np+1)
-	var blk []uint64
-	var idx []uint32
-	var pkt []byte
-	if n > 0 {
-		blk = unsafe.Slice((*uint64)(unsafe.Pointer(res.hit_block)), n)
-		idx = unsafe.Slice((*uint32)(unsafe.Pointer(res.hit_idx)), n)
-		pkt = unsafe.Slice((*byte)(unsafe.Pointer(res.pkt)), n*pb)
-	}
-	first := uint64(res.first_block) // = s.calls: amr_decode_batch never defers
-	s.calls += uint64(nBlocks)
-
-	// The result arrays belong to the handle until the next amr_* call: turn them
-	// into []Data now (NewData copies the bytes, parse.go:61-69).  Hits of a
-	// preamble are sorted by (call, idx), so one pass per preamble splits them by call.
+	first := s.calls // call index of input's first block
+	np := len(s.order)
 	type perCall [][]Data // [preamble id][]Data
 	calls := make([]perCall, nBlocks)
 	for k := range calls {
 		calls[k] = make(perCall, np)
 	}
-	for p := 0; p < np; p++ {
-		for i := int(off[p]); i < int(off[p+1]); i++ {
-			k := int(blk[i] - first)
-			data := NewData(pkt[i*pb : (i+1)*pb])
-			data.Idx = int(idx[i])
-			calls[k][p] = append(calls[k][p], data)
+	// The result arrays belong to the handle until the next amr_* call on it: turn them
+	// into []Data at once (NewData copies the bytes, parse.go:61-69).  Hits of a
+	// preamble are sorted by (call, idx), so one pass per preamble splits them by call.
+	take := func(res *C.amr_result) {
+		n, pb := int(res.n_hits), int(res.pkt_bytes)
+		if n == 0 {
+			return
+		}
+		off := unsafe.Slice((*uint64)(unsafe.Pointer(res.preamble_offset)), int(res.n_preambles)+1)
+		blk := unsafe.Slice((*uint64)(unsafe.Pointer(res.hit_block)), n)
+		idx := unsafe.Slice((*uint32)(unsafe.Pointer(res.hit_idx)), n)
+		pkt := unsafe.Slice((*byte)(unsafe.Pointer(res.pkt)), n*pb)
+		for p := 0; p < int(res.n_preambles); p++ {
+			for i := int(off[p]); i < int(off[p+1]); i++ {
+				data := NewData(pkt[i*pb : (i+1)*pb])
+				data.Idx = int(idx[i])
+				k := int(blk[i] - first)
+				calls[k][p] = append(calls[k][p], data)
+			}
 		}
 	}
+	if len(s.hs) > 1 {
+		d.decodeOnDevices(input, nBlocks, first, take)
+	} else {
+		var res C.amr_result
+		// input is Go memory: the library reads it during the call only (cgo pointer rules)
+		if st := C.amr_decode_batch(s.h, (*C.uint8_t)(unsafe.Pointer(&input[0])), C.size_t(nBlocks*bs2),
+			C.size_t(nBlocks), &res); st != C.AMR_OK {
+			fatal("amr_decode_batch", st)
+		}
+		take(&res) // res.first_block == first: amr_decode_batch never defers
+	}
+	s.calls += uint64(nBlocks)
 	var q []byte
 	if d.KeepQuantized {
 		q = make([]byte, nBlocks*bs/8)
@@ -300,9 +339,102 @@ func (d Decoder) Decode(input []byte) chan Message {
 	return msgCh
 }
 
+// decodeOnDevices: one Decode call's blocks over the handles of Devices.  Range r = blocks [k0, k1) goes to hs[r], which
+// first forgets its state (amr_reset) and is primed with the amr_prime_blocks blocks in front of k0 -- out of this call's
+// input, or for the first ranges out of the tail kept from the previous calls -- so that its histories are the single
+// Decoder's (decode.go:165-166); amr_set_block_base makes its call indices the stream's.  Every range is submitted before
+// any is collected: the devices run side by side, driven by this one thread.  The hit records come back per handle
+// (host memory, `take`); a host that wants them merged on one device instead -- a replay loop that consumes validated
+// records one step behind, like bench.py -- posts amr_gather_hits_all on the same handles (INTEGRATION.md).
+func (d Decoder) decodeOnDevices(input []byte, nBlocks int, first uint64, take func(*C.amr_result)) {
+	s := d.st
+	bs2 := d.Cfg.BlockSize2
+	n := len(s.hs)
+	pb := int(C.amr_prime_blocks(s.h))
+	halo := int(C.amr_halo_bytes(s.h))
+	// the stream so far, as far back as any range's priming can reach: tail ++ input -- in pinned C memory
+	// (amr_host_alloc): amr_submit_host goes on reading its input after it has returned, which the cgo rules allow for C
+	// memory only, and pinned memory makes the transfer a true DMA
+	need := len(s.tail) + nBlocks*bs2
+	if need > s.pinCap {
+		if s.pin != nil {
+			C.amr_host_free(s.pin)
+		}
+		if st := C.amr_host_alloc(C.size_t(need), &s.pin); st != C.AMR_OK {
+			fatal("amr_host_alloc", st)
+		}
+		s.pinCap = need
+	}
+	hist := unsafe.Slice((*byte)(s.pin), need)
+	copy(hist, s.tail)
+	copy(hist[len(s.tail):], input[:nBlocks*bs2])
+	base := len(s.tail) // offset of input's first block inside hist
+	ranges := make([][2]int, n)
+	for r := 0; r < n; r++ {
+		q, rem := nBlocks/n, nBlocks%n
+		k0 := r*q + min(r, rem)
+		k1 := k0 + q
+		if r < rem {
+			k1++
+		}
+		ranges[r] = [2]int{k0, k1}
+	}
+	for r, h := range s.hs {
+		k0, k1 := ranges[r][0], ranges[r][1]
+		if st := C.amr_reset(h); st != C.AMR_OK {
+			fatal("amr_reset", st)
+		}
+		start := base + k0*bs2                  // first byte of the range inside hist
+		p0 := max(base%bs2, start-pb*bs2)       // whole blocks only, never before the stream's start
+		if p0 < start {
+			var lead *C.uint8_t
+			if p0 >= halo {
+				lead = (*C.uint8_t)(unsafe.Pointer(&hist[p0-halo]))
+			}
+			if st := C.amr_prime(h, lead, (*C.uint8_t)(unsafe.Pointer(&hist[p0])), C.size_t((start-p0)/bs2), 0); st != C.AMR_OK {
+				fatal("amr_prime", st)
+			}
+		}
+		if st := C.amr_set_block_base(h, C.uint64_t(first+uint64(k0))); st != C.AMR_OK {
+			fatal("amr_set_block_base", st)
+		}
+		if k1 > k0 {
+			if st := C.amr_submit_host(h, (*C.uint8_t)(unsafe.Pointer(&hist[start])), C.size_t((k1-k0)*bs2), C.size_t(k1-k0)); st != C.AMR_OK {
+				fatal("amr_submit_host", st)
+			}
+		}
+	}
+	for r, h := range s.hs {
+		if ranges[r][1] == ranges[r][0] {
+			continue
+		}
+		var res C.amr_result
+		if st := C.amr_collect(h, &res); st != C.AMR_OK {
+			fatal("amr_collect", st)
+		}
+		take(&res)
+	}
+	keep := pb*bs2 + halo
+	if len(hist) > keep {
+		hist = hist[len(hist)-keep:]
+	}
+	s.tail = append(s.tail[:0], hist...)
+}
+
 // Close releases the GPU decoder (no counterpart in the reference, whose buffers are garbage collected).
 func (d *Decoder) Close() {
-	if d.st != nil && d.st.h != nil {
+	if d.st == nil {
+		return
+	}
+	for _, h := range d.st.hs[min(1, len(d.st.hs)):] {
+		C.amr_destroy(h) // destroys its communicator rank first
+	}
+	d.st.hs = nil
+	if d.st.pin != nil {
+		C.amr_host_free(d.st.pin)
+		d.st.pin, d.st.pinCap = nil, 0
+	}
+	if d.st.h != nil {
 		C.amr_destroy(d.st.h)
 		d.st.h = nil
 	}

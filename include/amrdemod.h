@@ -334,6 +334,21 @@ typedef struct amr_gathered {
 amr_status amr_comm_unique_id(void *id128);   /* ncclGetUniqueId */
 amr_status amr_comm_init(amr_handle *h, const void *id128, int32_t rank, int32_t world, int32_t root, uint64_t cap_hits);
 amr_status amr_comm_destroy(amr_handle *h);
+/*
+ * The single-process form (SURVEY.md 8b "amr_create_multi"): the reference caller is ONE process (main.go:59-128), and
+ * a host that holds a handle per GPU in one thread cannot call amr_comm_init n times -- the first ncclCommInitRank
+ * would wait for ever for ranks the same thread has not initialised yet.  amr_comm_init_all makes the communicator of
+ * hs[0..n) in one RCCL group (ncclGroupStart, n x ncclCommInitRank, ncclGroupEnd): handle i is rank i, one handle per
+ * device, hs[root] receives.  amr_gather_hits_all then posts ONE gather for all n handles -- the result each handle's
+ * amr_collect / amr_flush returned last -- with every rank's sends and the root's receives inside one group, so that a
+ * single thread can drive it; amr_gather_fetch / amr_gather_wait / amr_comm_ranks / amr_comm_destroy work per handle as
+ * before (fetch on hs[root]).  amr_gather_hits on a handle of such a communicator is AMR_EINVAL when n > 1.
+ * amr_comm_check_all is the argument check alone -- handles, or (hs == NULL) the device ordinals they would sit on --
+ * and needs neither a device nor RCCL.
+ */
+amr_status amr_comm_init_all(amr_handle **hs, int32_t n, int32_t root, uint64_t cap_hits);
+amr_status amr_gather_hits_all(amr_handle **hs, int32_t n, uint64_t *seq);
+amr_status amr_comm_check_all(amr_handle *const *hs, const int32_t *devices, int32_t n, int32_t root, uint64_t cap_hits);
 /* ranks the RCCL communicator spans (ncclCommCount): lets a bench line prove the gather ran over N ranks */
 amr_status amr_comm_ranks(const amr_handle *h, int32_t *n_ranks);
 /* Enqueue the gather of the result amr_collect / amr_flush returned last (with amr_set_validation: of its surviving

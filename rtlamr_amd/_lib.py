@@ -19,7 +19,7 @@ SYMBOLS = [
     "amr_halo_bytes", "amr_prime_blocks", "amr_copy_quantized", "amr_set_timing", "amr_get_timing", "amr_strerror",
     "amr_last_error", "amr_describe", "amr_dev_alloc", "amr_dev_free", "amr_dev_upload", "amr_dev_download",
     "amr_dev_sync", "amr_synth_noise", "amr_synth_uniform", "amr_synth_plant",
-    "amr_comm_unique_id", "amr_comm_init", "amr_comm_destroy", "amr_comm_ranks", "amr_gather_hits", "amr_gather_wait", "amr_gather_fetch",
+    "amr_comm_unique_id", "amr_comm_init", "amr_comm_init_all", "amr_gather_hits_all", "amr_comm_check_all", "amr_comm_destroy", "amr_comm_ranks", "amr_gather_hits", "amr_gather_wait", "amr_gather_fetch",
     "amr_gather_slot_bytes", "amr_gather_wire_bytes", "amr_gather_two_phase", "amr_gather_pack_host", "amr_gather_unpack",
 ]
 
@@ -141,6 +141,9 @@ def lib() -> C.CDLL:
     L.amr_comm_unique_id.argtypes = [vp]
     L.amr_comm_init.argtypes = [vp, vp, C.c_int32, C.c_int32, C.c_int32, C.c_uint64]
     L.amr_comm_destroy.argtypes = [vp]
+    L.amr_comm_init_all.argtypes = [C.POINTER(vp), C.c_int32, C.c_int32, C.c_uint64]
+    L.amr_gather_hits_all.argtypes = [C.POINTER(vp), C.c_int32, C.POINTER(C.c_uint64)]
+    L.amr_comm_check_all.argtypes = [C.POINTER(vp), C.POINTER(C.c_int32), C.c_int32, C.c_int32, C.c_uint64]
     L.amr_comm_ranks.argtypes = [vp, C.POINTER(C.c_int32)]
     L.amr_gather_hits.argtypes = [vp, C.POINTER(C.c_uint64)]
     L.amr_gather_wait.argtypes = [vp]

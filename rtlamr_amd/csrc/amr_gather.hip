@@ -187,6 +187,7 @@ struct Comm {
     hipEvent_t ev_hdr = nullptr;               // root: the headers of the gather being posted are in h_hdr
     hipEvent_t ev_host[2] = {nullptr, nullptr};   // root: the mirror of set k has arrived
     uint64_t seq_of[2] = {~0ull, ~0ull};       // gather sequence number each set holds
+    bool local_world = false;                  // every rank of the communicator lives in THIS process (amr_comm_init_all, n > 1)
     bool failed[2] = {false, false};           // root: that gather's headers did not fit; amr_gather_fetch refuses it
     uint64_t next_seq = 0;
 };
@@ -223,22 +224,11 @@ amr_status amr_comm_unique_id(void *id128)
     return AMR_OK;
 }
 
-amr_status amr_comm_init(amr_handle *h, const void *id128, int32_t rank, int32_t world, int32_t root, uint64_t cap_hits)
+// the buffers of a communicator that exists (c->comm, rank, world, root, cap set); on failure the caller destroys h->comm
+static amr_status comm_alloc(amr_handle *h, Comm *c)
 {
-    if (!h || !id128) return fail(AMR_EINVAL, "null argument");
-    if (world < 1 || world > 65535 || rank < 0 || rank >= world || root < 0 || root >= world || cap_hits == 0) return fail(AMR_EINVAL, "amr_comm_init: bad rank / world / capacity");
-    if (h->comm) return fail(AMR_EINVAL, "amr_comm_init: communicator exists already");
-    Rccl *r = rccl();
-    if (!r) return fail(AMR_ENODEV, "RCCL (librccl.so) not found");
-    HIP_TRY(hipSetDevice(h->device));
-    Comm *c = new (std::nothrow) Comm();
-    if (!c) return fail(AMR_ENOMEM, "Comm");
-    c->rank = rank; c->world = world; c->root = root; c->cap = cap_hits;
-    c->slot_bytes = gather_slot_bytes(cap_hits);
-    Id128 id;
-    memcpy(id.b, id128, 128);
-    int rc = r->CommInitRank(&c->comm, world, id, rank);
-    if (rc != 0) { delete c; return nccl_fail("ncclCommInitRank", rc); }
+    const int rank = c->rank, root = c->root, world = c->world;
+    c->slot_bytes = gather_slot_bytes(c->cap);
     hipError_t e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
     for (int k = 0; k < 2 && e == hipSuccess; ++k) {
         e = hipMalloc((void **)&c->d_send[k], c->slot_bytes);
@@ -253,6 +243,84 @@ amr_status amr_comm_init(amr_handle *h, const void *id128, int32_t rank, int32_t
     if (e == hipSuccess) e = hipMemsetAsync(c->d_zero, 0, (AMR_MAX_PREAMBLES + 1) * 8, c->stream);
     h->comm = c;
     if (e != hipSuccess) { (void)amr_comm_destroy(h); return fail(AMR_ENOMEM, "amr_comm_init: buffers", e); }
+    return AMR_OK;
+}
+
+amr_status amr_comm_init(amr_handle *h, const void *id128, int32_t rank, int32_t world, int32_t root, uint64_t cap_hits)
+{
+    if (!h || !id128) return fail(AMR_EINVAL, "null argument");
+    if (world < 1 || world > 65535 || rank < 0 || rank >= world || root < 0 || root >= world || cap_hits == 0) return fail(AMR_EINVAL, "amr_comm_init: bad rank / world / capacity");
+    if (h->comm) return fail(AMR_EINVAL, "amr_comm_init: communicator exists already");
+    Rccl *r = rccl();
+    if (!r) return fail(AMR_ENODEV, "RCCL (librccl.so) not found");
+    HIP_TRY(hipSetDevice(h->device));
+    Comm *c = new (std::nothrow) Comm();
+    if (!c) return fail(AMR_ENOMEM, "Comm");
+    c->rank = rank; c->world = world; c->root = root; c->cap = cap_hits;
+    Id128 id;
+    memcpy(id.b, id128, 128);
+    int rc = r->CommInitRank(&c->comm, world, id, rank);
+    if (rc != 0) { delete c; return nccl_fail("ncclCommInitRank", rc); }
+    return comm_alloc(h, c);
+}
+
+// The argument rules of the single-process form, checked before any device or RCCL call (tests drive this on CPU).
+amr_status amr_comm_check_all(amr_handle *const *hs, const int32_t *devices, int32_t n, int32_t root, uint64_t cap_hits)
+{
+    if (n < 1 || n > 65535 || root < 0 || root >= n || cap_hits == 0) return fail(AMR_EINVAL, "amr_comm_init_all: bad handle count / root / capacity");
+    if (!hs && !devices) return fail(AMR_EINVAL, "amr_comm_init_all: null argument");
+    for (int32_t i = 0; i < n; ++i) {
+        if (hs && !hs[i]) return fail(AMR_EINVAL, "amr_comm_init_all: null handle");
+        const int32_t di = devices ? devices[i] : hs[i]->device;
+        if (di < 0) return fail(AMR_EINVAL, "amr_comm_init_all: negative device ordinal");
+        for (int32_t j = 0; j < i; ++j) {
+            if (hs && hs[j] == hs[i]) return fail(AMR_EINVAL, "amr_comm_init_all: the same handle twice");
+            // one rank per device: two ranks of one communicator on one GPU deadlock in RCCL's point-to-point kernels
+            if ((devices ? devices[j] : hs[j]->device) == di) return fail(AMR_EINVAL, "amr_comm_init_all: two handles on one device");
+        }
+        if (hs && hs[i]->comm) return fail(AMR_EINVAL, "amr_comm_init_all: a handle has a communicator already");
+    }
+    return AMR_OK;
+}
+
+amr_status amr_comm_init_all(amr_handle **hs, int32_t n, int32_t root, uint64_t cap_hits)
+{
+    if (!hs) return fail(AMR_EINVAL, "amr_comm_init_all: null argument");
+    AMR_TRY(amr_comm_check_all(hs, nullptr, n, root, cap_hits));
+    Rccl *r = rccl();
+    if (!r) return fail(AMR_ENODEV, "RCCL (librccl.so) not found");
+    Id128 id;
+    NCCL_TRY(r->GetUniqueId(&id));
+    std::vector<Comm *> cs((size_t)n, nullptr);
+    for (int32_t i = 0; i < n; ++i) {
+        cs[(size_t)i] = new (std::nothrow) Comm();
+        if (!cs[(size_t)i]) { for (Comm *c : cs) delete c; return fail(AMR_ENOMEM, "Comm"); }
+        cs[(size_t)i]->rank = i; cs[(size_t)i]->world = n; cs[(size_t)i]->root = root; cs[(size_t)i]->cap = cap_hits;
+        cs[(size_t)i]->local_world = n > 1;
+    }
+    // ONE thread initialises every rank: the calls must sit in one group, or the first ncclCommInitRank waits for ever
+    // for peers this thread has not got round to yet (the reference caller is one process, main.go:59-128)
+    int rc = r->GroupStart();
+    for (int32_t i = 0; i < n && rc == 0; ++i) {
+        if (hipSetDevice(hs[i]->device) != hipSuccess) { rc = -1; break; }
+        rc = r->CommInitRank(&cs[(size_t)i]->comm, n, id, i);
+    }
+    const int rc_end = r->GroupEnd();
+    if (rc == 0) rc = rc_end;
+    if (rc != 0) {
+        for (Comm *c : cs) { if (c->comm) (void)r->CommDestroy(c->comm); delete c; }
+        return rc == -1 ? fail(AMR_EHIP, "amr_comm_init_all: hipSetDevice") : nccl_fail("ncclCommInitRank (group)", rc);
+    }
+    for (int32_t i = 0; i < n; ++i) {
+        hipError_t e = hipSetDevice(hs[i]->device);
+        amr_status st = e == hipSuccess ? comm_alloc(hs[i], cs[(size_t)i]) : fail(AMR_EHIP, "hipSetDevice", e);
+        if (st != AMR_OK) {
+            if (e != hipSuccess) { (void)r->CommDestroy(cs[(size_t)i]->comm); delete cs[(size_t)i]; }
+            for (int32_t j = 0; j < i; ++j) (void)amr_comm_destroy(hs[j]);
+            for (int32_t j = i + 1; j < n; ++j) { (void)r->CommDestroy(cs[(size_t)j]->comm); delete cs[(size_t)j]; }
+            return st;
+        }
+    }
     return AMR_OK;
 }
 
@@ -292,95 +360,153 @@ amr_status amr_comm_destroy(amr_handle *h)
     return AMR_OK;
 }
 
-amr_status amr_gather_hits(amr_handle *h, uint64_t *seq_out)
+}  // extern "C"
+
+namespace {
+
+struct GatherStep { uint64_t seq = 0, m_host = 0; int k = 0; };
+
+// One gather for the n handles of `hs` -- n == 1: the rank of a one-process-per-GPU job; n > 1: every rank of a
+// communicator made by amr_comm_init_all, driven by ONE thread, which therefore must post the matching sends and
+// receives of all ranks inside one RCCL group (a lone ncclRecv on the root may wait on the host for a peer this thread
+// has not served yet).  Same wire protocol in either case.
+amr_status gather_many(amr_handle *const *hs, int n, uint64_t *seq_out)
 {
-    if (!h || !h->comm) return fail(AMR_EINVAL, "amr_gather_hits: amr_comm_init first");
-    if (h->last_slot < 0 && !h->last_empty) return fail(AMR_EINVAL, "amr_gather_hits: no batch collected yet");
     Rccl *r = rccl();
-    Comm *c = h->comm;
-    HIP_TRY(hipSetDevice(h->device));
-    // the result amr_collect / amr_flush returned last; an amr_flush with nothing deferred returned an EMPTY one: zero
-    // records travel (the slot of the batch before it still holds that batch's hits)
-    const bool empty = h->last_empty;
-    Slot *s = empty ? nullptr : &h->slot[h->last_slot];
-    const uint8_t *packed = empty ? reinterpret_cast<const uint8_t *>(c->d_zero) : (h->validate ? s->d_val : s->d_out);
-    const uint64_t *offs = empty ? c->d_zero : (h->validate ? s->d_offs_val : s->d_offs_pre);
-    const uint64_t n_host = empty ? 0 : h->last_total;                 // = offs[n_pre] on the device
-    const uint64_t m_host = n_host < c->cap ? n_host : c->cap;         // records this rank sends
-    const uint64_t seq = c->next_seq++;
-    const int k = (int)(seq & 1);
-    c->failed[k] = false;
-    // on the communicator's stream: behind the sends (and the root's mirror kernel) that last used buffer set k
-    hipLaunchKernelGGL(k_gather_pack, dim3(64), dim3(256), 0, c->stream, packed, offs, h->sg.n_pre, c->cap, seq,
-                       reinterpret_cast<uint64_t *>(c->d_send[k]));
-    HIP_TRY(hipGetLastError());
-    if (s) {   // whoever overwrites this slot's result next waits for the pack kernel (enqueue_tail)
-        HIP_TRY(hipEventRecord(s->ev_pack, c->stream));
-        s->pack_pending = true;
-    }
+    std::vector<GatherStep> g((size_t)n);
     const size_t hdr_bytes = (size_t)kGatherHdr * 8;
-    if (!gather_two_phase(c->slot_bytes)) {
+    amr_handle *root_h = nullptr;
+    // ---- every rank: the pack kernel on its communicator's stream, behind the sends (and the root's mirror kernel) that
+    // last used buffer set k ----
+    for (int i = 0; i < n; ++i) {
+        amr_handle *h = hs[i];
+        Comm *c = h->comm;
+        HIP_TRY(hipSetDevice(h->device));
+        // the result amr_collect / amr_flush returned last; an amr_flush with nothing deferred returned an EMPTY one: zero
+        // records travel (the slot of the batch before it still holds that batch's hits)
+        const bool empty = h->last_empty;
+        Slot *s = empty ? nullptr : &h->slot[h->last_slot];
+        const uint8_t *packed = empty ? reinterpret_cast<const uint8_t *>(c->d_zero) : (h->validate ? s->d_val : s->d_out);
+        const uint64_t *offs = empty ? c->d_zero : (h->validate ? s->d_offs_val : s->d_offs_pre);
+        const uint64_t n_host = empty ? 0 : h->last_total;                 // = offs[n_pre] on the device
+        g[(size_t)i].m_host = n_host < c->cap ? n_host : c->cap;           // records this rank sends
+        g[(size_t)i].seq = c->next_seq++;
+        g[(size_t)i].k = (int)(g[(size_t)i].seq & 1);
+        c->failed[g[(size_t)i].k] = false;
+        hipLaunchKernelGGL(k_gather_pack, dim3(64), dim3(256), 0, c->stream, packed, offs, h->sg.n_pre, c->cap, g[(size_t)i].seq,
+                           reinterpret_cast<uint64_t *>(c->d_send[g[(size_t)i].k]));
+        HIP_TRY(hipGetLastError());
+        if (s) {   // whoever overwrites this slot's result next waits for the pack kernel (enqueue_tail)
+            HIP_TRY(hipEventRecord(s->ev_pack, c->stream));
+            s->pack_pending = true;
+        }
+        if (c->rank == c->root) root_h = h;
+        if (g[(size_t)i].seq != g[0].seq) return fail(AMR_EINVAL, "amr_gather_hits_all: the handles' gathers are out of step");
+    }
+    const uint64_t seq = g[0].seq;
+    const int k = g[0].k;
+    Comm *rc = root_h ? root_h->comm : nullptr;                            // the root's communicator, when the root is ours
+    auto finish_root = [&](const uint8_t *d_hdr) -> amr_status {
+        HIP_TRY(hipSetDevice(root_h->device));
+        hipLaunchKernelGGL(k_gather_mirror, dim3(8, (unsigned)rc->world), dim3(256), 0, rc->stream, d_hdr, rc->d_recv[k], rc->h_recv[k], rc->slot_bytes, rc->cap);
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipEventRecord(rc->ev_host[k], rc->stream));
+        return AMR_OK;
+    };
+    if (!gather_two_phase(hs[0]->comm->slot_bytes)) {
         // ---- small slots: the whole slot in one message, no host wait anywhere ----
         NCCL_TRY(r->GroupStart());
-        NCCL_TRY(r->Send(c->d_send[k], c->slot_bytes, kNcclUint8, c->root, c->comm, c->stream));
-        if (c->rank == c->root)
-            for (int p = 0; p < c->world; ++p)
-                NCCL_TRY(r->Recv(c->d_recv[k] + (size_t)p * c->slot_bytes, c->slot_bytes, kNcclUint8, p, c->comm, c->stream));
-        NCCL_TRY(r->GroupEnd());
-        if (c->rank == c->root) {
-            hipLaunchKernelGGL(k_gather_mirror, dim3(8, (unsigned)c->world), dim3(256), 0, c->stream, (const uint8_t *)nullptr, c->d_recv[k], c->h_recv[k], c->slot_bytes, c->cap);
-            HIP_TRY(hipGetLastError());
-            HIP_TRY(hipEventRecord(c->ev_host[k], c->stream));
+        for (int i = 0; i < n; ++i) {
+            Comm *c = hs[i]->comm;
+            HIP_TRY(hipSetDevice(hs[i]->device));
+            NCCL_TRY(r->Send(c->d_send[k], c->slot_bytes, kNcclUint8, c->root, c->comm, c->stream));
+            if (c->rank == c->root)
+                for (int p = 0; p < c->world; ++p)
+                    NCCL_TRY(r->Recv(c->d_recv[k] + (size_t)p * c->slot_bytes, c->slot_bytes, kNcclUint8, p, c->comm, c->stream));
         }
-        c->seq_of[k] = seq;
+        NCCL_TRY(r->GroupEnd());
+        if (rc) AMR_TRY(finish_root(nullptr));
+        for (int i = 0; i < n; ++i) hs[i]->comm->seq_of[k] = seq;
         if (seq_out) *seq_out = seq;
         return AMR_OK;
     }
     // ---- phase 1: the headers ----
     NCCL_TRY(r->GroupStart());
-    NCCL_TRY(r->Send(c->d_send[k], hdr_bytes, kNcclUint8, c->root, c->comm, c->stream));
-    if (c->rank == c->root)
-        for (int p = 0; p < c->world; ++p)
-            NCCL_TRY(r->Recv(c->d_hdr[k] + (size_t)p * hdr_bytes, hdr_bytes, kNcclUint8, p, c->comm, c->stream));
+    for (int i = 0; i < n; ++i) {
+        Comm *c = hs[i]->comm;
+        HIP_TRY(hipSetDevice(hs[i]->device));
+        NCCL_TRY(r->Send(c->d_send[k], hdr_bytes, kNcclUint8, c->root, c->comm, c->stream));
+        if (c->rank == c->root)
+            for (int p = 0; p < c->world; ++p)
+                NCCL_TRY(r->Recv(c->d_hdr[k] + (size_t)p * hdr_bytes, hdr_bytes, kNcclUint8, p, c->comm, c->stream));
+    }
     NCCL_TRY(r->GroupEnd());
-    // ---- phase 2: the records, sized by their count ----
-    if (c->rank != c->root) {
-        if (m_host) NCCL_TRY(r->Send(c->d_send[k] + hdr_bytes, gather_wire_bytes(m_host), kNcclUint8, c->root, c->comm, c->stream));
-    } else {
-        HIP_TRY(hipMemcpyAsync(c->h_hdr[k], c->d_hdr[k], (size_t)c->world * hdr_bytes, hipMemcpyDeviceToHost, c->stream));
-        HIP_TRY(hipEventRecord(c->ev_hdr, c->stream));
-        HIP_TRY(hipEventSynchronize(c->ev_hdr));        // every rank has posted this gather; 128 bytes each
-        const uint64_t *hh = reinterpret_cast<const uint64_t *>(c->h_hdr[k]);
+    // ---- phase 2: the records, sized by their count.  A rank that is not the root knows its count on the host and never
+    // waits; the root needs every peer's count before it can post its receives (RCCL point-to-point wants matching
+    // sizes) and waits for the 128-byte headers -- with all ranks in one thread, that wait comes first for everybody ----
+    bool consistent = true;
+    const uint64_t *hh = nullptr;
+    if (rc) {
+        HIP_TRY(hipSetDevice(root_h->device));
+        HIP_TRY(hipMemcpyAsync(rc->h_hdr[k], rc->d_hdr[k], (size_t)rc->world * hdr_bytes, hipMemcpyDeviceToHost, rc->stream));
+        HIP_TRY(hipEventRecord(rc->ev_hdr, rc->stream));
+        HIP_TRY(hipEventSynchronize(rc->ev_hdr));        // every rank has posted this gather; 128 bytes each
+        hh = reinterpret_cast<const uint64_t *>(rc->h_hdr[k]);
         // A header that does not fit (a rank out of step, or capacities that differ) fails this gather -- but only AFTER the
         // receives of phase 2 have been posted: every peer with records has its send enqueued already and would otherwise
         // block on the communicator's stream for ever.  The sizes it advertised are taken at their word up to
         // the slot's capacity (a sender cannot have more in its own slot); amr_gather_fetch refuses the gather's records.
-        bool consistent = true;
-        for (int p = 0; p < c->world; ++p) {
+        for (int p = 0; p < rc->world; ++p) {
             const uint64_t *hp = hh + (size_t)p * kGatherHdr;
-            if (hp[1] > c->cap || hp[1] > hp[0] || hp[12] != seq) consistent = false;
+            if (hp[1] > rc->cap || hp[1] > hp[0] || hp[12] != seq) consistent = false;
         }
-        NCCL_TRY(r->GroupStart());
-        if (m_host) NCCL_TRY(r->Send(c->d_send[k] + hdr_bytes, gather_wire_bytes(m_host), kNcclUint8, c->root, c->comm, c->stream));
-        for (int p = 0; p < c->world; ++p) {
-            const uint64_t m_adv = hh[(size_t)p * kGatherHdr + 1], m_p = m_adv < c->cap ? m_adv : c->cap;
-            if (m_p) NCCL_TRY(r->Recv(c->d_recv[k] + (size_t)p * c->slot_bytes + hdr_bytes, gather_wire_bytes(m_p), kNcclUint8, p, c->comm, c->stream));
-        }
-        NCCL_TRY(r->GroupEnd());
-        if (!consistent) {
-            c->seq_of[k] = seq;
-            c->failed[k] = true;
-            HIP_TRY(hipEventRecord(c->ev_host[k], c->stream));
-            if (seq_out) *seq_out = seq;
-            return fail(AMR_EHIP, "amr_gather_hits: a rank's header is inconsistent (ranks out of step, or capacities differ); the gather's records are refused");
-        }
-        hipLaunchKernelGGL(k_gather_mirror, dim3(8, (unsigned)c->world), dim3(256), 0, c->stream, c->d_hdr[k], c->d_recv[k], c->h_recv[k], c->slot_bytes, c->cap);
-        HIP_TRY(hipGetLastError());
-        HIP_TRY(hipEventRecord(c->ev_host[k], c->stream));
     }
-    c->seq_of[k] = seq;
+    NCCL_TRY(r->GroupStart());
+    for (int i = 0; i < n; ++i) {
+        Comm *c = hs[i]->comm;
+        HIP_TRY(hipSetDevice(hs[i]->device));
+        if (g[(size_t)i].m_host)
+            NCCL_TRY(r->Send(c->d_send[k] + hdr_bytes, gather_wire_bytes(g[(size_t)i].m_host), kNcclUint8, c->root, c->comm, c->stream));
+        if (c->rank == c->root)
+            for (int p = 0; p < c->world; ++p) {
+                const uint64_t m_adv = hh[(size_t)p * kGatherHdr + 1], m_p = m_adv < c->cap ? m_adv : c->cap;
+                if (m_p) NCCL_TRY(r->Recv(c->d_recv[k] + (size_t)p * c->slot_bytes + hdr_bytes, gather_wire_bytes(m_p), kNcclUint8, p, c->comm, c->stream));
+            }
+    }
+    NCCL_TRY(r->GroupEnd());
+    for (int i = 0; i < n; ++i) hs[i]->comm->seq_of[k] = seq;
     if (seq_out) *seq_out = seq;
+    if (rc && !consistent) {
+        rc->failed[k] = true;
+        HIP_TRY(hipSetDevice(root_h->device));
+        HIP_TRY(hipEventRecord(rc->ev_host[k], rc->stream));
+        return fail(AMR_EHIP, "amr_gather_hits: a rank's header is inconsistent (ranks out of step, or capacities differ); the gather's records are refused");
+    }
+    if (rc) AMR_TRY(finish_root(rc->d_hdr[k]));
     return AMR_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+amr_status amr_gather_hits(amr_handle *h, uint64_t *seq_out)
+{
+    if (!h || !h->comm) return fail(AMR_EINVAL, "amr_gather_hits: amr_comm_init first");
+    if (h->last_slot < 0 && !h->last_empty) return fail(AMR_EINVAL, "amr_gather_hits: no batch collected yet");
+    if (h->comm->local_world) return fail(AMR_EINVAL, "amr_gather_hits: this communicator's ranks share one process (amr_comm_init_all): use amr_gather_hits_all");
+    return gather_many(&h, 1, seq_out);
+}
+
+amr_status amr_gather_hits_all(amr_handle **hs, int32_t n, uint64_t *seq_out)
+{
+    if (!hs || n < 1) return fail(AMR_EINVAL, "amr_gather_hits_all: null argument");
+    for (int32_t i = 0; i < n; ++i) {
+        if (!hs[i] || !hs[i]->comm) return fail(AMR_EINVAL, "amr_gather_hits_all: amr_comm_init_all first");
+        if (hs[i]->comm->world != n || hs[i]->comm->rank != i) return fail(AMR_EINVAL, "amr_gather_hits_all: pass the handles of amr_comm_init_all, in its order");
+        if (hs[i]->last_slot < 0 && !hs[i]->last_empty) return fail(AMR_EINVAL, "amr_gather_hits_all: a handle has no collected batch yet");
+    }
+    return gather_many(hs, n, seq_out);
 }
 
 amr_status amr_gather_wait(amr_handle *h)

@@ -259,3 +259,89 @@ class CommGatherer:
                 raise OverflowError(f"rank {r} had {n_true} hit records, the gather capacity is {self.cap}")
             rows.append(rows_from_gathered(off, blk, idx))
         return np.concatenate(rows) if rows else np.zeros((0, 3), np.int64)
+
+
+def check_device_group(devices, root: int = 0, cap_hits: int = 1 << 16) -> None:
+    """The argument rules of amr_comm_init_all for a set of device ordinals, from the library itself (amr_comm_check_all:
+    no device, no RCCL): one handle per device, root inside the group, a capacity.  Raises AmrError (AMR_EINVAL)."""
+    import ctypes as C
+    from . import _lib
+    arr = (C.c_int32 * len(devices))(*[int(d) for d in devices])
+    _lib.check(_lib.lib().amr_comm_check_all(None, arr, len(devices), root, cap_hits), "amr_comm_check_all")
+
+
+class DeviceGroup:
+    """ONE process, one Decoder per GPU -- the shape of the reference caller (main.go:59-128 is one process) and what a
+    cgo host gets from `Decoder.Devices` (go/protocol/decode_amd.go): the stream is cut into block ranges, decoder r owns
+    range r, primed with the blocks in front of it; the hit records meet on decoders[root] through the C ABI's
+    single-process communicator (amr_comm_init_all / amr_gather_hits_all: every rank's sends and the root's receives in
+    one RCCL group, so that one thread can drive all of them).
+
+        grp = DeviceGroup(make_decoder, devices=[0, 1, 2, 3])      # make_decoder(device_id) -> allocated Decoder
+        rows = grp.decode(iq)                                      # int64[n,3] (pid, call, idx) == one Decoder's result
+    """
+
+    def __init__(self, make_decoder, devices, root: int = 0, cap_hits: int = 1 << 16):
+        import ctypes as C
+        from . import _lib
+        check_device_group(devices, root, cap_hits)
+        self.devices, self.root, self.cap = list(devices), root, cap_hits
+        self.decoders = [make_decoder(d) for d in self.devices]
+        self._arr = (C.c_void_p * len(self.decoders))(*[d._require() for d in self.decoders])
+        _lib.check(_lib.lib().amr_comm_init_all(self._arr, len(self.decoders), root, cap_hits), "amr_comm_init_all")
+        self.last_seq = -1
+
+    @property
+    def world(self) -> int:
+        return len(self.decoders)
+
+    def plan(self, total_blocks: int):
+        """[(k0, k1, p0)] per decoder: its block range and the first block it is primed with."""
+        out = []
+        for r, dec in enumerate(self.decoders):
+            k0, k1 = shard_range(total_blocks, self.world, r)
+            p0, _ = prime_range(k0, dec.prime_blocks())
+            out.append((k0, k1, p0))
+        return out
+
+    def post(self) -> int:
+        """One gather for all decoders (the result each one collected last); returns its sequence number at once."""
+        import ctypes as C
+        from . import _lib
+        seq = C.c_uint64(0)
+        _lib.check(_lib.lib().amr_gather_hits_all(self._arr, self.world, C.byref(seq)), "amr_gather_hits_all")
+        self.last_seq = int(seq.value)
+        return self.last_seq
+
+    def result(self, seq: int = None) -> np.ndarray:
+        """int64[n,3] rows (pid, call, idx) of gather `seq` (default: the last), all decoders in range order."""
+        seq = self.last_seq if seq is None else seq
+        rows = []
+        for r in range(self.world):
+            n_true, off, blk, idx = self.decoders[self.root].gather_fetch(r, seq)
+            if n_true > len(blk):
+                raise OverflowError(f"decoder {r} had {n_true} hit records, the gather capacity is {self.cap}")
+            rows.append(rows_from_gathered(off, blk, idx))
+        return np.concatenate(rows) if rows else np.zeros((0, 3), np.int64)
+
+    def decode(self, iq: np.ndarray) -> np.ndarray:
+        """The whole stream `iq` (whole blocks, from the stream start) through the group: every decoder its range."""
+        d0 = self.decoders[0]
+        bs2 = d0.Cfg.BlockSize2
+        total = iq.size // bs2
+        for dec, (k0, k1, p0) in zip(self.decoders, self.plan(total)):
+            dec.reset()
+            if k0 > p0:
+                dec.prime(iq[p0 * bs2: k0 * bs2], iq[p0 * bs2 - dec.halo_bytes(): p0 * bs2] if p0 > 0 else None)
+            dec.set_block_base(k0)
+            if k1 > k0:
+                dec.decode_batch(iq[k0 * bs2: k1 * bs2])
+            else:
+                dec.flush()          # an empty range: an empty result to gather
+        self.post()
+        return self.result()
+
+    def close(self) -> None:
+        for d in self.decoders:
+            d.close()
+        self.decoders = []

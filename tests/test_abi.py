@@ -116,3 +116,32 @@ def test_plan_geometry_equals_oracle_for_every_protocol_set_and_chip_length(amr_
     g = _lib.AmrGeometry()
     assert amr_lib.amr_plan(bad, 1, C.byref(g), None) == _lib.AMR_EINVAL
     assert amr_lib.amr_plan(None, 1, C.byref(g), None) == _lib.AMR_EINVAL
+
+
+def test_single_process_communicator_argument_rules(amr_lib):
+    """amr_comm_check_all: the rules of amr_comm_init_all (one handle per device, root inside the group, a capacity),
+    checked before any device or RCCL call -- what a host can ask on a box without a GPU (VERDICT r04 #6)."""
+    from rtlamr_amd import _lib, dist
+
+    def rc(devices, root=0, cap=1 << 12):
+        arr = (C.c_int32 * max(1, len(devices)))(*devices)
+        return amr_lib.amr_comm_check_all(None, arr, len(devices), root, cap)
+    assert rc([0]) == _lib.AMR_OK and rc([0, 1, 2, 3, 4, 5, 6, 7], root=7) == _lib.AMR_OK and rc([3, 1]) == _lib.AMR_OK
+    assert rc([]) == _lib.AMR_EINVAL                       # no rank
+    assert rc([0, 1], root=2) == _lib.AMR_EINVAL           # root outside the group
+    assert rc([0, 1], root=-1) == _lib.AMR_EINVAL
+    assert rc([0, 1], cap=0) == _lib.AMR_EINVAL
+    assert rc([0, 1, 0]) == _lib.AMR_EINVAL                # two ranks of one communicator on one device
+    assert b"one device" in amr_lib.amr_last_error()
+    assert rc([0, -1]) == _lib.AMR_EINVAL
+    assert amr_lib.amr_comm_check_all(None, None, 1, 0, 1) == _lib.AMR_EINVAL
+    assert amr_lib.amr_comm_init_all(None, 1, 0, 1) == _lib.AMR_EINVAL
+    assert amr_lib.amr_gather_hits_all(None, 1, None) == _lib.AMR_EINVAL
+    dist.check_device_group([0, 1, 2, 3])
+    with pytest.raises(_lib.AmrError):
+        dist.check_device_group([0, 0])
+    # the block ranges a group of 8 gives a stream: contiguous, whole, in order; priming never reaches before the stream
+    total, world, pb = 1000, 8, 5
+    ranges = [dist.shard_range(total, world, r) for r in range(world)]
+    assert ranges[0][0] == 0 and ranges[-1][1] == total and all(a[1] == b[0] for a, b in zip(ranges, ranges[1:]))
+    assert [dist.prime_range(k0, pb)[0] for k0, _ in ranges] == [max(0, k0 - pb) for k0, _ in ranges]

@@ -201,3 +201,62 @@ def test_pipelined_gathers_carry_their_own_batch(tmp_path):
         if d.value:
             L.amr_dev_free(0, d)
         dec.close()
+
+
+def _group_case(devices, protos=("scm", "idm"), chip=72, n_blocks=200, cap_hits=1 << 16):
+    """DeviceGroup (ONE process, one decoder per device, amr_comm_init_all / amr_gather_hits_all) against the oracle."""
+    from rtlamr_amd import dist
+    import rtlamr_amd as ra
+
+    def mk(dev):
+        d = ra.new_decoder(dev)
+        for p in protos:
+            d.RegisterProtocol(ra.new_parser(p, chip))
+        d.Allocate()
+        return d
+    grp = dist.DeviceGroup(mk, devices, root=0, cap_hits=cap_hits)
+    try:
+        bs = grp.decoders[0].Cfg.BlockSize
+        iq, _ = util.synth_stream(list(protos), chip, n_blocks, bs, seed=57, n_packets=10, edge_every=2)
+        _, _, want, _ = util.oracle_run(list(protos), chip, iq)
+        assert len(want) > 0
+        for _ in range(2):                                   # twice: the two buffer sets, amr_reset between streams
+            got = grp.decode(iq)
+            order = np.lexsort((got[:, 2], got[:, 1], got[:, 0]))
+            assert np.array_equal(got[order], want), "the group's gathered hits differ from the single decoder's"
+        assert all(d.comm_ranks() == len(devices) for d in grp.decoders)
+    finally:
+        grp.close()
+
+
+@pytest.mark.parametrize("cap_hits", [1 << 12, 1 << 16], ids=["whole-slot", "two-phase"])
+def test_single_process_group_of_one_device(cap_hits):
+    """amr_comm_init_all / amr_gather_hits_all with n = 1: what every MI355X box can run -- the grouped init, the
+    grouped gather (send to self + receive inside one group), both wire forms."""
+    _group_case([0], cap_hits=cap_hits)
+
+
+def test_single_process_group_refuses_the_one_rank_gather_and_bad_handle_sets():
+    import ctypes as C
+    from rtlamr_amd import _lib
+    L = _lib.lib()
+    dec = util.make_decoder(["scm"], 72)
+    try:
+        arr = (C.c_void_p * 2)(dec._require(), dec._require())
+        assert L.amr_comm_init_all(arr, 2, 0, 1 << 12) == _lib.AMR_EINVAL        # the same handle twice
+        assert L.amr_gather_hits_all(arr, 1, None) == _lib.AMR_EINVAL            # no communicator yet
+        one = (C.c_void_p * 1)(dec._require())
+        _lib.check(L.amr_comm_init_all(one, 1, 0, 1 << 12), "amr_comm_init_all")
+        assert L.amr_comm_init_all(one, 1, 0, 1 << 12) == _lib.AMR_EINVAL        # exists already
+        assert L.amr_gather_hits_all(one, 1, None) == _lib.AMR_EINVAL            # nothing collected yet
+    finally:
+        dec.close()
+
+
+def test_single_process_group_of_two_devices():
+    """The real thing: two GPUs, ONE thread holding both handles (skipped on 1-GPU boxes)."""
+    from rtlamr_amd import _lib
+    if _lib.device_count() < 2:
+        pytest.skip("needs two gfx950 devices")
+    _group_case([0, 1], cap_hits=1 << 12)
+    _group_case([1, 0], protos=("scm",), n_blocks=333, cap_hits=1 << 16)
