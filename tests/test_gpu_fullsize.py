@@ -39,6 +39,9 @@ CASES = [("cfg2", 0), ("cfg2", 3), ("cfg3", 0), ("cfg5", 0)] + [(f"cfg4:{c}", 0)
 # (every LUT entry, every magnitude sum far from the synthetic noise floor; nothing planted: the hits are the search's
 # false positives, 2^-21 of all positions)
 CASES.append(("cfg2+uniform", 0))
+# shards behind the first at BlockSize 8192 (amr_prime with 14 history blocks) and at BlockSize 512 (chip 8: 1 Mi blocks):
+# what ranks 1..7 of the 8-GPU run do first
+CASES += [("cfg3", 5), ("cfg5", 2), ("cfg4:8", 7)]
 
 
 def _rows_pkt(dec, br):
