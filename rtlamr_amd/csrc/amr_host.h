@@ -79,6 +79,7 @@ struct Slot {
     bool tail_split = false;      // ... on the second stream
     bool tail_gated = false;      // ... enqueued ahead, behind k_gate: K3 then runs next to the following K1's end and search
     bool folded = false;          // the state update ran inside the search kernel: no stream-A ticket for this batch
+    bool single = false;          // the batch was one block through the one-launch path (k1_single.h): h_out holds its result already
     hipEvent_t ev_k2 = nullptr, ev_t = nullptr;   // K2 stop, K3 start (timing level 2 with the tail on the second stream)
     hipEvent_t ev_pack = nullptr; bool pack_pending = false;   // multi-GPU gather: its pack kernel still reads d_out / d_val of this slot
     // the batch in flight
@@ -123,6 +124,8 @@ struct amr_handle {
     bool lazy_tail = false;
     uint64_t *d_tail_done = nullptr;   // device word: ticket of the last batch whose second-stream part has finished
     uint64_t *d_k1_started = nullptr;  // device word: ticket of the last batch whose K1 has all its waves on the chip (k_gate)
+    uint64_t gate_timeout_ticks = 400000000ull;   // k_gate gives up after this many 100 MHz ticks (4 s; test hook AMR_GATE_TIMEOUT_US)
+    uint64_t gate_timeouts = 0;   // batches searched again because their gate gave up (amr_describe)
     uint64_t *h_flags = nullptr;  // pinned: [0] ticket of the last batch whose search has started, [1] whose stream-A part is done
     bool timing_valid = false;
     amr_timing timing{};
@@ -144,6 +147,10 @@ struct amr_handle {
     int dense_streak = 0;        // consecutive batches whose sparse lists overflowed; >= 4: stay dense for a while
     int dense_hold = 0;          // batches left in which the dense kernel is used straight away
     uint8_t *d_iq = nullptr;      size_t iq_cap = 0;       // staging for host input
+    uint8_t *h_iq1 = nullptr;    // pinned: the block of a one-block amr_decode_batch (read by k_single_block over the link)
+    bool no_single = false;      // test hook AMR_NO_SINGLE: one-block calls take the regular kernels
+    unsigned long long *d_single_dbg = nullptr;   // AMR_SINGLE_DBG: 8 phase time stamps of the last k_single_block (pinned)
+    bool single_ready = false;   // k_single_block's dynamic LDS limit has been raised
     uint32_t *d_untile = nullptr; size_t untile_words = 0;
 
     struct Comm *comm = nullptr;   // multi-GPU hit gather (amr_comm_init), see the section at the end of this file

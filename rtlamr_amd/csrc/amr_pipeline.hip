@@ -7,6 +7,7 @@
 #include "launch.h"
 #include "k3_slice.h"
 #include "k4_r900.h"
+#include "k1_single.h"
 
 using namespace amr_host;
 
@@ -353,7 +354,8 @@ amr_status submit(amr_handle *h, const uint8_t *d_iq, size_t n_blocks, bool sear
     // behind K2 on the compute stream 0.289; the gate's extra delay -- 0, 6 or 20 us --, whether it is enqueued before
     // or behind K2, and stream priorities make no difference that survives the run-to-run noise.)
     if (gate_prev) {
-        hipLaunchKernelGGL(amr::k_gate, dim3(1), dim3(1), 0, h->tail_stream, h->d_k1_started, s.ticket, 600u /* 6 us */);
+        hipLaunchKernelGGL(amr::k_gate, dim3(1), dim3(1), 0, h->tail_stream, h->d_k1_started, s.ticket, 600u /* 6 us */,
+                           h->gate_timeout_ticks, prev.d_overflow);
         HIP_TRY(hipGetLastError());
         AMR_TRY(launch_tail(h, prev));
         prev.tail_gated = true;
@@ -378,6 +380,7 @@ amr_status submit(amr_handle *h, const uint8_t *d_iq, size_t n_blocks, bool sear
         if (lazy) AMR_TRY(enqueue_k2(h, s, st, false, s.dense, true, &ha, &folded));
         else AMR_TRY(enqueue_search(h, s, false, s.dense));
     }
+    s.single = false;
     s.tail_enqueued = !lazy;
     s.tail_split = lazy;
     s.tail_gated = false;
@@ -413,6 +416,69 @@ amr_status submit(amr_handle *h, const uint8_t *d_iq, size_t n_blocks, bool sear
     h->zero_halo = false;
     h->n_head = new_head;
     if (search) h->calls_done += rows;
+    s.pending = true;
+    h->n_pending++;
+    h->next_slot = (h->next_slot + 1) % kSlots;
+    return AMR_OK;
+}
+
+// One block, nothing in flight: the whole Decode call as ONE launch (k1_single.h) -- demodulation, search, slice, state
+// update and ticket by one workgroup, the result written straight into the slot's pinned host mirror.  `iq`: the block
+// in device memory, or in pinned host memory (the kernel reads it over the link: 8 to 16 KiB, one round trip).
+// Bookkeeping as submit(): the batch is left "in flight" for collect(), which finds nothing to copy.
+bool single_block_ok(const amr_handle *h, size_t n_blocks, const void *iq)
+{
+    return n_blocks == 1 && !h->no_single && h->n_pending == 0 && h->n_head == 0 && !h->validate && h->r900_pid < 0 &&
+           !h->dense_search && h->dense_hold == 0 && (reinterpret_cast<uintptr_t>(iq) & 15u) == 0 &&
+           amr::k_single_lds_bytes(h->sg) <= 160 * 1024 - 512;
+}
+
+amr_status submit_single(amr_handle *h, const uint8_t *iq)
+{
+    HIP_TRY(hipSetDevice(h->device));
+    Slot &s = h->slot[h->next_slot];
+    Slot &other = h->slot[(h->next_slot + 1) % kSlots];
+    AMR_TRY(ensure_capacity(h, s, other, 1));
+    const size_t rec = 12 + h->sg.pkt_bytes;
+    if (s.host_cap < s.out_cap) {             // the kernel writes the pinned mirror itself: it must hold what the device buffer holds
+        AMR_TRY(host_realloc(s.h_out, s.out_cap * rec));
+        s.host_cap = s.out_cap;
+    }
+    const size_t lds = amr::k_single_lds_bytes(h->sg);
+    if (!h->single_ready) {
+        HIP_TRY(hipFuncSetAttribute((const void *)amr::k_single_block, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        h->single_ready = true;
+    }
+    s.ticket = h->next_ticket++;
+    s.d_iq = iq;
+    s.n_blocks = 1;
+    s.n_tiles = 2;
+    s.search = true;
+    s.calls_base = h->calls_done + h->block_base;
+    s.iqhist_valid = h->iqhist_valid;
+    s.iqhist_buf = h->iqhist_cur;
+    s.timed = h->timing_level;
+    s.dense = false;
+    amr::SingleArgs a{};
+    a.iq = iq; a.carry = h->d_head; a.carry_out = h->d_head; a.lut = h->d_lut;
+    a.qt = s.d_qt; a.qt_next = other.d_qt; a.ovf_next = other.d_overflow;
+    a.gcnt_next = other.d_gcnt; a.gcnt_words = other.gcnt_words;
+    a.out = s.d_out; a.h_out = s.h_out; a.cap = s.out_cap;
+    a.offs_pre = s.d_offs_pre; a.h_offs_pre = s.h_off; a.h_overflow = s.h_ovf;
+    a.block_base = s.calls_base;
+    a.done_flag = s.h_done; a.adone_flag = &h->h_flags[1]; a.done_value = s.ticket;
+    a.chip_length = (uint32_t)h->geom.chip_length; a.halo_bytes = h->halo_bytes; a.hist_rows = h->hist_rows;
+    a.zero_halo = h->zero_halo ? 1u : 0u;
+    a.g = h->sg;
+    a.dbg = h->d_single_dbg;
+    hipExtLaunchKernelGGL(amr::k_single_block, dim3(1), dim3(amr::kSingleThreads), lds, h->stream,
+                          s.timed ? s.ev0 : nullptr, s.timed ? s.ev1 : nullptr, 0, a);
+    HIP_TRY(hipGetLastError());
+    AMR_DBG(h->stream, "k_single_block");
+    s.tail_enqueued = true; s.tail_split = false; s.tail_gated = false; s.folded = false;
+    s.single = true;
+    h->zero_halo = false;
+    h->calls_done += 1;
     s.pending = true;
     h->n_pending++;
     h->next_slot = (h->next_slot + 1) % kSlots;
@@ -553,6 +619,7 @@ amr_status collect(amr_handle *h, amr_result *res)
     uint64_t total = 0, searched = 0;
     bool use_dense = s.dense;
     if (s.search) {
+        bool searched_again = false;
         for (int attempt = 0;; ++attempt) {
             const uint32_t ovf = *s.h_ovf;
             total = s.h_off[n_pre];
@@ -562,6 +629,9 @@ amr_status collect(amr_handle *h, amr_result *res)
             // this batch is searched again with the dense kernel; the next one starts sparse again unless
             // overflows keep coming
             if (ovf & 2u) { use_dense = true; rerun = true; }
+            // the gate in front of this batch's K3 gave up waiting for the following K1 (k_gate): K3.. did not touch the
+            // result; searched again here, on the compute stream, in order behind the batch's own K2
+            if (ovf & amr::kOvfGate) { h->gate_timeouts++; rerun = true; }
             if (ovf & 1u) {   // a tile found more hits than its staging slot holds
                 s.stage_cap *= 8;
                 const uint64_t lim = (uint64_t)64 * h->geom.block_size;
@@ -588,6 +658,7 @@ amr_status collect(amr_handle *h, amr_result *res)
             // submitted before this one has been collected), so the search can simply run again.
             AMR_TRY(enqueue_search(h, s, true, use_dense));
             AMR_TRY(sync_compute(h));
+            searched_again = true;
         }
         if (use_dense && !s.dense) {
             if (++h->dense_streak >= 4) { h->dense_hold = 32; h->dense_streak = 0; }
@@ -602,7 +673,8 @@ amr_status collect(amr_handle *h, amr_result *res)
             AMR_TRY(host_realloc(s.h_out, nc * (12 + h->sg.pkt_bytes)));
             s.host_cap = nc;
         }
-        if (total) {   // on the copy stream: overlaps the next batch's kernels
+        // (the one-launch path for a single block wrote the pinned mirror itself, k1_single.h)
+        if (total && !(s.single && !searched_again)) {   // on the copy stream: overlaps the next batch's kernels
             HIP_TRY(hipMemcpyAsync(s.h_out, h->validate ? s.d_val : s.d_out, total * (12 + h->sg.pkt_bytes),
                                    hipMemcpyDeviceToHost, h->copy_stream));
             if (h->r900_pid >= 0) {
@@ -618,18 +690,26 @@ amr_status collect(amr_handle *h, amr_result *res)
             // the read-back takes as long as a K1 launch: keep an eye on the batches behind this one meanwhile.  Only
             // through the pinned flags (launch_ready_tails without last_too): asking the runtime about the COMPUTE stream
             // (hipStreamQuery) puts a marker packet behind the youngest batch's search, right in front of the next K1.
-            for (;;) {
+            // A caller that is draining its pipeline (this batch and at most one more in flight: the end of a run, or a
+            // caller that never keeps three in flight) submits nothing while it waits here: then the youngest batch's tail
+            // is launched as soon as its search has finished, next to this read-back, instead of behind it -- asked of the
+            // runtime now and then only, because that is the query that costs a marker packet.
+            const bool draining = h->n_pending <= 2;
+            for (uint32_t spin = 0;; ++spin) {
                 const hipError_t qe = hipStreamQuery(h->copy_stream);
                 if (qe == hipSuccess) break;
                 if (qe != hipErrorNotReady) return fail(AMR_EHIP, "hipStreamQuery(copy stream)", qe);
-                AMR_TRY(launch_ready_tails(h, false));
+                AMR_TRY(launch_ready_tails(h, draining && (spin & 63u) == 63u));
                 cpu_relax();
             }
         }
     }
     float a = 0, b = 0, c = 0;
     h->timing_valid = false;
-    if (s.timed && hipEventSynchronize(s.ev1) == hipSuccess && hipEventElapsedTime(&a, s.ev0, s.ev1) == hipSuccess) {
+    if (s.timed && s.single && hipEventSynchronize(s.ev1) == hipSuccess && hipEventElapsedTime(&a, s.ev0, s.ev1) == hipSuccess) {
+        h->timing = amr_timing{a, 0.f, a};     // one launch: demodulation, search and slice are not separable
+        h->timing_valid = true;
+    } else if (s.timed && hipEventSynchronize(s.ev1) == hipSuccess && hipEventElapsedTime(&a, s.ev0, s.ev1) == hipSuccess) {
         if (s.timed >= 2 && s.search && s.tail_split && hipEventSynchronize(s.ev_k2) == hipSuccess &&
             hipEventElapsedTime(&b, s.ev_s, s.ev_k2) == hipSuccess)
             // K2 and the tail ran apart (pipelined callers): what the batch cost the compute stream besides K1 is its K2.
@@ -748,6 +828,16 @@ amr_status amr_decode_batch(amr_handle *h, const uint8_t *iq, size_t iq_bytes, s
     if (iq_bytes < need) return fail(AMR_EINVAL, "short input (the Go decoder panics here, decode.go:222)");
     HIP_TRY(hipSetDevice(h->device));
     AMR_TRY(drain(h));   // the host staging buffer is single: finish what is in flight first
+    if (n_blocks == 1) {
+        // the unchanged main.go loop (main.go:235): the block goes into a pinned buffer of the handle's (8 to 16 KiB: a
+        // memcpy) and ONE launch reads it from there -- no host-to-device copy, no device-to-host copy
+        if (!h->h_iq1) HIP_TRY(hipHostMalloc((void **)&h->h_iq1, (size_t)h->geom.block_size2, hipHostMallocDefault));
+        if (single_block_ok(h, n_blocks, h->h_iq1)) {
+            memcpy(h->h_iq1, iq, need);
+            AMR_TRY(submit_single(h, h->h_iq1));
+            return collect(h, res);
+        }
+    }
     AMR_TRY(stage_host_input(h, iq, need));
     AMR_TRY(submit(h, h->d_iq, n_blocks, true));
     return collect(h, res);
@@ -757,7 +847,8 @@ amr_status amr_decode_batch_device(amr_handle *h, const void *d_iq, size_t n_blo
 {
     if (!h || !d_iq) return fail(AMR_EINVAL, "null argument");
     AMR_TRY(drain(h));
-    AMR_TRY(submit(h, (const uint8_t *)d_iq, n_blocks, true));
+    if (single_block_ok(h, n_blocks, d_iq)) AMR_TRY(submit_single(h, (const uint8_t *)d_iq));
+    else AMR_TRY(submit(h, (const uint8_t *)d_iq, n_blocks, true));
     return collect(h, res);
 }
 

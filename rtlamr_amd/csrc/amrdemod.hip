@@ -134,7 +134,10 @@ amr_status amr_create(const amr_protocol *protos, int32_t n_protos, int32_t devi
     h->device = device_id;
     h->n_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     h->dense_search = getenv("AMR_DENSE_SEARCH") != nullptr;   // test hook: force the fallback search kernel
-    if (const char *hc = getenv("AMR_HIT_CAP")) h->init_hit_cap = std::max<uint64_t>(256, strtoull(hc, nullptr, 10));
+    if (const char *gt = getenv("AMR_GATE_TIMEOUT_US")) h->gate_timeout_ticks = strtoull(gt, nullptr, 10) * 100ull;   // test hook
+    if (getenv("AMR_SINGLE_DBG")) (void)hipHostMalloc((void **)&h->d_single_dbg, 64, hipHostMallocCoherent);   // diagnostic
+    h->no_single = getenv("AMR_NO_SINGLE") != nullptr;             // test hook: keep the regular kernels under the one-block tests
+    if (const char *hc = getenv("AMR_HIT_CAP")) h->init_hit_cap = std::max<uint64_t>(64, strtoull(hc, nullptr, 10));
 
     {
         amr_status ps = plan_geometry(protos, n_protos, h->geom, h->sg, h->proto_pid, h->halo_bytes, h->hist_rows);
@@ -218,6 +221,13 @@ amr_status amr_destroy(amr_handle *h)
     for (void *p : ptrs) if (p) (void)hipFree(p);
     for (uint8_t *p : h->d_iqhist) if (p) (void)hipFree(p);
     if (h->h_flags) (void)hipHostFree(h->h_flags);
+    if (h->h_iq1) (void)hipHostFree(h->h_iq1);
+    if (h->d_single_dbg) {
+        const unsigned long long *t = h->d_single_dbg;
+        fprintf(stderr, "AMR_SINGLE_DBG (last call, us): stage+hist %.2f, mags %.2f, chain %.2f, filter %.2f, state+search %.2f, slots+slice %.2f, fence %.2f\n",
+                (t[1] - t[0]) * 0.01, (t[2] - t[1]) * 0.01, (t[3] - t[2]) * 0.01, (t[4] - t[3]) * 0.01, (t[5] - t[4]) * 0.01, (t[6] - t[5]) * 0.01, (t[7] - t[6]) * 0.01);
+        (void)hipHostFree(h->d_single_dbg);
+    }
     for (Slot &sl : h->slot) {
         void *dp[] = {sl.d_qt, sl.d_counts, sl.d_gcnt, sl.d_offs_pre, sl.d_overflow, sl.d_staging, sl.d_out, sl.d_iq_stage, sl.d_r900,
                       sl.d_val, sl.d_keep, sl.d_listoff, sl.d_offs_val};
@@ -381,9 +391,11 @@ amr_status amr_describe(const amr_handle *h, char *buf, size_t buf_bytes)
     if (!h || !buf || buf_bytes == 0) return fail(AMR_EINVAL, "null argument");
     hipDeviceProp_t prop;
     HIP_TRY(hipGetDeviceProperties(&prop, h->device));
-    snprintf(buf, buf_bytes, "amrdemod 0.1 %s %d CUs clock %d kHz chip %d BS %d PL %d preambles %d", prop.gcnArchName,
-             prop.multiProcessorCount, prop.clockRate, h->geom.chip_length, h->geom.block_size, h->geom.packet_length,
-             h->geom.n_preambles);
+    int n = snprintf(buf, buf_bytes, "amrdemod 0.1 %s %d CUs clock %d kHz chip %d BS %d PL %d preambles %d", prop.gcnArchName,
+                     prop.multiProcessorCount, prop.clockRate, h->geom.chip_length, h->geom.block_size, h->geom.packet_length,
+                     h->geom.n_preambles);
+    if (h->gate_timeouts && n > 0 && (size_t)n < buf_bytes)
+        snprintf(buf + n, buf_bytes - (size_t)n, " gate-timeouts %llu", (unsigned long long)h->gate_timeouts);
     return AMR_OK;
 }
 

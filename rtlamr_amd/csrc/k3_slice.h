@@ -651,21 +651,33 @@ __global__ void k_done(uint64_t *flag, uint64_t value, uint64_t *dev_flag)
 // First kernel of a tail that was enqueued AHEAD of time (submit of the following batch): holds the second stream until
 // that batch's K1 has all its waves on the chip (K1Args::started), plus `delay` ticks of the 100 MHz clock for the other
 // XCDs' dispatchers.  One lane; it sleeps between polls and needs no LDS and 8 registers, so it fits next to a full K1.
+//
+// The wait is bounded (`timeout` ticks): the K1 launch it waits for sits behind this batch's search on the compute stream,
+// and that stream may be held up for any length of time (foreign work on a caller's stream, amr_set_stream; a
+// serialising tool).  A gate that gives up must NOT let the tail through as if nothing had happened -- nothing else
+// orders K3 against this batch's K2, which may still be running: it sets bit 2 (value 4) of the batch's overflow word.
+// K3 / K4 / K5 then leave the result alone (they do for any non-zero overflow word), the word reaches the host with the
+// batch ticket, and amr_collect searches the batch again on the COMPUTE stream, in order behind its K2.
 #ifndef AMR_GATE_CLK
 #define AMR_GATE_CLK 0      // diagnostic builds: the gate measures the shader clock while it waits (cycles per 100 MHz tick)
 #endif
 #if AMR_GATE_CLK
 __device__ unsigned long long k_gate_clk[4096];
 #endif
-__global__ void k_gate(const uint64_t *flag, uint64_t value, uint32_t delay)
+constexpr uint32_t kOvfGate = 4u;      // overflow word, bit 2: the tail's gate timed out; bits 0 / 1: K2's capacities
+__global__ void k_gate(const uint64_t *flag, uint64_t value, uint32_t delay, uint64_t timeout, uint32_t *overflow)
 {
     const uint64_t t0 = __builtin_amdgcn_s_memrealtime();
 #if AMR_GATE_CLK
     const uint64_t c0 = __builtin_readcyclecounter();
 #endif
-    while (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < value &&
-           __builtin_amdgcn_s_memrealtime() - t0 < 400000000ull)        // 4 s: a device that lost the K1 launch; the host will see the fault
+    bool open = false;                   // timeout 0 (test hook AMR_GATE_TIMEOUT_US=0): give up without looking
+    while (timeout) {
+        if (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= value) { open = true; break; }
+        if (__builtin_amdgcn_s_memrealtime() - t0 >= timeout) break;
         __builtin_amdgcn_s_sleep(16);
+    }
+    if (!open) { atomicOr(overflow, kOvfGate); return; }
     const uint64_t t1 = __builtin_amdgcn_s_memrealtime();
 #if AMR_GATE_CLK
     k_gate_clk[(value & 2047) * 2] = __builtin_readcyclecounter() - c0;

@@ -27,3 +27,33 @@ for k in range(n):
 dt = (time.perf_counter() - t0) / n
 print(f"scm chip {chip}: one block ({bs} samples) per call from host memory: {dt * 1e6:.0f} us per call = "
       f"{bs / dt / 1e6:.1f} Msamples/s ({bs / 2.4e6 * 1e3:.2f} ms of signal at 2.4 Msps per block)")
+
+# the library call alone (ctypes, no numpy wrapping of the result), and the kernel's own duration
+res = _lib.AmrResult()
+h = dec._require()
+t0 = time.perf_counter()
+for k in range(n):
+    L.amr_decode_batch(h, iq.ctypes.data + k * bs2, bs2, 1, C.byref(res))
+dt_c = (time.perf_counter() - t0) / n
+dec.set_timing(1)
+ks = []
+for k in range(100):
+    dec.decode_batch(iq[k * bs2:(k + 1) * bs2])
+    ks.append(dec.timing()["demod_ms"])
+print(f"  amr_decode_batch alone (ctypes loop): {dt_c * 1e6:.1f} us per call; first kernel of the call (HIP events): "
+      f"median {np.median(ks) * 1e3:.1f} us, min {np.min(ks) * 1e3:.1f} us")
+for protos in (["idm"], ["scm", "scm+", "idm", "r900"]):
+    d2 = ra.new_decoder(0)
+    for p in protos:
+        d2.RegisterProtocol(ra.new_parser(p, chip))
+    d2.Allocate()
+    b2 = d2.Cfg.BlockSize2
+    iq2 = synth.noise(200 * d2.Cfg.BlockSize, seed=6)
+    for k in range(20):
+        d2.decode_batch(iq2[k * b2:(k + 1) * b2])
+    t0 = time.perf_counter()
+    for k in range(20, 200):
+        d2.decode_batch(iq2[k * b2:(k + 1) * b2])
+    print(f"  {'+'.join(protos)}: {(time.perf_counter() - t0) / 180 * 1e6:.0f} us per call of {d2.Cfg.BlockSize} samples")
+    d2.close()
+dec.close()
