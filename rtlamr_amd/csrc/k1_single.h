@@ -155,92 +155,110 @@ __device__ __forceinline__ float ks_sum_seq_fast(const float *mag, float *cs, ui
     return c;
 }
 
-// cs[j] = csum[j + 1] for j < n, by the whole workgroup (kSingleThreads threads); part: kSingleThreads words, ctl: 8 words
-__device__ __forceinline__ void ks_running_sum(const float *mag, float *cs, uint32_t n, uint32_t *part, uint32_t *ctl, uint32_t tid)
+// inclusive scan of transducers over the 64 lanes of a wave (DPP: the pattern of k3_wave_scan; (0, 0) is the identity)
+__device__ __forceinline__ KsPair ks_wave_scan(KsPair x)
 {
-    constexpr uint32_t NT = kSingleThreads;
+#define KS_STEP(CTRL, RMASK, BC)                                                                                       \
+    {                                                                                                                  \
+        KsPair y;                                                                                                      \
+        y.d0 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x.d0, CTRL, RMASK, 0xf, BC);                              \
+        y.d1 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x.d1, CTRL, RMASK, 0xf, BC);                              \
+        x = ks_compose(y, x);                                                                                          \
+    }
+    KS_STEP(0x111, 0xf, true) KS_STEP(0x112, 0xf, true) KS_STEP(0x114, 0xf, true) KS_STEP(0x118, 0xf, true)   // row_shr:1, 2, 4, 8
+    KS_STEP(0x142, 0xa, false)                                                                                // row_bcast:15 into rows 1 and 3
+    KS_STEP(0x143, 0xc, false)                                                                                // row_bcast:31 into rows 2 and 3
+#undef KS_STEP
+    return x;
+}
+
+// cs[j] = csum[j + 1] for j < n, by the whole workgroup (kSingleThreads threads); scratch: 64 words.
+// A phase takes a WINDOW of terms, twice as many as have been summed so far (stationary noise doubles its sum when the
+// count doubles): thread t its run of `per` consecutive terms -> the run's transducer (the terms' (a, tie) parked in the
+// very words of cs that will receive their sums) -> scan inside the wave (DPP), the 8 wave totals through LDS -> every
+// thread walks its run again from its exclusive prefix, writes the sums and reports the first term that leaves the
+// binade -> everybody reads that index, performs the one float32 addition and moves on.  Two barriers per phase.
+__device__ __forceinline__ void ks_running_sum(const float *mag, float *cs, uint32_t n, uint32_t *scratch, uint32_t tid)
+{
+    constexpr uint32_t NT = kSingleThreads, NW = NT / 64;
     const uint32_t lane = tid & 63, wv = tid >> 6;
-    KsPair *wpair = reinterpret_cast<KsPair *>(part);       // [NT] thread composites, then their exclusive prefixes
+    KsPair *wtot = reinterpret_cast<KsPair *>(scratch);     // [NW] inclusive total of every wave
+    uint32_t *first = scratch + 2 * NW;                     // [3] first term that leaves the binade, rotating by phase
+    uint32_t *seq = scratch + 2 * NW + 3;                   // [2] the sequential prologue's (position, sum)
     if (tid == 0) {
-        const uint32_t n_seq = kSumSeq;                      // n >= BlockSize + SymbolLength >= 272
-        const float c = ks_sum_seq_fast(mag, cs, n_seq / 4);
-        ctl[0] = n_seq; ctl[1] = __float_as_uint(c);
+        const float c = ks_sum_seq_fast(mag, cs, kSumSeq / 4);       // n >= BlockSize + SymbolLength >= 272
+        seq[0] = kSumSeq; seq[1] = __float_as_uint(c);
+        first[0] = 0xffffffffu; first[1] = 0xffffffffu; first[2] = 0xffffffffu;
     }
     __syncthreads();
-    for (uint32_t phase = 0;; ++phase) {
-        const uint32_t pos = ctl[0], cbits = ctl[1];
-        if (pos >= n) break;
+    uint32_t pos = seq[0], cbits = seq[1];                  // workgroup-uniform from here on
+    for (uint32_t phase = 0; pos < n; ++phase) {
         if (cbits == 0 || phase >= kSumMaxPhases) {         // a sum still zero behind 256 terms, or far too many binades: sequentially
-            if (tid == 0) { ks_sum_seq(mag, cs, pos, n, __uint_as_float(cbits)); ctl[0] = n; }
-            __syncthreads();
+            if (tid == 0) ks_sum_seq(mag, cs, pos, n, __uint_as_float(cbits));
             break;
         }
         const uint32_t E = cbits >> 23;                     // biased exponent of the sum (positive, normal: >= 2^-15)
         const float ulp = __uint_as_float((E - 23u) << 23), inv_ulp = __uint_as_float((277u - E) << 23);
         const uint32_t n0 = (cbits & 0x7fffffu) | 0x800000u;
-        const uint32_t rem = n - pos;
-        uint32_t per = (rem + NT - 1) / NT;
+        const uint32_t rem = n - pos, want = 2 * pos > NT ? 2 * pos : NT, win = want < rem ? want : rem;
+        uint32_t per = (win + NT - 1) / NT;
         per |= 1u;                                          // odd: lane-to-lane stride in LDS words without bank conflicts
-        const uint32_t i0 = pos + tid * per, i1 = i0 + per < n ? i0 + per : n;
+        const uint32_t end = pos + win;
+        const uint32_t i0 = pos + tid * per < end ? pos + tid * per : end, i1 = i0 + per < end ? i0 + per : end;
+        uint32_t *park = reinterpret_cast<uint32_t *>(cs);
         // 1. this thread's run of terms as one transducer
         KsPair f{0u, 0u};
         for (uint32_t i = i0; i < i1; ++i) {
             uint32_t a; bool tie;
             ks_term(mag[i], inv_ulp, a, tie);
+            park[i] = a | (tie ? 0x80000000u : 0u);         // a <= 2^26
             KsPair g{ks_sat(a + (tie ? (a & 1u) : 0u)), ks_sat(a + (tie ? ((a + 1u) & 1u) : 0u))};
             f = ks_compose(f, g);
         }
-        wpair[tid] = f;
+        // 2. exclusive prefix: inside the wave by DPP, the waves in front through LDS
+        const KsPair inc = ks_wave_scan(f);
+        KsPair ex;
+        ex.d0 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)inc.d0, 0x138, 0xf, 0xf, true);   // wave_shr:1, lane 0: identity
+        ex.d1 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)inc.d1, 0x138, 0xf, 0xf, true);
+        if (lane == 63) wtot[wv] = inc;
+        // the next phase's word (three rotate: the one being reset was last read two phases ago, two barriers back; with
+        // two, a wave still reading the previous phase's result would race with this reset)
+        if (tid == 0) first[(phase + 1) % 3] = 0xffffffffu;
         __syncthreads();
-        // 2. exclusive scan of the NT transducers by one wave: NT / 64 each, then across the lanes
-        if (wv == 0) {
-            KsPair v[NT / 64], acc{0u, 0u};
-#pragma unroll
-            for (uint32_t k = 0; k < NT / 64; ++k) { v[k] = wpair[lane * (NT / 64) + k]; acc = ks_compose(acc, v[k]); }
-            KsPair inc = acc;
-#pragma unroll
-            for (int d = 1; d < 64; d <<= 1) {
-                KsPair y; y.d0 = __shfl_up(inc.d0, d); y.d1 = __shfl_up(inc.d1, d);
-                if ((int)lane >= d) inc = ks_compose(y, inc);
-            }
-            KsPair run; run.d0 = __shfl_up(inc.d0, 1); run.d1 = __shfl_up(inc.d1, 1);
-            if (lane == 0) run = KsPair{0u, 0u};
-#pragma unroll
-            for (uint32_t k = 0; k < NT / 64; ++k) { wpair[lane * (NT / 64) + k] = run; run = ks_compose(run, v[k]); }
-        }
-        if (tid == 0) ctl[2] = n;                           // first term at which the sum leaves the binade
-        __syncthreads();
+        KsPair base{0u, 0u};
+        for (uint32_t w = 0; w < wv; ++w) base = ks_compose(base, wtot[w]);
+        const KsPair e = ks_compose(base, ex);
         // 3. the sums of this thread's terms, up to the first one that leaves the binade
         {
-            const KsPair e = wpair[tid];
             uint32_t nn = ks_sat(n0 + ((n0 & 1u) ? e.d1 : e.d0));
-            uint32_t ev = n;
-            if (nn >= (1u << 24)) ev = i0 < n ? i0 : n;     // left the binade in front of this thread's terms
+            uint32_t ev = 0xffffffffu;
+            if (nn >= (1u << 24)) ev = i0;                  // left the binade in front of this thread's run (a smaller index wins)
             else
                 for (uint32_t i = i0; i < i1; ++i) {
-                    uint32_t a; bool tie;
-                    ks_term(mag[i], inv_ulp, a, tie);
-                    nn = ks_step(nn, a, tie);
+                    const uint32_t t = park[i];
+                    nn = ks_step(nn, t & 0x7fffffffu, (t >> 31) != 0);
                     if (nn >= (1u << 24)) { ev = i; break; }
                     cs[i] = (float)nn * ulp;                // exact: nn < 2^24, ulp a power of two
                 }
-            if (ev < n) atomicMin(&ctl[2], ev);
+            if (ev < end) atomicMin(&first[phase % 3], ev);
         }
         __syncthreads();
-        // 4. that one addition in float32, and on to the next binade
-        if (tid == 0) {
-            const uint32_t j = ctl[2];
-            if (j < n) {
-                const float cp = j == pos ? __uint_as_float(cbits) : cs[j - 1];
-                const float c = cp + mag[j];                // decode.go:234
-                cs[j] = c;
-                ctl[0] = j + 1; ctl[1] = __float_as_uint(c);
-            } else {
-                ctl[0] = n;
-            }
+        // 4. the term that leaves the binade: that one addition in float32 (everybody, the same value); none in this window:
+        //    on with the next window in the same binade
+        const uint32_t j = first[phase % 3];
+        if (j < end) {
+            const float cp = j == pos ? __uint_as_float(cbits) : cs[j - 1];
+            const float c = cp + mag[j];                    // decode.go:234
+            if (tid == 0) cs[j] = c;
+            pos = j + 1; cbits = __float_as_uint(c);
+        } else {
+            cbits = __float_as_uint(cs[end - 1]);
+            pos = end;
         }
-        __syncthreads();
+        // (cs[j] is written by thread 0 after everybody has read cs[j - 1]; cs[j] itself is read in the next phase only
+        // behind its first barrier)
     }
+    __syncthreads();
 }
 
 __global__ __launch_bounds__(kSingleThreads) void k_single_block(const SingleArgs a)
@@ -296,7 +314,7 @@ __global__ __launch_bounds__(kSingleThreads) void k_single_block(const SingleArg
 
     KS_STAMP(2);
     // ---- B: the running sum (decode.go:232-236): the reference's sequential float32 additions, reproduced exactly ----
-    ks_running_sum(mag, cs, n_sig, part, misc + 16, tid);
+    ks_running_sum(mag, cs, n_sig, misc + 16, tid);
     __syncthreads();
     KS_STAMP(3);
 
