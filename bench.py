@@ -598,17 +598,22 @@ def main():
         alg_bytes = ALG_BYTES_PER_SAMPLE * n_samples
         achieved = alg_bytes / (k1_ms * 1e-3) / 1e9
         traffic, traffic_src = None, None
+        k1_full = dec.k1_kernel()                      # what the library launches for this chip length, as rocprofv3 prints it
+        k1_name = k1_full.replace("void amr::", "").split("<")[0] + f"<{chip}>"
         tf = os.path.join(ROOT, "profiles", "k1_hbm_traffic.json")
         if wl["name"] == "cfg2" and n_blocks == GIB // bs2 and os.path.exists(tf):
             try:
                 tj = json.load(open(tf))
                 traffic = tj.get("bytes_per_launch")
                 traffic_src = f"profiles/k1_hbm_traffic.json (static: rocprofv3 --pmc passes of this command, {tj.get('tag', 'see profiles/README.md')}); not measured in this run"
+                # the committed figure belongs to ONE kernel: a K1 that has changed since (another template configuration,
+                # another generation) must not go on quoting it
+                norm = lambda t: "".join(str(t).split())
+                if norm(tj.get("kernel")) != norm(k1_full):
+                    check["traffic"] = f"MISMATCH: profiles/k1_hbm_traffic.json was measured on {tj.get('kernel')!r}, the library launches {k1_full!r}: re-collect the PMC passes"
+                    traffic, rc = None, rc or 8
             except Exception:
                 traffic = None
-        # every chip length up to 88 runs the tile kernel (k1_tile.h; 80 / 88 with part of the csum ring in LDS), 96 the
-        # first-generation one (k1_demod.h)
-        k1_name = f"k1t_demod<{chip}>" if chip <= 88 else f"k1_demod<{chip}>"
         ms_step = dt / args.steps * 1e3
         out = {
             "metric": "IQ Msamples/s through Decoder.Decode (SCM, 72 sym/len)" if wl["name"] == "cfg2" else

@@ -6,6 +6,7 @@
 // GPU.  There is NO CPU fallback: without a gfx950 device amr_create fails
 // with AMR_ENODEV.
 #include "amr_host.h"
+#include "launch.h"
 
 namespace {
 
@@ -394,6 +395,13 @@ amr_status amr_describe(const amr_handle *h, char *buf, size_t buf_bytes)
     int n = snprintf(buf, buf_bytes, "amrdemod 0.1 %s %d CUs clock %d kHz chip %d BS %d PL %d preambles %d", prop.gcnArchName,
                      prop.multiProcessorCount, prop.clockRate, h->geom.chip_length, h->geom.block_size, h->geom.packet_length,
                      h->geom.n_preambles);
+    {   // the demodulation kernel whole wave-tiles of this chip length run (bench.py: the committed PMC figure must be this kernel's)
+        char name[160] = "";
+        amr::K1Args q{};
+        q.iq = reinterpret_cast<const uint8_t *>(name); q.n_blocks = sizeof name;
+        if (amr::launch_k1(h->geom.chip_length, dim3(0), nullptr, q, nullptr, nullptr) && n > 0 && (size_t)n < buf_bytes)
+            n += snprintf(buf + n, buf_bytes - (size_t)n, " | K1 %s |", name);
+    }
     if (h->gate_timeouts && n > 0 && (size_t)n < buf_bytes)
         snprintf(buf + n, buf_bytes - (size_t)n, " gate-timeouts %llu", (unsigned long long)h->gate_timeouts);
     return AMR_OK;

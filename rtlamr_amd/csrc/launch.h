@@ -11,6 +11,8 @@ namespace amr {
 
 // K1 for one chip length (flags.go:127-132), whole wave-tiles of 64 blocks; false: not a legal chip length
 bool launch_k1(int chip_length, dim3 grid, hipStream_t st, const K1Args &a, hipEvent_t start, hipEvent_t stop);
+// (grid.x == 0, a.qt == nullptr: no launch -- the name of the kernel this chip length gets, as rocprofv3 prints it, into the
+// host buffer a.iq points to, a.n_blocks bytes)
 // K1 for the blocks behind the last whole wave-tile (and for the single block of the unchanged main.go loop): one wave per
 // block (k1_coop.h), blocks first_block .. first_block + n_blocks - 1 of the launch
 bool launch_k1_coop(int chip_length, uint32_t first_block, uint32_t n_blocks, hipStream_t st, K1Args a, hipEvent_t start, hipEvent_t stop);

@@ -530,9 +530,14 @@ class Decoder:
         return out
 
     def describe(self) -> str:
-        buf = C.create_string_buffer(256)
-        _lib.check(_lib.lib().amr_describe(self._require(), buf, 256), "amr_describe")
+        buf = C.create_string_buffer(512)
+        _lib.check(_lib.lib().amr_describe(self._require(), buf, 512), "amr_describe")
         return buf.value.decode()
+
+    def k1_kernel(self) -> str:
+        """The demodulation kernel whole wave-tiles of this decoder's chip length run, as rocprofv3 prints it."""
+        d = self.describe()
+        return d.split(" | K1 ", 1)[1].split(" |", 1)[0] if " | K1 " in d else ""
 
 
 class PinnedBuffer:
