@@ -173,6 +173,48 @@ def cpu_baseline(wl, dec, d_iq, bs2, seconds=12.0):
                       "C restatement of protocol/decode.go (gcc -O2 -ffp-contract=off), one stream per thread"}
 
 
+def measure_traffic(spec: str, blocks: int, k1_full: str):
+    """K1's HBM bytes per launch, measured now: FETCH_SIZE and WRITE_SIZE in separate rocprofv3 --pmc passes (TCC slots) over a
+    short run of this workload with one batch in flight (with counters the profiler runs one kernel at a time), units and
+    the gfx950 correction as /opt/skills/guides/MI355X_MICROARCH.md prescribes: KiB, wide coalesced reads reported at half.
+    -> (bytes per launch, description) or (None, why not)."""
+    import collections
+    import csv
+    import glob
+    import shutil
+    import subprocess
+    import tempfile
+    rp = shutil.which("rocprofv3")
+    if not rp:
+        return None, "rocprofv3 not on this box"
+    norm = lambda t: "".join(str(t).split())
+    vals = {}
+    with tempfile.TemporaryDirectory(dir="/tmp") as tmp:
+        env = dict(os.environ, TMPDIR="/tmp")
+        for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
+            out = os.path.join(tmp, ctr)
+            cmd = [rp, "--kernel-trace", "--pmc", ctr, "-d", out, "-o", "pmc", "--output-format", "csv", "--", sys.executable,
+                   os.path.abspath(__file__), "--workload", spec, "--steps", "3", "--warmup", "1", "--depth", "1", "--k1-events", "0",
+                   "--no-cpu-baseline", "--no-verify", "--spinup-ms", "0"] + (["--blocks", str(blocks)] if blocks else [])
+            try:
+                subprocess.run(cmd, cwd="/tmp", env=env, capture_output=True, timeout=600)
+            except Exception as e:
+                return None, f"rocprofv3 --pmc {ctr} failed: {e}"
+            got = collections.defaultdict(list)
+            for f in glob.glob(os.path.join(out, "**", "*counter_collection.csv"), recursive=True):
+                for r in csv.DictReader(open(f)):
+                    if r["Counter_Name"] == ctr:
+                        got[norm(r["Kernel_Name"].split("(")[0])].append(float(r["Counter_Value"]))
+            v = got.get(norm(k1_full))
+            if not v:
+                return None, f"no {ctr} rows for {k1_full} in the rocprofv3 output"
+            vals[ctr] = (sum(v) / len(v), len(v))
+    rd, wr = vals["FETCH_SIZE"][0] * 1024 * 2, vals["WRITE_SIZE"][0] * 1024
+    return rd + wr, (f"measured in this run: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes over {vals['FETCH_SIZE'][1]} launches of "
+                     f"{k1_full} (--depth 1); KiB x 1024, FETCH_SIZE x 2 (gfx950 reports half of wide coalesced reads): "
+                     f"{rd:.0f} B read + {wr:.0f} B written per launch")
+
+
 def single_block_latency(ra, wl, local_rank, d_iq, bs, bs2, n=300, warm=50):
     """The latency case, the unchanged main.go loop (main.go:235): ONE block per Decode call, from host memory, results back
     on the host before the next call.  Not what the GPU is for -- reported so that nobody has to guess (us per call)."""
@@ -297,6 +339,10 @@ def main():
     ap.add_argument("--no-verify", action="store_true", help="skip the golden hit count / planted message check")
     ap.add_argument("--k1-events", type=int, default=4,
                     help="HIP events around the K1 dispatch of every N-th timed step (0 = none: roofline fields are NaN)")
+    ap.add_argument("--measure-traffic", action="store_true",
+                    help="N = 1: after the timed region, measure K1's HBM bytes per launch in THIS run: two rocprofv3 --pmc passes "
+                         "(FETCH_SIZE, WRITE_SIZE; kernel trace only) of a short --depth 1 run of the same workload; needs rocprofv3 "
+                         "on the box and takes about a minute.  Off: roofline.traffic is the committed figure of the same kernel")
     ap.add_argument("--validate", action="store_true",
                     help="also run the parsers' checksum tests + repeat removal on the GPU (K5); only surviving hits are read back")
     ap.add_argument("--gather", choices=["validated", "raw"], default="validated",
@@ -614,6 +660,12 @@ def main():
                     traffic, rc = None, rc or 8
             except Exception:
                 traffic = None
+        if args.measure_traffic and world == 1:
+            t_now, how = measure_traffic(args.workload, args.blocks, k1_full)
+            if t_now is not None:
+                traffic, traffic_src = t_now, how
+            else:
+                traffic_src = (traffic_src or "none") + f" ({how})"
         ms_step = dt / args.steps * 1e3
         out = {
             "metric": "IQ Msamples/s through Decoder.Decode (SCM, 72 sym/len)" if wl["name"] == "cfg2" else

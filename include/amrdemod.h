@@ -76,9 +76,14 @@ typedef struct amr_geometry {
  *   hit_block[i]  index of the Decode call that reports the hit, counted from
  *                 the last amr_reset (plus amr_set_block_base)
  *   hit_idx[i]    Data.Idx, the index into Decoder.Quantized (decode.go:371)
- *   pkt[i*pkt_bytes .. ]  Data.Bytes as built by Decoder.Slice (decode.go:363-366);
- *                 when PacketSymbols%8 != 0 the unused high bits of the last
- *                 byte are zero (Go leaves stale bits there; parsers ignore them).
+ *   pkt[i*pkt_bytes .. ]  Data.Bytes as built by Decoder.Slice (decode.go:363-366),
+ *                 every bit of it: when PacketSymbols%8 != 0 (r900 alone or with
+ *                 scm) Go never clears the high bits of the last byte, which then
+ *                 hold symbols of the hits sliced before -- reproduced here in the
+ *                 order call, preamble id, idx, across calls and batches.  (A
+ *                 shard primed with amr_prime starts that chain from zero, like a
+ *                 fresh Decoder: its first hit's stale bits are the one thing a
+ *                 block-range split cannot know.)
  */
 typedef struct amr_result {
     uint32_t n_preambles;

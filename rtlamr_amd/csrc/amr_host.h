@@ -79,6 +79,8 @@ struct Slot {
     bool tail_split = false;      // ... on the second stream
     bool tail_gated = false;      // ... enqueued ahead, behind k_gate: K3 then runs next to the following K1's end and search
     bool folded = false;          // the state update ran inside the search kernel: no stream-A ticket for this batch
+    int carry_in_slot = 0;        // k3_stale.h: the slot whose carry byte precedes this batch's first hit
+    bool force_rerun = false;     // ... and "search this batch's tail again": an older batch's re-search changed that byte
     bool single = false;          // the batch was one block through the one-launch path (k1_single.h): h_out holds its result already
     hipEvent_t ev_k2 = nullptr, ev_t = nullptr;   // K2 stop, K3 start (timing level 2 with the tail on the second stream)
     hipEvent_t ev_pack = nullptr; bool pack_pending = false;   // multi-GPU gather: its pack kernel still reads d_out / d_val of this slot
@@ -147,6 +149,8 @@ struct amr_handle {
     int dense_streak = 0;        // consecutive batches whose sparse lists overflowed; >= 4: stay dense for a while
     int dense_hold = 0;          // batches left in which the dense kernel is used straight away
     uint8_t *d_iq = nullptr;      size_t iq_cap = 0;       // staging for host input
+    uint8_t *d_pkt_carry = nullptr;   // [kSlots] k3_stale.h: final last packet byte of each slot's last hit (PacketSymbols % 8 != 0)
+    int carry_slot = 0;               // the slot of the last batch that was searched
     uint8_t *h_iq1 = nullptr;    // pinned: the block of a one-block amr_decode_batch (read by k_single_block over the link)
     bool no_single = false;      // test hook AMR_NO_SINGLE: one-block calls take the regular kernels
     unsigned long long *d_single_dbg = nullptr;   // AMR_SINGLE_DBG: 8 phase time stamps of the last k_single_block (pinned)

@@ -8,6 +8,7 @@
 #include "k3_slice.h"
 #include "k4_r900.h"
 #include "k1_single.h"
+#include "k3_stale.h"
 
 using namespace amr_host;
 
@@ -211,6 +212,15 @@ amr_status enqueue_tail(amr_handle *h, Slot &s, hipStream_t st, bool split)
     hipExtLaunchKernelGGL(amr::k3_slice_words, dim3(s.n_tiles - k3.fold, n_pre), dim3(256), k3lds, st, k3e0, k3e1, 0, k3);
     HIP_TRY(hipGetLastError());
     AMR_DBG(st, "k3_slice");
+    if (h->sg.packet_symbols & 7u) {   // the bits Decoder.Slice never clears in a last byte of fewer than 8 symbols (k3_stale.h)
+        amr::StaleArgs sa{};
+        sa.out = s.d_out; sa.offs_pre = s.d_offs_pre; sa.overflow = s.d_overflow; sa.cap = s.out_cap;
+        sa.carry_in = h->d_pkt_carry + s.carry_in_slot; sa.carry_out = h->d_pkt_carry + (&s - h->slot);
+        sa.n_pre = n_pre; sa.pkt_bytes = h->sg.pkt_bytes; sa.r = h->sg.packet_symbols & 7u;
+        hipLaunchKernelGGL(amr::k_stale_bits, dim3((unsigned)((s.out_cap + 255) / 256)), dim3(256), 0, st, sa);
+        HIP_TRY(hipGetLastError());
+        AMR_DBG(st, "k_stale_bits");
+    }
     if (h->r900_pid >= 0) {
         amr::K4Args k4{};
         k4.iq = s.d_iq; k4.hist = h->d_iqhist[s.iqhist_buf]; k4.lut = h->d_lut; k4.out_packed = s.d_out;
@@ -289,6 +299,11 @@ amr_status submit(amr_handle *h, const uint8_t *d_iq, size_t n_blocks, bool sear
     s.calls_base = h->calls_done + h->block_base;
     s.iqhist_valid = h->iqhist_valid;
     s.iqhist_buf = h->iqhist_cur;
+    s.force_rerun = false;
+    if (search) {                                      // k3_stale.h: this batch's first hits continue the previous search batch's last
+        s.carry_in_slot = h->carry_slot;
+        h->carry_slot = h->next_slot;
+    }
 
     // wave-tile 0 of a launch that starts with deferred blocks: completed in the head buffer with this batch's first blocks
     uint8_t *head_rows = h->d_head + h->halo_bytes;
@@ -430,6 +445,7 @@ bool single_block_ok(const amr_handle *h, size_t n_blocks, const void *iq)
 {
     return n_blocks == 1 && !h->no_single && h->n_pending == 0 && h->n_head == 0 && !h->validate && h->r900_pid < 0 &&
            !h->dense_search && h->dense_hold == 0 && (reinterpret_cast<uintptr_t>(iq) & 15u) == 0 &&
+           (h->sg.packet_symbols & 7u) == 0 &&        // (a last byte of fewer than 8 symbols carries bits of earlier hits: k3_stale.h)
            amr::k_single_lds_bytes(h->sg) <= 160 * 1024 - 512;
 }
 
@@ -477,6 +493,7 @@ amr_status submit_single(amr_handle *h, const uint8_t *iq)
     AMR_DBG(h->stream, "k_single_block");
     s.tail_enqueued = true; s.tail_split = false; s.tail_gated = false; s.folded = false;
     s.single = true;
+    s.force_rerun = false;
     h->zero_halo = false;
     h->calls_done += 1;
     s.pending = true;
@@ -625,6 +642,9 @@ amr_status collect(amr_handle *h, amr_result *res)
             total = s.h_off[n_pre];
             if (attempt > 8) return fail(AMR_EOVERFLOW, "hit capacity could not be grown");
             bool rerun = false;
+            // an older batch was searched again after this one's tail had run: the byte its last hit hands on (k3_stale.h) was
+            // not there yet -- this batch's tail once more, on the compute stream, behind that re-search
+            if (s.force_rerun && attempt == 0) rerun = true;
             // sparse hit list overflowed (e.g. the zero history of a fresh stream matches r900's 16 leading zeros):
             // this batch is searched again with the dense kernel; the next one starts sparse again unless
             // overflows keep coming
@@ -660,6 +680,10 @@ amr_status collect(amr_handle *h, amr_result *res)
             AMR_TRY(sync_compute(h));
             searched_again = true;
         }
+        s.force_rerun = false;
+        if (searched_again && (h->sg.packet_symbols & 7u))
+            for (Slot &o : h->slot)
+                if (&o != &s && o.pending && o.search) o.force_rerun = true;
         if (use_dense && !s.dense) {
             if (++h->dense_streak >= 4) { h->dense_hold = 32; h->dense_streak = 0; }
         } else if (!use_dense) {

@@ -185,6 +185,8 @@ amr_status amr_create(const amr_protocol *protos, int32_t n_protos, int32_t devi
         if (e == hipSuccess) e = hipHostMalloc((void **)&sl.h_off, (AMR_MAX_PREAMBLES + 1) * 8, hipHostMallocDefault);
         if (e == hipSuccess) e = hipHostMalloc((void **)&sl.h_ovf, 4, hipHostMallocDefault);
     }
+    if (e == hipSuccess) e = hipMalloc((void **)&h->d_pkt_carry, 16);
+    if (e == hipSuccess) e = hipMemset(h->d_pkt_carry, 0, 16);
     if (e == hipSuccess) e = hipMalloc((void **)&h->d_lut, 1024);
     const size_t head_bytes = h->halo_bytes + (size_t)64 * h->geom.block_size2;
     if (e == hipSuccess) e = hipMalloc((void **)&h->d_head, head_bytes);
@@ -218,7 +220,7 @@ amr_status amr_destroy(amr_handle *h)
     if (h->stream) (void)hipStreamSynchronize(h->stream);
     if (h->tail_stream) (void)hipStreamSynchronize(h->tail_stream);
     if (h->copy_stream) (void)hipStreamSynchronize(h->copy_stream);
-    void *ptrs[] = {h->d_lut, h->d_head, h->d_iq, h->d_untile, h->d_tail_done};
+    void *ptrs[] = {h->d_lut, h->d_head, h->d_iq, h->d_untile, h->d_tail_done, h->d_pkt_carry};
     for (void *p : ptrs) if (p) (void)hipFree(p);
     for (uint8_t *p : h->d_iqhist) if (p) (void)hipFree(p);
     if (h->h_flags) (void)hipHostFree(h->h_flags);
@@ -257,6 +259,8 @@ amr_status amr_reset(amr_handle *h)
     HIP_TRY(hipStreamSynchronize(h->tail_stream));
     for (Slot &sl : h->slot)
         if (sl.d_qt) HIP_TRY(hipMemsetAsync(sl.d_qt, 0, (size_t)64 * h->sg.wpb * 4, h->stream));
+    AMR_TRY(sync_compute(h));
+    HIP_TRY(hipMemsetAsync(h->d_pkt_carry, 0, 16, h->stream));      // a fresh Decoder's pkt is zero (decode.go:151)
     AMR_TRY(sync_compute(h));
     h->zero_halo = true;
     h->calls_done = 0;

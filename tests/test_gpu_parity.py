@@ -167,6 +167,7 @@ def test_sharded_decode_with_priming_equals_single_decoder(protos, chip, n_block
     want = util.gpu_run(one, iq)
     o = util.oracle_run(protos, chip, iq)
     util.assert_same(o, want, one.Cfg.PacketSymbols)
+    PS = one.Cfg.PacketSymbols
     one.close()
     world = 3
     got_h, got_p = [], []
@@ -190,7 +191,14 @@ def test_sharded_decode_with_priming_equals_single_decoder(protos, chip, n_block
     p = np.concatenate(got_p)
     order = np.lexsort((h[:, 2], h[:, 1], h[:, 0]))
     assert np.array_equal(h[order], want[1])
-    assert np.array_equal(p[order], want[2])
+    p, wp = p[order].copy(), want[2].copy()
+    ps = PS
+    if ps % 8:
+        # the one thing a block-range split cannot know: the bits Decoder.Slice never clears above the last byte's fresh
+        # symbols come from the hit sliced before -- for a shard's first hit that is another shard's last (include/amrdemod.h)
+        p[:, -1] &= (1 << (ps % 8)) - 1
+        wp[:, -1] &= (1 << (ps % 8)) - 1
+    assert np.array_equal(p, wp)
 
 
 def test_dense_search_fallback_kernel(monkeypatch):
