@@ -149,8 +149,9 @@ struct amr_handle {
     int dense_streak = 0;        // consecutive batches whose sparse lists overflowed; >= 4: stay dense for a while
     int dense_hold = 0;          // batches left in which the dense kernel is used straight away
     uint8_t *d_iq = nullptr;      size_t iq_cap = 0;       // staging for host input
-    uint8_t *d_pkt_carry = nullptr;   // [kSlots] k3_stale.h: final last packet byte of each slot's last hit (PacketSymbols % 8 != 0)
-    int carry_slot = 0;               // the slot of the last batch that was searched
+    uint8_t *d_pkt_carry = nullptr;   // [kSlots + 1] k3_stale.h: final last packet byte of each slot's last hit (PacketSymbols % 8 != 0)
+    int carry_slot = 4;               // the slot of the last batch that was searched; kSlots: none yet (a byte of its own, zero: a
+                                      // batch must never read and write the same byte -- its first and its last hit do so at once)
     uint8_t *h_iq1 = nullptr;    // pinned: the block of a one-block amr_decode_batch (read by k_single_block over the link)
     bool no_single = false;      // test hook AMR_NO_SINGLE: one-block calls take the regular kernels
     unsigned long long *d_single_dbg = nullptr;   // AMR_SINGLE_DBG: 8 phase time stamps of the last k_single_block (pinned)

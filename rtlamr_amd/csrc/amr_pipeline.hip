@@ -302,6 +302,10 @@ amr_status submit(amr_handle *h, const uint8_t *d_iq, size_t n_blocks, bool sear
     s.force_rerun = false;
     if (search) {                                      // k3_stale.h: this batch's first hits continue the previous search batch's last
         s.carry_in_slot = h->carry_slot;
+        if (s.carry_in_slot == h->next_slot) {         // (three batches without a search in between, amr_prime: the ring has come round)
+            HIP_TRY(hipMemcpyAsync(h->d_pkt_carry + kSlots, h->d_pkt_carry + h->next_slot, 1, hipMemcpyDeviceToDevice, h->stream));
+            s.carry_in_slot = kSlots;                  // never the byte this batch writes
+        }
         h->carry_slot = h->next_slot;
     }
 
@@ -727,6 +731,13 @@ amr_status collect(amr_handle *h, amr_result *res)
                 cpu_relax();
             }
         }
+    }
+    if (getenv("AMR_STALE_DBG")) {
+        uint8_t cb[16] = {};
+        (void)hipDeviceSynchronize();
+        (void)hipMemcpy(cb, h->d_pkt_carry, 16, hipMemcpyDeviceToHost);
+        fprintf(stderr, "[stale] slot %d in-slot %d blocks %zu first %llu total %llu ovf %u carry %02x %02x %02x %02x\n", si, s.carry_in_slot, s.n_blocks,
+                (unsigned long long)s.calls_base, (unsigned long long)total, *s.h_ovf, cb[0], cb[1], cb[2], cb[3]);
     }
     float a = 0, b = 0, c = 0;
     h->timing_valid = false;

@@ -262,6 +262,7 @@ amr_status amr_reset(amr_handle *h)
     AMR_TRY(sync_compute(h));
     HIP_TRY(hipMemsetAsync(h->d_pkt_carry, 0, 16, h->stream));      // a fresh Decoder's pkt is zero (decode.go:151)
     AMR_TRY(sync_compute(h));
+    h->carry_slot = 4;
     h->zero_halo = true;
     h->calls_done = 0;
     h->last_n_blocks = 0;
