@@ -81,6 +81,9 @@ struct Slot {
     bool folded = false;          // the state update ran inside the search kernel: no stream-A ticket for this batch
     int carry_in_slot = 0;        // k3_stale.h: the slot whose carry byte precedes this batch's first hit
     bool force_rerun = false;     // ... and "search this batch's tail again": an older batch's re-search changed that byte
+    bool early = false;           // the batch's search ran on the search stream, next to its K1 (early search)
+    uint32_t *d_k1flags = nullptr;   // [cnt_tiles] one "done" word per K1 wave-tile: the batch ticket when its rows are in memory
+    hipEvent_t ev_k2done = nullptr;  // early search: recorded behind K2 on the search stream (K3 on the tail stream waits for it)
     bool single = false;          // the batch was one block through the one-launch path (k1_single.h): h_out holds its result already
     hipEvent_t ev_k2 = nullptr, ev_t = nullptr;   // K2 stop, K3 start (timing level 2 with the tail on the second stream)
     hipEvent_t ev_pack = nullptr; bool pack_pending = false;   // multi-GPU gather: its pack kernel still reads d_out / d_val of this slot
@@ -121,6 +124,13 @@ struct amr_handle {
     hipStream_t own_stream = nullptr, stream = nullptr, copy_stream = nullptr, h2d_stream = nullptr;
     // K3 / K4 / K5 of batch i run here, next to the search of batch i+1, once the caller pipelines (lazy_tail)
     hipStream_t tail_stream = nullptr;
+    // early search: K2 of a batch next to its K1, tile by tile
+    hipStream_t search_stream = nullptr;
+    int early_mode = -1;              // -1: where it was measured to pay (BlockSize <= 512: K1 runs several rounds in one launch
+                                      // there, out of step anyway); AMR_EARLY_SEARCH=1: wherever it applies; 0: never
+    bool k2_on_search = false;        // the last batch's search ran on the search stream
+    hipEvent_t ev_switch = nullptr, ev_last_early = nullptr;   // hand-over between the two orders (ev_last_early: a slot's ev_k2done)
+    uint8_t *d_carry_alt = nullptr, *d_carry_cur = nullptr;    // the IQ halo of the next batch's block 0: in d_head or here
     // The host launches the tail when it sees the next batch's search start (a pinned flag; no event on the compute
     // stream: stream dependencies were tried and cost ~10 us of bubbles per batch, cfg2 0.237 ms per step against 0.227).
     bool lazy_tail = false;

@@ -74,6 +74,10 @@ amr_status ensure_capacity(amr_handle *h, Slot &s, Slot &other, size_t n_blocks)
         if (grows && h->n_pending) AMR_TRY(sync_compute(h));
     }
     AMR_TRY(ensure_qt(h, s, other, bt + 2));
+    if (st > s.cnt_tiles) {     // one "done" word per K1 wave-tile (early search), zero: below every ticket
+        AMR_TRY(dev_realloc(s.d_k1flags, st));
+        HIP_TRY(hipMemsetAsync(s.d_k1flags, 0, st * 4, h->stream));
+    }
     if (st > s.cnt_tiles) {     // per list: hits (K2), then survivors of K5's test and the list's slot (K3)
         AMR_TRY(dev_realloc(s.d_counts, 2 * st * h->sg.n_pre));
         AMR_TRY(dev_realloc(s.d_listoff, st * h->sg.n_pre));
@@ -106,7 +110,7 @@ amr_status ensure_capacity(amr_handle *h, Slot &s, Slot &other, size_t n_blocks)
 // (pipelined callers: collect() launches it when the next batch's K1 has finished, so that it runs next to that
 // batch's K2 instead of in front of its K1).  `split`: K2 gets a stop event of its own for timing level 2.
 amr_status enqueue_k2(amr_handle *h, Slot &s, hipStream_t st, bool rerun, bool dense, bool split,
-                      const amr::HistArgs *fold = nullptr, bool *folded = nullptr)
+                      const amr::HistArgs *fold = nullptr, bool *folded = nullptr, bool early = false)
 {
     if (folded) *folded = false;
     const uint32_t n_pre = h->sg.n_pre;
@@ -125,6 +129,7 @@ amr_status enqueue_k2(amr_handle *h, Slot &s, hipStream_t st, bool rerun, bool d
     const bool t2 = s.timed >= 2;
     hipEvent_t k2stop = (t2 && split) ? s.ev_k2 : nullptr;
     k2.started = rerun ? nullptr : &h->h_flags[0];
+    if (early) { k2.k1_flags = s.d_k1flags; k2.k1_flag_value = (uint32_t)s.ticket; }   // next to K1, tile by tile (submit)
     k2.started_value = s.ticket;
     // the overflow word is zeroed by the previous batch's k_hist_update; only a re-run has to do it here
     if (rerun) {
@@ -321,7 +326,7 @@ amr_status submit(amr_handle *h, const uint8_t *d_iq, size_t n_blocks, bool sear
 
     amr::K1Args k1{};
     k1.iq = d_iq - n_head * bs2;      // row r >= 64 of the launch is block r - n_head of the caller's batch
-    k1.carry = h->d_head;
+    k1.carry = n_head ? h->d_head : h->d_carry_cur;   // (deferred rows sit behind the carry in the head buffer: its writer left it current)
     k1.lut = h->d_lut;
     k1.qt = s.d_qt;
     k1.n_blocks = (uint32_t)rows;
@@ -337,8 +342,42 @@ amr_status submit(amr_handle *h, const uint8_t *d_iq, size_t n_blocks, bool sear
     if (lazy) h->lazy_tail = true;
     const bool all_coop = rows > 0 && rows <= h->k1_coop_max;   // see below
     const bool gate_prev = prev.pending && prev.search && prev.tail_split && !prev.tail_enqueued;
+    s.dense = h->dense_hold > 0;
+    if (s.dense) h->dense_hold--;
+    // EARLY SEARCH: the search of this batch on a stream of its own, next to K1 -- the wave of a tile starts
+    // as soon as the K1 waves that wrote it are done -- so that the next K1 launch follows this one directly.  For batches of
+    // whole wave-tiles through the tile kernel, one preamble with a row kernel, nothing deferred; everything else keeps the
+    // search between two K1 launches in stream order.
+    bool early = false;
+    // Measured (profiles/r05/early_search_ab.txt): at BlockSize >= 2048 the next K1 launch, no longer held back by the search,
+    // starts while the last searching waves (and the previous batch's K3) still hold wave slots; some of its waves start
+    // late, the launch loses its lock-step and K1 takes 0.25-0.27 ms instead of 0.187: 20 % slower at chip 72, 1-6 % at chip
+    // 32 .. 48.  At BlockSize 512 (chip 8) K1 is one launch of eight rounds, out of step anyway: 3-5 % faster.
+    const bool early_here = h->early_mode > 0 || (h->early_mode < 0 && bs <= 512);
+    if (lazy && early_here && !all_coop && rem == 0 && full > 0 && n_head == 0 && new_head == 0 && h->r900_pid < 0 && !s.dense &&
+        !h->dense_search && h->sg.n_pre == 1 && h->geom.chip_length != 96) {
+        const int kind = amr::k2_walk_kind_of(h->sg.pre_len[0], h->sg.pre_bits[0]);
+        amr::K2Args q{};                              // qt null: a question, not a launch
+        q.g = h->sg; q.n_tiles = s.n_tiles;
+        hipError_t qe = hipSuccess;
+        early = kind >= 0 && amr::launch_k2_row(h->sg.symbol_length, (uint32_t)kind, 0u, 0, nullptr, nullptr, nullptr, q, &qe);
+    }
+    // the two orders must not overtake each other where they change hands: the state update (history rows, reset words)
+    // rides in the search, on whichever stream that runs
+    if (early && !h->k2_on_search) {
+        HIP_TRY(hipEventRecord(h->ev_switch, st));
+        HIP_TRY(hipStreamWaitEvent(h->search_stream, h->ev_switch, 0));
+    } else if (!early && h->k2_on_search) {
+        HIP_TRY(hipStreamWaitEvent(st, h->ev_last_early, 0));
+    }
+    h->k2_on_search = early;
+    uint8_t *carry_next = h->d_head;                  // where this batch leaves the IQ halo of the next one
+    if (early) {
+        carry_next = h->d_carry_cur == h->d_head ? h->d_carry_alt : h->d_head;   // never the buffer wave-tile 0 is reading
+        k1.done_flags = s.d_k1flags; k1.done_value = (uint32_t)s.ticket; k1.carry_out = carry_next;
+    }
     amr::K1Args k1_last = k1;                     // the launch that announces itself to the gate: the batch's last one
-    if (gate_prev) { k1_last.started = h->d_k1_started; k1_last.started_value = s.ticket; }
+    if (gate_prev || early) { k1_last.started = h->d_k1_started; k1_last.started_value = s.ticket; }
     // One launch per "round" for long blocks: K1 holds 8 waves per CU, and a launch that exactly fills the chip keeps its
     // waves in step -- all of them read together and write their output bursts together.  A larger grid runs the later
     // rounds out of step (output stores trickle into the read stream all the time): BlockSize 4096, 4 GiB: 0.895 ms in
@@ -376,29 +415,41 @@ amr_status submit(amr_handle *h, const uint8_t *d_iq, size_t n_blocks, bool sear
         hipLaunchKernelGGL(amr::k_gate, dim3(1), dim3(1), 0, h->tail_stream, h->d_k1_started, s.ticket, 600u /* 6 us */,
                            h->gate_timeout_ticks, prev.d_overflow);
         HIP_TRY(hipGetLastError());
+        // (an early search ran on its own stream: nothing but this event orders K3 behind it)
+        if (prev.early) HIP_TRY(hipStreamWaitEvent(h->tail_stream, prev.ev_k2done, 0));
         AMR_TRY(launch_tail(h, prev));
         prev.tail_gated = true;
     }
-    s.dense = h->dense_hold > 0;
-    if (s.dense) h->dense_hold--;
     // state carried to the next batch (decode.go:165-166): the last rows of this slot's bitstream become the history
     // tile of the NEXT slot, the last HBA bytes of IQ (and the deferred blocks behind them) go to the head buffer, the
     // next slot's search words are reset.  Whatever does it is also the last thing in front of the next K1 launch, which
     // must not meet the previous batch's K3.. (it needs every wave slot): it waits for them on a device word.
     const uint8_t *launch_end = rows > n_head ? d_iq + (rows - n_head) * bs2 : head_rows + rows * bs2;
     amr::HistArgs ha{s.d_qt, other.d_qt, (uint32_t)rows, h->hist_rows, h->sg.wpb, h->sg.lg_wpb,
-                     launch_end - h->halo_bytes, h->d_head, h->halo_bytes,
+                     launch_end - h->halo_bytes, h->d_head, early ? 0u : h->halo_bytes,     // (early: K1's last wave-tile left the halo)
                      (uint32_t)(new_head * bs2), new_head ? 16u : 0u, other.d_overflow,
                      other.d_gcnt, other.gcnt_words,
                      lazy ? nullptr : s.h_done, s.ticket, &h->h_flags[1],
-                     (prev.pending && prev.search && prev.tail_split) ? h->d_tail_done : nullptr, prev.ticket};
+                     // (early: the next K1 launch no longer waits for this kernel, so there is nothing to hold back)
+                     (!early && prev.pending && prev.search && prev.tail_split) ? h->d_tail_done : nullptr, prev.ticket,
+                     early ? s.d_k1flags + (full - 1) : nullptr, (uint32_t)s.ticket};
     // pipelined callers: the update rides along with the search as more workgroups of its launch instead of following it
     // as a 5 us kernel
     bool folded = false;
     if (search) {
-        if (lazy) AMR_TRY(enqueue_k2(h, s, st, false, s.dense, true, &ha, &folded));
+        if (early) {
+            // behind a gate of its own: the searching waves wait for K1 waves, so they must not get on the chip before every
+            // one of those has its slot (they would be holding what K1 is waiting for)
+            hipLaunchKernelGGL(amr::k_gate, dim3(1), dim3(1), 0, h->search_stream, h->d_k1_started, s.ticket, 0u, h->gate_timeout_ticks, s.d_overflow);
+            HIP_TRY(hipGetLastError());
+            AMR_TRY(enqueue_k2(h, s, h->search_stream, false, false, true, &ha, &folded, true));
+            HIP_TRY(hipEventRecord(s.ev_k2done, h->search_stream));
+            h->ev_last_early = s.ev_k2done;
+        } else if (lazy) AMR_TRY(enqueue_k2(h, s, st, false, s.dense, true, &ha, &folded));
         else AMR_TRY(enqueue_search(h, s, false, s.dense));
     }
+    s.early = early;
+    h->d_carry_cur = carry_next;
     s.single = false;
     s.tail_enqueued = !lazy;
     s.tail_split = lazy;
@@ -480,7 +531,9 @@ amr_status submit_single(amr_handle *h, const uint8_t *iq)
     s.timed = h->timing_level;
     s.dense = false;
     amr::SingleArgs a{};
-    a.iq = iq; a.carry = h->d_head; a.carry_out = h->d_head; a.lut = h->d_lut;
+    a.iq = iq; a.carry = h->d_carry_cur; a.carry_out = h->d_head; a.lut = h->d_lut;
+    h->d_carry_cur = h->d_head;
+    s.early = false;
     a.qt = s.d_qt; a.qt_next = other.d_qt; a.ovf_next = other.d_overflow;
     a.gcnt_next = other.d_gcnt; a.gcnt_words = other.gcnt_words;
     a.out = s.d_out; a.h_out = s.h_out; a.cap = s.out_cap;
@@ -565,8 +618,9 @@ amr_status search_finished(amr_handle *h, int k, bool wait, bool *yes)
         *yes = __atomic_load_n(flag, __ATOMIC_ACQUIRE) >= value;
         return AMR_OK;
     }
-    if (wait) { HIP_TRY(hipStreamSynchronize(h->stream)); *yes = true; return AMR_OK; }
-    const hipError_t e = hipStreamQuery(h->stream);
+    hipStream_t sst = t.early ? h->search_stream : h->stream;       // where the batch's search ran
+    if (wait) { HIP_TRY(hipStreamSynchronize(sst)); *yes = true; return AMR_OK; }
+    const hipError_t e = hipStreamQuery(sst);
     if (e != hipSuccess && e != hipErrorNotReady) return fail(AMR_EHIP, "hipStreamQuery", e);
     *yes = e == hipSuccess;
     return AMR_OK;
@@ -612,6 +666,7 @@ amr_status amr_host::sync_compute(amr_handle *h)
         AMR_TRY(launch_tail(h, t));
     }
     HIP_TRY(hipStreamSynchronize(h->stream));
+    HIP_TRY(hipStreamSynchronize(h->search_stream));
     HIP_TRY(hipStreamSynchronize(h->tail_stream));
     return AMR_OK;
 }
@@ -745,7 +800,11 @@ amr_status collect(amr_handle *h, amr_result *res)
         h->timing = amr_timing{a, 0.f, a};     // one launch: demodulation, search and slice are not separable
         h->timing_valid = true;
     } else if (s.timed && hipEventSynchronize(s.ev1) == hipSuccess && hipEventElapsedTime(&a, s.ev0, s.ev1) == hipSuccess) {
-        if (s.timed >= 2 && s.search && s.tail_split && hipEventSynchronize(s.ev_k2) == hipSuccess &&
+        if (s.timed >= 2 && s.search && s.early && hipEventSynchronize(s.ev_k2) == hipSuccess && hipEventElapsedTime(&b, s.ev1, s.ev_k2) == hipSuccess) {
+            // early search: K2 ran next to K1 from its first retiring wave on; what it cost is what stuck out behind K1's end
+            b = b > 0.f ? b : 0.f;
+            h->timing = amr_timing{a, b, a + b};
+        } else if (s.timed >= 2 && s.search && s.tail_split && hipEventSynchronize(s.ev_k2) == hipSuccess &&
             hipEventElapsedTime(&b, s.ev_s, s.ev_k2) == hipSuccess)
             // K2 and the tail ran apart (pipelined callers): what the batch cost the compute stream besides K1 is its K2.
             // The tail (K3, K4, K5) runs on the second stream next to the following batch's kernels -- let in behind a gate
@@ -972,6 +1031,7 @@ amr_status amr_prime(amr_handle *h, const uint8_t *lead, const uint8_t *halo_iq,
         HIP_TRY(hipMemcpyAsync(h->d_head, lead, h->halo_bytes,
                                on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, h->stream));
         h->zero_halo = false;
+        h->d_carry_cur = h->d_head;
     }
     AMR_TRY(drain(h));
     const uint8_t *src = halo_iq;

@@ -160,6 +160,9 @@ amr_status amr_create(const amr_protocol *protos, int32_t n_protos, int32_t devi
     if (e == hipSuccess) e = hipStreamCreateWithFlags(&h->copy_stream, hipStreamNonBlocking);
     if (e == hipSuccess) e = hipStreamCreateWithFlags(&h->h2d_stream, hipStreamNonBlocking);
     if (e == hipSuccess) e = hipStreamCreateWithFlags(&h->tail_stream, hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipStreamCreateWithFlags(&h->search_stream, hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&h->ev_switch, hipEventDisableTiming);
+    if (const char *es = getenv("AMR_EARLY_SEARCH")) h->early_mode = atoi(es) != 0 ? 1 : 0;
     if (e == hipSuccess) e = hipHostMalloc((void **)&h->h_flags, 16, hipHostMallocCoherent);
     if (e == hipSuccess) { h->h_flags[0] = 0; h->h_flags[1] = 0; }
     if (e == hipSuccess) e = hipMalloc((void **)&h->d_tail_done, 16);
@@ -174,6 +177,7 @@ amr_status amr_create(const amr_protocol *protos, int32_t n_protos, int32_t devi
         if (e == hipSuccess) e = hipEventCreate(&sl.ev_k2);
         if (e == hipSuccess) e = hipEventCreate(&sl.ev_t);
         if (e == hipSuccess) e = hipEventCreateWithFlags(&sl.ev_pack, hipEventDisableTiming);
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&sl.ev_k2done, hipEventDisableTiming);
         if (e == hipSuccess) e = hipEventCreateWithFlags(&sl.ev_h2d, hipEventDisableTiming);
         if (e == hipSuccess) e = hipHostMalloc((void **)&sl.h_done, 8, hipHostMallocCoherent);
         if (e == hipSuccess) *sl.h_done = 0;
@@ -185,6 +189,8 @@ amr_status amr_create(const amr_protocol *protos, int32_t n_protos, int32_t devi
         if (e == hipSuccess) e = hipHostMalloc((void **)&sl.h_off, (AMR_MAX_PREAMBLES + 1) * 8, hipHostMallocDefault);
         if (e == hipSuccess) e = hipHostMalloc((void **)&sl.h_ovf, 4, hipHostMallocDefault);
     }
+    if (e == hipSuccess) e = hipMalloc((void **)&h->d_carry_alt, h->halo_bytes);
+    if (e == hipSuccess) e = hipMemset(h->d_carry_alt, 0, h->halo_bytes);
     if (e == hipSuccess) e = hipMalloc((void **)&h->d_pkt_carry, 16);
     if (e == hipSuccess) e = hipMemset(h->d_pkt_carry, 0, 16);
     if (e == hipSuccess) e = hipMalloc((void **)&h->d_lut, 1024);
@@ -192,6 +198,7 @@ amr_status amr_create(const amr_protocol *protos, int32_t n_protos, int32_t devi
     if (e == hipSuccess) e = hipMalloc((void **)&h->d_head, head_bytes);
     if (e == hipSuccess) e = hipMemcpy(h->d_lut, h->lut, 1024, hipMemcpyHostToDevice);
     if (e == hipSuccess) e = hipMemset(h->d_head, 0, head_bytes);
+    h->d_carry_cur = h->d_head;
     if (e == hipSuccess) e = hipDeviceSynchronize();   // the memsets above ran on the null stream; ours is non-blocking
     if (e != hipSuccess) { amr_destroy(h); return fail(AMR_EHIP, "amr_create: device setup", e); }
     *out = h;
@@ -218,9 +225,10 @@ amr_status amr_destroy(amr_handle *h)
     // the communicator first: its stream may still hold a pack kernel that reads the slots' result buffers
     if (h->comm) (void)amr_comm_destroy(h);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
+    if (h->search_stream) (void)hipStreamSynchronize(h->search_stream);
     if (h->tail_stream) (void)hipStreamSynchronize(h->tail_stream);
     if (h->copy_stream) (void)hipStreamSynchronize(h->copy_stream);
-    void *ptrs[] = {h->d_lut, h->d_head, h->d_iq, h->d_untile, h->d_tail_done, h->d_pkt_carry};
+    void *ptrs[] = {h->d_lut, h->d_head, h->d_iq, h->d_untile, h->d_tail_done, h->d_pkt_carry, h->d_carry_alt};
     for (void *p : ptrs) if (p) (void)hipFree(p);
     for (uint8_t *p : h->d_iqhist) if (p) (void)hipFree(p);
     if (h->h_flags) (void)hipHostFree(h->h_flags);
@@ -232,6 +240,8 @@ amr_status amr_destroy(amr_handle *h)
         (void)hipHostFree(h->d_single_dbg);
     }
     for (Slot &sl : h->slot) {
+        if (sl.ev_k2done) (void)hipEventDestroy(sl.ev_k2done);
+        if (sl.d_k1flags) (void)hipFree(sl.d_k1flags);
         void *dp[] = {sl.d_qt, sl.d_counts, sl.d_gcnt, sl.d_offs_pre, sl.d_overflow, sl.d_staging, sl.d_out, sl.d_iq_stage, sl.d_r900,
                       sl.d_val, sl.d_keep, sl.d_listoff, sl.d_offs_val};
         if (sl.h_r900) (void)hipHostFree(sl.h_r900);
@@ -247,6 +257,8 @@ amr_status amr_destroy(amr_handle *h)
     if (h->copy_stream) (void)hipStreamDestroy(h->copy_stream);
     if (h->h2d_stream) (void)hipStreamDestroy(h->h2d_stream);
     if (h->tail_stream) (void)hipStreamDestroy(h->tail_stream);
+    if (h->search_stream) (void)hipStreamDestroy(h->search_stream);
+    if (h->ev_switch) (void)hipEventDestroy(h->ev_switch);
     delete h;
     return AMR_OK;
 }
@@ -263,6 +275,7 @@ amr_status amr_reset(amr_handle *h)
     HIP_TRY(hipMemsetAsync(h->d_pkt_carry, 0, 16, h->stream));      // a fresh Decoder's pkt is zero (decode.go:151)
     AMR_TRY(sync_compute(h));
     h->carry_slot = 4;
+    h->d_carry_cur = h->d_head;
     h->zero_halo = true;
     h->calls_done = 0;
     h->last_n_blocks = 0;

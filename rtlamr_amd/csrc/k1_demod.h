@@ -99,6 +99,14 @@ struct K1Args {
     // end of this launch instead of standing in front of it.  null: no announcement.
     uint64_t *started;
     uint64_t started_value;
+    // Early search (amr_pipeline.hip): the search of this batch runs on a stream of its own NEXT to this launch
+    // and takes a tile as soon as the waves that wrote it are done.  Every wave, at its end, waits for its stores (sc1:
+    // written through, nothing stays dirty in the XCD's L2) and then stores done_value into done_flags[wave-tile]; the wave of
+    // the batch's last wave-tile also leaves the IQ halo of the next batch's block 0 in carry_out (decode.go:165), which the
+    // state update inside the search can no longer do in front of the next K1 launch.  null: none of this (k1t_demod only).
+    uint32_t *done_flags;
+    uint8_t *carry_out;
+    uint32_t done_value;
 };
 
 __device__ __forceinline__ void k1_announce(const K1Args &a, uint32_t lane)

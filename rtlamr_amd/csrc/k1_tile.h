@@ -543,6 +543,20 @@ __global__ __launch_bounds__(64, 2) void k1t_demod(const K1Args a)
     if (C::DIAG == 3) U.nch = 0;
     if (U.nch) k1t_flush<CL, C>(L, U, qrow);
     if (C::DIAG == 3 || C::DIAG == 2) qrow[lane * 4] = L.xs ^ L.acc;
+    if (a.done_flags) {
+        // early search: the rows of this wave-tile are in memory once every store of the wave has been acknowledged (they are
+        // write-through, sc1) -- then, and only then, the flag (sc1 as well; the searching wave polls it with sc1 loads)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (lane == 0) {
+            uint32_t *p = a.done_flags + wg;
+            const uint32_t v = a.done_value;
+            asm volatile("global_store_dword %0, %1, off sc1" :: "v"(p), "v"(v) : "memory");
+        }
+        if (a.carry_out && (wg + 1) * kRows == a.n_blocks && lane < (uint32_t)G::HBA / 16) {   // the batch's last wave-tile
+            const uint4 *src = reinterpret_cast<const uint4 *>(a.iq + (size_t)a.n_blocks * bs2 - G::HBA);   // (no head rows in this mode)
+            reinterpret_cast<uint4 *>(a.carry_out)[lane] = src[lane];
+        }
+    }
 #if AMR_K1T_CLK
     if (blockIdx.x == 0 && lane == 0) {
         const uint64_t c = __builtin_readcyclecounter() - clk0, r = __builtin_amdgcn_s_memrealtime() - rt0;

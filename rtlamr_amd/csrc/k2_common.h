@@ -88,6 +88,10 @@ struct HistArgs {
     // (k_done of that batch) -- for at most ~2 ms, in case the host never launches them.
     const uint64_t *wait_flag;
     uint64_t wait_value;
+    // early search (K2Args::k1_flags): the batch's last rows may still be on their way when this workgroup starts -- it waits
+    // for the flag of the wave-tile that holds them and reads them past its caches (sc1)
+    const uint32_t *k1_flag;     // &done_flags[last wave-tile], or null
+    uint32_t k1_flag_value;
 };
 
 __device__ __forceinline__ size_t qt_index_fwd(uint64_t R, uint32_t w, uint32_t lg_wpb)   // = qt_index, defined below
@@ -96,9 +100,28 @@ __device__ __forceinline__ size_t qt_index_fwd(uint64_t R, uint32_t w, uint32_t 
 }
 
 // the work, by a workgroup of `nt` threads with hr * wpb words of LDS at tmp
+// Spin (one lane sleeps and polls with agent-scope loads, i.e. past L1) until *flag >= value; bounded: `ticks` of the
+// 100 MHz clock.  false: gave up.
+__device__ __forceinline__ bool k1_flag_wait(const uint32_t *flag, uint32_t value, uint64_t ticks)
+{
+    const uint64_t t0 = __builtin_amdgcn_s_memrealtime();
+    while ((int32_t)(__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - value) < 0) {
+        if (__builtin_amdgcn_s_memrealtime() - t0 > ticks) return false;
+        __builtin_amdgcn_s_sleep(8);
+    }
+    return true;
+}
+constexpr uint64_t kK1FlagTicks = 50000000ull;      // 0.5 s: a K1 launch takes 0.2 ms; beyond this something is broken
+constexpr uint32_t kOvfGate = 4u;                   // overflow word, bit 2: a device-side wait gave up -- the host searches the
+                                                    // batch again on the compute stream, in order (bits 0 / 1: K2's capacities)
+
 __device__ __forceinline__ void hist_body(const HistArgs &a, uint32_t *tmp, uint32_t nt)
 {
     const uint32_t tid = threadIdx.x;
+    if (a.k1_flag) {     // early search: the rows below are ready when the wave-tile that holds them has said so
+        if (tid == 0) (void)k1_flag_wait(a.k1_flag, a.k1_flag_value, kK1FlagTicks);   // (giving up is reported by the searching
+        __syncthreads();                                                              // waves, which wait for the same launch)
+    }
     for (uint32_t i = tid; i < a.carry_bytes / 16; i += nt)
         reinterpret_cast<uint4 *>(a.carry_dst)[i] = reinterpret_cast<const uint4 *>(a.carry_src)[i];
     if (tid == nt - 1) *a.ovf_next = 0;
@@ -108,7 +131,8 @@ __device__ __forceinline__ void hist_body(const HistArgs &a, uint32_t *tmp, uint
         const uint32_t j = i >> a.lg_wpb, w = i & (a.wpb - 1);
         // new history row j = stream row (n_blocks - hr + j) of the batch; negative -> old history
         const int64_t srow = (int64_t)64 + a.n_blocks - a.hr + j;  // tiled row index (tile 0 rows 0..63 = old history)
-        tmp[i] = a.qt[qt_index_fwd((uint64_t)srow, w, a.lg_wpb)];
+        const uint32_t *src = a.qt + qt_index_fwd((uint64_t)srow, w, a.lg_wpb);
+        tmp[i] = a.k1_flag ? __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : *src;
     }
     __syncthreads();
     for (uint32_t i = tid; i < n; i += nt) {
@@ -160,6 +184,12 @@ struct K2Args {
     // no completion ticket (the search is still running
     // when it is done; a ticket from inside the kernel would also need every workgroup to release its writes, an L2
     // write-back each): the host takes "the next search has started" or "the stream is idle" as the signal instead.
+    // Early search: this launch runs on a stream of its own NEXT to the batch's K1 (behind a gate: every K1 wave is on
+    // the chip by then); the wave of tile T waits for done_flags[T - 1] (its rows) and done_flags[T] (the head of the tile
+    // behind it) of K1Args before it loads anything, and loads past its caches (sc1).  null: the launch follows K1 in
+    // stream order, as always.
+    const uint32_t *k1_flags;
+    uint32_t k1_flag_value;
     uint32_t do_hist;
     uint32_t walk_pids;        // k2_walk.h: the preamble id of each of rtlamr's four preambles (scm, scm+, idm, r900), 8 bits each
     HistArgs hist;

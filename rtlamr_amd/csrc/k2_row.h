@@ -192,7 +192,9 @@ __device__ __forceinline__ void k2r_fill(K2WRing<CPRN> &R, const uint8_t *tile, 
 {
     if constexpr (K < CPRN) {
         const uint8_t *base = tile + (size_t)(K / 4) * 4096;          // wave-uniform: an SGPR pair
-        asm volatile("global_load_dwordx4 %0, %1, %2 offset:%3" : "=v"(R.c[K]) : "v"(voff), "s"(base), "n"((K % 4) * 1024) : "memory");
+        // sc1: past L1 -- the rows may have been written by a K1 wave on another compute unit microseconds ago (early search);
+        // every word is read once, there is nothing L1 could give back
+        asm volatile("global_load_dwordx4 %0, %1, %2 offset:%3 sc1" : "=v"(R.c[K]) : "v"(voff), "s"(base), "n"((K % 4) * 1024) : "memory");
         k2r_fill<CPRN, K + 1>(R, tile, voff);
     }
 }
@@ -280,6 +282,17 @@ __global__ __launch_bounds__(64 * kK2WWaves, AMR_K2R_WPE) void k2_search_row(con
     if (a.dbg && lane == 0 && h2 == 0) a.dbg[(size_t)T * 16 + 8] = __builtin_amdgcn_s_memrealtime();
 #endif
     K2W_STAMP(0);
+    if (a.k1_flags) {
+        // early search: tile T was written by K1's wave-tile T - 1, the row behind lane 63 (X) by wave-tile T; lanes 0 and 1
+        // wait for one each.  A wait that gives up marks the batch: the host searches it again, in stream order.
+        const uint32_t n_wt = a.n_tiles - 1;                          // K1's wave-tiles
+        bool ok = true;
+        if (lane < 2) {
+            const int64_t wt = (int64_t)T - 1 + lane;
+            if (wt >= 0 && wt < (int64_t)n_wt) ok = k1_flag_wait(a.k1_flags + wt, a.k1_flag_value, kK1FlagTicks);
+        }
+        if (__any(!ok) && lane == 0) atomicOr(a.overflow, kOvfGate);
+    }
 
     // ---- the lane's words, all of them, and the head of what follows lane 63 (lane c: its chunk c) ----
     const uint8_t *tile = reinterpret_cast<const uint8_t *>(tw);
@@ -290,7 +303,7 @@ __global__ __launch_bounds__(64 * kK2WWaves, AMR_K2R_WPE) void k2_search_row(con
         // behind the wave's last one: row RPW (h2 + 1) of this tile, or row 0 of the next tile
         const uint32_t xoff = (lane < (uint32_t)G::NLA ? lane : (uint32_t)G::NLA - 1) * 1024;
         const uint8_t *next = (h2 + 1 < (uint32_t)LPR) ? tile + (size_t)RPW * (h2 + 1) * 16 : tile + (size_t)tile_words * 4;
-        asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(X) : "v"(xoff), "s"(next) : "memory");
+        asm volatile("global_load_dwordx4 %0, %1, %2 sc1" : "=v"(X) : "v"(xoff), "s"(next) : "memory");
     }
     k2r_fill<G::CPR, 0>(R, tile, (uint32_t)G::CPR * hl * 1024u + rt * 16u);
 
@@ -331,8 +344,9 @@ __global__ __launch_bounds__(64 * kK2WWaves, AMR_K2R_WPE) void k2_search_row(con
                     const uint32_t o = pk * SL;
                     const uint32_t x = w + (o >> 5);
                     // word x of the stream that starts with row l of this tile: tiled row l + x / rw (may be row 0 of the next tile)
-                    const uint32_t A = tw[qt_index(l + (x >> lg_rw), x & (rw - 1), lg_rw)];
-                    const uint32_t B = tw[qt_index(l + ((x + 1) >> lg_rw), (x + 1) & (rw - 1), lg_rw)];
+                    // (agent-scope loads = sc1: see k2r_fill)
+                    const uint32_t A = __hip_atomic_load(&tw[qt_index(l + (x >> lg_rw), x & (rw - 1), lg_rw)], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    const uint32_t B = __hip_atomic_load(&tw[qt_index(l + ((x + 1) >> lg_rw), (x + 1) & (rw - 1), lg_rw)], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     Wd[k] = (o & 31) ? __builtin_amdgcn_alignbit(A, B, 16) : A;
                 }
 #pragma unroll

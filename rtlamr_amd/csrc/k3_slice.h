@@ -664,7 +664,6 @@ __global__ void k_done(uint64_t *flag, uint64_t value, uint64_t *dev_flag)
 #if AMR_GATE_CLK
 __device__ unsigned long long k_gate_clk[4096];
 #endif
-constexpr uint32_t kOvfGate = 4u;      // overflow word, bit 2: the tail's gate timed out; bits 0 / 1: K2's capacities
 __global__ void k_gate(const uint64_t *flag, uint64_t value, uint32_t delay, uint64_t timeout, uint32_t *overflow)
 {
     const uint64_t t0 = __builtin_amdgcn_s_memrealtime();

@@ -25,6 +25,13 @@ def _k1_policy(request, monkeypatch):
         monkeypatch.setenv("AMR_K1_COOP_MAX", "0")
     else:
         monkeypatch.delenv("AMR_K1_COOP_MAX", raising=False)
+    # ... and every third seed forces the early search (K2 next to K1, tile by tile, on its own stream) wherever it applies
+    # -- whole wave-tiles through the tile kernel, one preamble with a row kernel, batches in flight --, which by default
+    # runs at BlockSize <= 512 only (AMR_EARLY_SEARCH, read at amr_create)
+    if seed % 3 == 0:
+        monkeypatch.setenv("AMR_EARLY_SEARCH", "1")
+    else:
+        monkeypatch.delenv("AMR_EARLY_SEARCH", raising=False)
 
 
 def _random_split(rng, n):

@@ -78,3 +78,19 @@ def test_pipelined_decoder_under_a_serialising_runtime(protos, chip, per, n, env
     assert {k: got[k] for k in want} == want
     assert got["seconds"] < 2.0, f"the pipelined part took {got['seconds']:.2f} s: a device-side wait ran into its time-out"
     assert "gate-timeouts" not in got["describe"]
+
+
+@pytest.mark.parametrize("chip", [72, 8, 32])
+def test_early_search_next_to_k1_equals_oracle(chip):
+    """The search of a batch on its own stream next to the batch's K1, every tile as soon as the K1 waves that wrote it have
+    said so (per-wave-tile flags, write-through stores, loads past L1), the next K1 launch no longer behind it: forced with
+    AMR_EARLY_SEARCH=1 (by default only BlockSize <= 512 runs this way, where it was measured to pay); also with a gate that
+    gives up at once, which must end in a re-search, not in other hits."""
+    protos, per, n = ["scm"], 256, 7
+    want = oracle_digest(protos, chip, per, n)
+    assert want["n_hits"] > 0
+    for env in ({"AMR_EARLY_SEARCH": "1"}, {"AMR_EARLY_SEARCH": "0"}, {"AMR_EARLY_SEARCH": "1", "AMR_GATE_TIMEOUT_US": "0"}):
+        got = probe(protos, chip, per, n, env=dict(env, AMR_K1_COOP_MAX="0"))
+        assert {k: got[k] for k in want} == want, f"{env}: other hits than the oracle's"
+        assert ("gate-timeouts" in got["describe"]) == ("AMR_GATE_TIMEOUT_US" in env)
+        assert got["seconds"] < 2.0
