@@ -787,13 +787,6 @@ amr_status collect(amr_handle *h, amr_result *res)
             }
         }
     }
-    if (getenv("AMR_STALE_DBG")) {
-        uint8_t cb[16] = {};
-        (void)hipDeviceSynchronize();
-        (void)hipMemcpy(cb, h->d_pkt_carry, 16, hipMemcpyDeviceToHost);
-        fprintf(stderr, "[stale] slot %d in-slot %d blocks %zu first %llu total %llu ovf %u carry %02x %02x %02x %02x\n", si, s.carry_in_slot, s.n_blocks,
-                (unsigned long long)s.calls_base, (unsigned long long)total, *s.h_ovf, cb[0], cb[1], cb[2], cb[3]);
-    }
     float a = 0, b = 0, c = 0;
     h->timing_valid = false;
     if (s.timed && s.single && hipEventSynchronize(s.ev1) == hipSuccess && hipEventElapsedTime(&a, s.ev0, s.ev1) == hipSuccess) {
