@@ -19,7 +19,7 @@
 // Output, halo and carry conventions are K1Args' (the "tiled4" bitstream, the head buffer, zero history of a fresh Decoder).
 #pragma once
 #include "exact_sum.h"
-#include "k1_demod.h"
+#include "k1_common.h"
 
 namespace amr {
 

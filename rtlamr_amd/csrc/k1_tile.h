@@ -15,7 +15,7 @@
 //      wave made it finish 9 % earlier and leave the other one alone for the rest of the launch.
 // Output layout, arguments and the halo/carry conventions are those of k1_demod.h (K1Args, "tiled4" bitstream).
 #pragma once
-#include "k1_demod.h"
+#include "k1_common.h"
 
 // Developer diagnostics (K1TCfg::DIAG, 0 in the product): 1 = no HBM traffic after the prologue (arithmetic side
 // alone), 2 = staging + drains only (memory side alone), 3 = no output stores, 5 = no LUT gathers (one cheap ALU op per

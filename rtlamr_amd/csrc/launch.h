@@ -4,7 +4,7 @@
 #include <hip/hip_runtime.h>
 #include <hip/hip_ext.h>
 
-#include "k1_demod.h"
+#include "k1_common.h"
 #include "k2_common.h"
 
 namespace amr {
