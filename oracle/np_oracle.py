@@ -80,3 +80,21 @@ def slice_packets(qq: np.ndarray, hits: np.ndarray, g: dict, packet_symbols: int
         for p, b in enumerate(bits):
             out[h, p >> 3] = ((int(out[h, p >> 3]) << 1) | int(b)) & 0xFF
     return out
+
+
+def stale_last_bytes(pkts: np.ndarray, rows: np.ndarray, packet_symbols: int) -> np.ndarray:
+    """The bits Decoder.Slice never clears (decode.go:353-375): `pkt` is shifted per symbol and lives as long as the Decoder,
+    so with r = PacketSymbols % 8 != 0 the last byte of hit j is  B(j) = (B(j-1) << r | fresh(j)) & 0xff  over the hits in
+    the order they are sliced -- call, preamble id (registration order: the literal C restatement's order), idx.
+    pkts: the packets with CLEAN last bytes (slice_packets), rows: int64[n,3] (preamble id, call, idx) in any order.
+    -> a copy of pkts with the last bytes as the Decoder leaves them."""
+    r = packet_symbols % 8
+    out = pkts.copy()
+    if r == 0 or not len(pkts):
+        return out
+    order = np.lexsort((rows[:, 2], rows[:, 0], rows[:, 1]))       # call, then preamble id, then idx
+    b = 0
+    for j in order:
+        b = ((b << r) | int(pkts[j, -1])) & 0xFF
+        out[j, -1] = b
+    return out

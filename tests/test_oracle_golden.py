@@ -190,6 +190,33 @@ def test_c_and_numpy_restatements_agree_on_random_configurations(seed):
         assert np.array_equal(npo.slice_packets(qq, hits, gg, pkt_sym)[:, :nfull], p[:, :nfull])
 
 
+@pytest.mark.parametrize("protos,chip", [(["scm", "r900"], 72), (["r900", "scm"], 8), (["scm", "r900"], 32)])
+def test_stale_bits_of_the_last_packet_byte_agree_between_the_restatements(protos, chip):
+    """PacketSymbols % 8 != 0 (116: r900 with or without scm): the literal C restatement never clears d.pkt, like
+    decode.go:353-375; the numpy restatement slices clean packets and applies the recurrence B(j) = (B(j-1) << r | fresh(j))
+    over the hits in slicing order (call, preamble id, idx).  Every byte of every packet must agree -- this is what the GPU's
+    k_stale_bits is held to (tests/util.py compares every byte)."""
+    d = OracleDecoder(protos, chip)
+    g = d.geom
+    assert g.packet_symbols % 8 == 4
+    n_blocks = max(60, (4 * g.packet_length) // g.block_size + 8)
+    iq, _ = util.synth_stream(["scm"], chip, n_blocks, g.block_size, seed=3 + chip, n_packets=3, edge_every=2)
+    _, q, h, p = util.oracle_run(protos, chip, iq)                 # h rows: (preamble id, call, idx)
+    assert len(h) > 15
+    qn = npo.quantize_stream(iq, chip, g.block_size)
+    gg = npo.geometry(chip, g.preamble_symbols, g.packet_symbols)
+    rows, clean = [], []
+    for pid, name in enumerate(protos):
+        hits, qq = npo.search_stream(qn, PROTOCOLS[name][0], gg)
+        rows.append(np.concatenate([np.full((len(hits), 1), pid, np.int64), hits], axis=1))
+        clean.append(npo.slice_packets(qq, hits, gg, g.packet_symbols))
+    rows, clean = np.concatenate(rows), np.concatenate(clean)
+    assert np.array_equal(rows, h)
+    assert np.array_equal(clean[:, :-1], p[:, :-1]) and np.array_equal(clean[:, -1] & 15, p[:, -1] & 15)
+    assert not np.array_equal(clean, p), "no stale bit anywhere: the test tests nothing"
+    assert np.array_equal(npo.stale_last_bytes(clean, rows, g.packet_symbols), p)
+
+
 # ---- full-size machinery: the C generator, the threaded sharded decode, the bench goldens ---------------------------
 
 def test_c_generator_equals_numpy_generator():
