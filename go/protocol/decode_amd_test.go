@@ -18,6 +18,8 @@ import (
 	"os"
 	"path/filepath"
 	"sort"
+	"strconv"
+	"strings"
 	"sync"
 	"testing"
 
@@ -55,9 +57,10 @@ type run struct {
 	hits []hit
 }
 
-func decodeAmd(t *testing.T, protos []string, chip int, iq []byte, blocksPerCall int) run {
+func decodeAmd(t *testing.T, protos []string, chip int, iq []byte, blocksPerCall int, devices ...int) run {
 	d := protocol.NewDecoder()
-	d.KeepQuantized = true
+	d.KeepQuantized = len(devices) < 2 // (a diagnostic of one device: see Decoder.Devices)
+	d.Devices = devices
 	var mu sync.Mutex
 	var recs []*[][]protocol.Data // per distinct preamble, in order of first registration
 	seen := map[string]bool{}
@@ -185,6 +188,33 @@ func TestAmdMatchesReferenceGoldens(t *testing.T) {
 		b := decodeAmd(t, c.Protocols, c.Chip, iq, 37)
 		if len(b.hits) != c.NHits || b.hitsSha() != c.HitsSha || b.pktSha(b.cfg.PacketSymbols/8) != c.PktSha {
 			t.Errorf("%s: batched decode differs from the reference", c.Name)
+		}
+	}
+}
+
+// TestDevicesMatchOneDevice: Decoder.Devices (one process, several GPUs: amr_comm_init_all, every Decode call's blocks cut
+// into one primed range per device) against the same stream on one device -- every hit, every packet byte.  Needs
+// AMR_TEST_DEVICES=0,1,... (at least two gfx950 ordinals); skipped otherwise.
+func TestDevicesMatchOneDevice(t *testing.T) {
+	var devs []int
+	for _, f := range strings.Split(os.Getenv("AMR_TEST_DEVICES"), ",") {
+		if v, err := strconv.Atoi(strings.TrimSpace(f)); err == nil {
+			devs = append(devs, v)
+		}
+	}
+	if len(devs) < 2 {
+		t.Skip("AMR_TEST_DEVICES names fewer than two devices")
+	}
+	iq, err := os.ReadFile(filepath.Join("..", "assets", "sample.bin"))
+	if err != nil {
+		t.Skip("assets/sample.bin not found")
+	}
+	for _, per := range []int{64, 200, 1} { // ranges longer and shorter than the priming reach, and the main.go loop
+		one := decodeAmd(t, []string{"scm", "idm"}, 72, iq, per)
+		many := decodeAmd(t, []string{"scm", "idm"}, 72, iq, per, devs...)
+		if len(one.hits) != len(many.hits) || one.hitsSha() != many.hitsSha() ||
+			one.pktSha(one.cfg.PacketSymbols/8) != many.pktSha(many.cfg.PacketSymbols/8) {
+			t.Errorf("%d blocks per call: %d devices give %d hits, one device %d (or other bytes)", per, len(devs), len(many.hits), len(one.hits))
 		}
 	}
 }
