@@ -43,10 +43,12 @@ __device__ __forceinline__ KsPair ks_compose(KsPair f, KsPair g)
 __device__ __forceinline__ void ks_term(float m, float inv_ulp, uint32_t &a, bool &tie)
 {
     const float x = m * inv_ulp;                            // exact: inv_ulp is a power of two
-    if (x >= 33554432.0f) { a = kSumCap; tie = false; return; }
-    const float t = truncf(x);
-    tie = (x - t) == 0.5f;                                  // exact difference
-    a = (uint32_t)(tie ? t : rintf(x));
+    const bool big = x >= 33554432.0f;                      // 2^25 ulps or more: the sum leaves the binade whatever it is
+    const float xs = big ? 0.0f : x;                        // (branch-free: the callers run this for every lane's every term)
+    const float t = truncf(xs);
+    tie = (xs - t) == 0.5f;                                 // exact difference
+    const uint32_t r = (uint32_t)(tie ? t : rintf(xs));
+    a = big ? kSumCap : r;
 }
 __device__ __forceinline__ uint32_t ks_step(uint32_t n, uint32_t a, bool tie) { return ks_sat(n + a + (tie ? ((n + a) & 1u) : 0u)); }
 
