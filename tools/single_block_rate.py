@@ -57,3 +57,21 @@ for protos in (["idm"], ["scm", "scm+", "idm", "r900"]):
     print(f"  {'+'.join(protos)}: {(time.perf_counter() - t0) / 180 * 1e6:.0f} us per call of {d2.Cfg.BlockSize} samples")
     d2.close()
 dec.close()
+
+# does a long-running loop of single-block calls ramp the shader clock (a fresh process starts low: bench.py's spin-up)?
+dec = ra.new_decoder(0)
+dec.RegisterProtocol(ra.new_parser("scm", chip))
+dec.Allocate()
+h = dec._require()
+lat = []
+t_end = time.perf_counter() + 2.0
+k = 0
+while time.perf_counter() < t_end:
+    t0 = time.perf_counter()
+    L.amr_decode_batch(h, iq.ctypes.data + (k % n) * bs2, bs2, 1, C.byref(res))
+    lat.append(time.perf_counter() - t0)
+    k += 1
+lat = np.array(lat) * 1e6
+q = len(lat) // 10
+print(f"  2 s of back-to-back single-block calls ({len(lat)}): median us per call by tenth of the run: " + " ".join(f"{np.median(lat[i * q:(i + 1) * q]):.1f}" for i in range(10)))
+dec.close()
