@@ -83,6 +83,9 @@ struct Slot {
     bool force_rerun = false;     // ... and "search this batch's tail again": an older batch's re-search changed that byte
     bool early = false;           // the batch's search ran on the search stream, next to its K1 (early search)
     uint32_t *d_k1flags = nullptr;   // [cnt_tiles] one "done" word per K1 wave-tile: the batch ticket when its rows are in memory
+    // stop event of this batch's second-to-last K1 round (batches of several launches): the PREVIOUS batch's gate kernel comes
+    // onto the chip behind it (amr_pipeline.hip, submit)
+    hipEvent_t ev_gate = nullptr;
     hipEvent_t ev_k2done = nullptr;  // early search: recorded behind K2 on the search stream (K3 on the tail stream waits for it)
     bool single = false;          // the batch was one block through the one-launch path (k1_single.h): h_out holds its result already
     hipEvent_t ev_k2 = nullptr, ev_t = nullptr;   // K2 stop, K3 start (timing level 2 with the tail on the second stream)

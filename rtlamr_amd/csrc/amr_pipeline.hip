@@ -109,6 +109,14 @@ amr_status ensure_capacity(amr_handle *h, Slot &s, Slot &other, size_t n_blocks)
 // same stream at once (enqueue_search; also every re-run after a capacity overflow) or later on the second stream
 // (pipelined callers: collect() launches it when the next batch's K1 has finished, so that it runs next to that
 // batch's K2 instead of in front of its K1).  `split`: K2 gets a stop event of its own for timing level 2.
+// developer hook for A/B runs: AMR_GATE_EVENT=0 leaves the gate kernel where round 4 had it (resident as soon as the tail
+// stream reaches it)
+static bool getenv_off_gate_event(const amr_handle *)
+{
+    static const int off = [] { const char *e = getenv("AMR_GATE_EVENT"); return (e && e[0] == '0') ? 1 : 0; }();
+    return off != 0;
+}
+
 amr_status enqueue_k2(amr_handle *h, Slot &s, hipStream_t st, bool rerun, bool dense, bool split,
                       const amr::HistArgs *fold = nullptr, bool *folded = nullptr, bool early = false)
 {
@@ -387,15 +395,27 @@ amr_status submit(amr_handle *h, const uint8_t *d_iq, size_t n_blocks, bool sear
     const uint32_t round = bs >= 4096 ? (uint32_t)h->n_cus * 8u : full;
     // Small batches entirely as one wave per block (k1_coop.h): a wave-tile costs a whole wave life (150-175 us) however few
     // tiles there are; a wave per block finishes in ~50 us as long as the waves fit the chip side by side (all_coop).
+    // What the previous batch's gate kernel waits for before it comes onto the chip (see below): the end of the K1 round in
+    // front of this batch's LAST K1 launch, as the stop event of that dispatch (its completion signal: an event recorded
+    // between the two launches is a packet of its own and costs the compute stream 5 us).  Batches of one launch: nothing --
+    // the gate is gone 6 us after the launch's last workgroup has started, a workgroup it displaced starts 7 us late, and
+    // the search's end as a stop event costs more than that (1 us of the search, 2 us of the K1 behind it:
+    // profiles/r05/k1_gate_fragmentation.txt).
+    const bool gate_ev = gate_prev && !getenv_off_gate_event(h);
+    hipEvent_t gate_wait = nullptr;
     if (all_coop) {
         amr::launch_k1_coop(h->geom.chip_length, 0u, (uint32_t)rows, st, k1_last, e0, e1);
     } else {
-        for (uint32_t w0 = 0; w0 < full; w0 += round) {
+        const uint32_t n_launches = (full ? (full + round - 1) / round : 0u) + (rem ? 1u : 0u);
+        uint32_t li = 0;
+        for (uint32_t w0 = 0; w0 < full; w0 += round, ++li) {
             const uint32_t n = std::min(round, full - w0);
             const bool last = w0 + n == full && !rem;
             amr::K1Args &kk = last ? k1_last : k1;
             kk.wg_first = w0;
-            amr::launch_k1(h->geom.chip_length, dim3(n), st, kk, w0 == 0 ? e0 : nullptr, last ? e1 : nullptr);
+            hipEvent_t stop = last ? e1 : nullptr;
+            if (li + 2 == n_launches && gate_ev) { stop = s.ev_gate; gate_wait = s.ev_gate; }   // the launch in front of the announcing one
+            amr::launch_k1(h->geom.chip_length, dim3(n), st, kk, w0 == 0 ? e0 : nullptr, stop);
         }
         if (rem)     // the blocks behind the last whole wave-tile (sync callers, flush): a wave each
             amr::launch_k1_coop(h->geom.chip_length, full * 64u, rem, st, k1_last, full ? nullptr : e0, e1);
@@ -412,6 +432,16 @@ amr_status submit(amr_handle *h, const uint8_t *d_iq, size_t n_blocks, bool sear
     // behind K2 on the compute stream 0.289; the gate's extra delay -- 0, 6 or 20 us --, whether it is enqueued before
     // or behind K2, and stream priorities make no difference that survives the run-to-run noise.)
     if (gate_prev) {
+        // The gate's one wave must not come onto the chip while waves of OTHER kernels are there.  It needs 8 registers and K1
+        // leaves 16 per SIMD free -- but a SIMD's registers are handed out as contiguous ranges, and a gate that started
+        // next to search or K3 waves (whenever the tail stream got to it: usually during this slot's previous search) may sit
+        // in the MIDDLE of its SIMD's file, where no two ranges of 248 fit around it.  One K1 workgroup then finds no slot
+        // and, the dispatcher placing workgroups in order, holds up the ones behind it on its XCD until the first K1 wave of
+        // that shader engine retires: 4 of 2048 workgroups start 330 us late and run alone at the end (IDM geometry with
+        // the two-lanes-per-row search: first K1 round 530 us instead of 400; profiles/r05/k1_gate_fragmentation.txt).  So the
+        // gate waits, as an event in front of it, for the end of what precedes the K1 launch it is about (gate_wait above):
+        // by then the chip holds nothing but K1 waves (ranges at 0, 248 and 496), or nothing.
+        if (gate_wait) HIP_TRY(hipStreamWaitEvent(h->tail_stream, gate_wait, 0));
         hipLaunchKernelGGL(amr::k_gate, dim3(1), dim3(1), 0, h->tail_stream, h->d_k1_started, s.ticket, 600u /* 6 us */,
                            h->gate_timeout_ticks, prev.d_overflow);
         HIP_TRY(hipGetLastError());
@@ -859,9 +889,16 @@ amr_status amr_host::drain(amr_handle *h)
     return AMR_OK;
 }
 
+#if AMR_K1T_CLK
+namespace amr { void k1t_dump_timeline(const char *path); }   // k1_launch.inc, diagnostic builds
+#endif
+
 void amr_host::dump_diagnostics(amr_handle *h)
 {
     (void)h;
+#if AMR_K1T_CLK
+    if (const char *fn = getenv("AMR_K1_TIMELINE")) amr::k1t_dump_timeline(fn);
+#endif
 #if AMR_K3_DBG
     {   // diagnostic build: phases of the last K3 launch's workgroups
         (void)hipDeviceSynchronize();

@@ -182,6 +182,7 @@ amr_status amr_create(const amr_protocol *protos, int32_t n_protos, int32_t devi
         if (e == hipSuccess) e = hipEventCreate(&sl.ev_t);
         if (e == hipSuccess) e = hipEventCreateWithFlags(&sl.ev_pack, hipEventDisableTiming);
         if (e == hipSuccess) e = hipEventCreateWithFlags(&sl.ev_k2done, hipEventDisableTiming);
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&sl.ev_gate, hipEventDisableTiming);
         if (e == hipSuccess) e = hipEventCreateWithFlags(&sl.ev_h2d, hipEventDisableTiming);
         if (e == hipSuccess) e = hipHostMalloc((void **)&sl.h_done, 8, hipHostMallocCoherent);
         if (e == hipSuccess) *sl.h_done = 0;
@@ -245,6 +246,7 @@ amr_status amr_destroy(amr_handle *h)
     }
     for (Slot &sl : h->slot) {
         if (sl.ev_k2done) (void)hipEventDestroy(sl.ev_k2done);
+        if (sl.ev_gate) (void)hipEventDestroy(sl.ev_gate);
         if (sl.d_k1flags) (void)hipFree(sl.d_k1flags);
         void *dp[] = {sl.d_qt, sl.d_counts, sl.d_gcnt, sl.d_offs_pre, sl.d_overflow, sl.d_staging, sl.d_out, sl.d_iq_stage, sl.d_r900,
                       sl.d_val, sl.d_keep, sl.d_listoff, sl.d_offs_val};

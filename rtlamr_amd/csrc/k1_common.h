@@ -20,6 +20,11 @@
 #define AMR_K1_PIPE 0   // first-generation kernel only (k1_demod.h); K1Geom::NW below depends on it
 #endif
 
+// diagnostic builds (make EXTRA=-DAMR_K1T_CLK=1, tools/build_variant.sh): per-workgroup clock stamps of k1t_demod
+#ifndef AMR_K1T_CLK
+#define AMR_K1T_CLK 0
+#endif
+
 namespace amr {
 
 constexpr int kRows = 64;                       // block-rows per wave, one per lane
@@ -45,7 +50,7 @@ struct K1Args {
     // end of this launch instead of standing in front of it.  null: no announcement.
     uint64_t *started;
     uint64_t started_value;
-    // Early search (amr_pipeline.hip): the search of this batch runs on a stream of its own NEXT to this launch
+    // Early search (amr_pipeline.hip): the search of this batch runs off the compute stream, NEXT to this launch,
     // and takes a tile as soon as the waves that wrote it are done.  Every wave, at its end, waits for its stores (sc1:
     // written through, nothing stays dirty in the XCD's L2) and then stores done_value into done_flags[wave-tile]; the wave of
     // the batch's last wave-tile also leaves the IQ halo of the next batch's block 0 in carry_out (decode.go:165), which the
@@ -53,6 +58,9 @@ struct K1Args {
     uint32_t *done_flags;
     uint8_t *carry_out;
     uint32_t done_value;
+#if AMR_K1T_CLK
+    uint32_t tl_seq;       // diagnostic builds: slot of this launch in k1t_timeline (k1_launch.inc counts)
+#endif
 };
 
 __device__ __forceinline__ void k1_announce(const K1Args &a, uint32_t lane)

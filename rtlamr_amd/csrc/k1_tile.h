@@ -23,10 +23,7 @@
 // window (they stay in the L2 / Infinity Cache).
 // Tuning knobs are template parameters (struct K1TCfg) so that one binary can hold several variants and compare them on
 // the same buffer (tools/k1_bench.hip); the product instantiates K1TDefault only.
-// harness only: lane 0 of workgroup 0 leaves (shader clock ticks, 100 MHz real-time ticks) of its run in qt[0..3]
-#ifndef AMR_K1T_CLK
-#define AMR_K1T_CLK 0
-#endif
+// harness only (AMR_K1T_CLK, k1_common.h): lane 0 of workgroup 0 leaves (shader clock ticks, 100 MHz real-time ticks) of its run in qt[0..3]
 #ifndef AMR_K1T_LUT_DMA
 #define AMR_K1T_LUT_DMA 1     // 0: the round-2 table fill (global load + ds_write in front of the first tile), for A/B builds
 #endif
@@ -34,7 +31,10 @@
 namespace amr {
 
 #if AMR_K1T_CLK
-__device__ unsigned long long k1t_timeline[2 * 8192];   // harness only: 100 MHz start / end tick of every workgroup
+// diagnostic builds only: per workgroup of the last kK1TLaunches launches (K1Args::tl_seq picks the slot): 100 MHz start
+// tick, end tick, (XCC_ID << 32 | HW_ID)
+constexpr int kK1TLaunches = 64, kK1TWgs = 2048;
+__device__ unsigned long long k1t_timeline[kK1TLaunches][kK1TWgs][3];
 #endif
 
 // SCHED  instruction order inside a tile: 0 = per group: 16 gathers, then the 8 samples' arithmetic; 1 = per half
@@ -562,7 +562,13 @@ __global__ __launch_bounds__(64, 2) void k1t_demod(const K1Args a)
         const uint64_t c = __builtin_readcyclecounter() - clk0, r = __builtin_amdgcn_s_memrealtime() - rt0;
         a.qt[0] = (uint32_t)c; a.qt[1] = (uint32_t)(c >> 32); a.qt[2] = (uint32_t)r; a.qt[3] = (uint32_t)(r >> 32);
     }
-    if (lane == 0 && blockIdx.x < 8192) { k1t_timeline[2 * blockIdx.x] = rt0; k1t_timeline[2 * blockIdx.x + 1] = __builtin_amdgcn_s_memrealtime(); }
+    if (lane == 0 && blockIdx.x < (uint32_t)kK1TWgs) {
+        uint32_t xcc, hw;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+        unsigned long long *t = k1t_timeline[a.tl_seq % kK1TLaunches][blockIdx.x];
+        t[0] = rt0; t[1] = __builtin_amdgcn_s_memrealtime(); t[2] = ((unsigned long long)xcc << 32) | hw;
+    }
 #endif
 }
 

@@ -62,13 +62,15 @@ constexpr int k2r_wpb()
     while (bs < pl) bs <<= 1;
     return (int)(bs / 32);
 }
-// lanes a row is split over: 1 up to 128 words (0: no row kernel for this geometry).  Rows of 256 words (idm / netidm /
-// r900 alone at chip length 72 .. 96) run as TWO lanes per row in the harness only (AMR_K2R_LPR2, tools/k2_bench.hip):
-// the kernel is bit-identical to the walk and 20 % faster on its own (idm, 4 GiB: 64.0 -> 51.4 us), but in the pipelined
-// product the FIRST of the two K1 rounds behind it then takes 500 us instead of 390 (shader clock unchanged; not at
-// --depth 1, not with one-round batches: profiles/r04/k2_row2_cfg3.txt) and cfg3 loses 7 %.  Not understood; not used.
+// lanes a row is split over: 1 up to 128 words, 2 for rows of 256 words (idm / netidm / r900 alone at chip length 72 .. 96),
+// 0: no row kernel for this geometry.  Two lanes per row read the bitstream once where the walk re-reads every row's
+// look-ahead: bit-identical, 20 % faster on its own (idm, 4 GiB: 64.0 -> 51.4 us in tools/k2_bench.hip).  Round 4 had it in
+// the harness only, because in the pipelined product the FIRST of the two K1 rounds behind it took 500 us instead of 390;
+// round 5 found why (the previous batch's gate kernel, which came onto the chip next to this kernel's waves and ended up in
+// the middle of a SIMD's register file: submit() in amr_pipeline.hip, profiles/r05/k1_gate_fragmentation.txt) and it is
+// the product's search for these geometries now.  AMR_K2R_LPR2=0 builds the round-4 library (tools/build_variant.sh).
 #ifndef AMR_K2R_LPR2
-#define AMR_K2R_LPR2 0
+#define AMR_K2R_LPR2 1
 #endif
 template <int SL, int KIND>
 constexpr int k2r_lpr()

@@ -182,21 +182,21 @@ int main(int argc, char **argv)
             { uint32_t c[4]; CK(hipMemcpy(c, d_qt, 16, hipMemcpyDeviceToHost));
               const double cyc = (double)(((uint64_t)c[1] << 32) | c[0]), rt = (double)(((uint64_t)c[3] << 32) | c[2]);
               if (rt > 0) printf("  clk %.2f GHz", cyc / (rt * 10.0));
-              static std::vector<unsigned long long> tl(2 * 8192);
+              static std::vector<unsigned long long> tl(3 * amr::kK1TWgs);      // slot 0 of the timeline (tl_seq stays 0 here)
               CK(hipMemcpyFromSymbol(tl.data(), HIP_SYMBOL(amr::k1t_timeline), tl.size() * 8));
-              const unsigned nwg = std::min<unsigned>(8192, n_blocks / 64);
+              const unsigned nwg = std::min<unsigned>(amr::kK1TWgs, n_blocks / 64);
               unsigned long long t0 = ~0ull, t1 = 0;
-              for (unsigned i = 0; i < nwg; ++i) { t0 = std::min(t0, tl[2 * i]); t1 = std::max(t1, tl[2 * i + 1]); }
+              for (unsigned i = 0; i < nwg; ++i) { t0 = std::min(t0, tl[3 * i]); t1 = std::max(t1, tl[3 * i + 1]); }
               std::vector<double> st, du, en;
-              for (unsigned i = 0; i < nwg; ++i) { st.push_back((tl[2 * i] - t0) * 0.01); du.push_back((tl[2 * i + 1] - tl[2 * i]) * 0.01); en.push_back((t1 - tl[2 * i + 1]) * 0.01); }
+              for (unsigned i = 0; i < nwg; ++i) { st.push_back((tl[3 * i] - t0) * 0.01); du.push_back((tl[3 * i + 1] - tl[3 * i]) * 0.01); en.push_back((t1 - tl[3 * i + 1]) * 0.01); }
               std::sort(st.begin(), st.end()); std::sort(du.begin(), du.end()); std::sort(en.begin(), en.end());
               auto pc = [](const std::vector<double> &v, double f) { return v[(size_t)(f * (v.size() - 1))]; };
               printf("\n     timeline us (last launch): span %.1f | start p50 %.1f p90 %.1f p99 %.1f max %.1f | duration p1 %.1f p50 %.1f p99 %.1f | end before last: p50 %.1f p90 %.1f max %.1f",
                      (t1 - t0) * 0.01, pc(st, .5), pc(st, .9), pc(st, .99), pc(st, 1), pc(du, .01), pc(du, .5), pc(du, .99), pc(en, .5), pc(en, .9), pc(en, 1));
               printf("\n     mean duration per XCD (b %% 8):");
-              for (unsigned x = 0; x < 8; ++x) { double m = 0, mx = 0; unsigned n = 0; for (unsigned i = x; i < nwg; i += 8) { const double d = (tl[2 * i + 1] - tl[2 * i]) * 0.01; m += d; mx = std::max(mx, d); ++n; } printf(" %.1f(max %.1f)", m / n, mx); }
+              for (unsigned x = 0; x < 8; ++x) { double m = 0, mx = 0; unsigned n = 0; for (unsigned i = x; i < nwg; i += 8) { const double d = (tl[3 * i + 1] - tl[3 * i]) * 0.01; m += d; mx = std::max(mx, d); ++n; } printf(" %.1f(max %.1f)", m / n, mx); }
               printf("\n     mean duration by dispatch order (b >> 3, 8 groups of 32):");
-              for (unsigned gq = 0; gq < 8; ++gq) { double m = 0; unsigned n = 0; for (unsigned i = 0; i < nwg; ++i) if (((i >> 3) * 8 / (nwg / 8)) == gq) { m += (tl[2 * i + 1] - tl[2 * i]) * 0.01; ++n; } printf(" %.1f", n ? m / n : 0.0); }
+              for (unsigned gq = 0; gq < 8; ++gq) { double m = 0; unsigned n = 0; for (unsigned i = 0; i < nwg; ++i) if (((i >> 3) * 8 / (nwg / 8)) == gq) { m += (tl[3 * i + 1] - tl[3 * i]) * 0.01; ++n; } printf(" %.1f", n ? m / n : 0.0); }
             }
 #endif
             printf("\n");
