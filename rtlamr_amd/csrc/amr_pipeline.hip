@@ -363,7 +363,7 @@ amr_status submit(amr_handle *h, const uint8_t *d_iq, size_t n_blocks, bool sear
     // 32 .. 48.  At BlockSize 512 (chip 8) K1 is one launch of eight rounds, out of step anyway: 3-5 % faster.
     const bool early_here = h->early_mode > 0 || (h->early_mode < 0 && bs <= 512);
     if (lazy && early_here && !all_coop && rem == 0 && full > 0 && n_head == 0 && new_head == 0 && h->r900_pid < 0 && !s.dense &&
-        !h->dense_search && h->sg.n_pre == 1 && h->geom.chip_length != 96) {
+        !h->dense_search && h->sg.n_pre == 1) {
         const int kind = amr::k2_walk_kind_of(h->sg.pre_len[0], h->sg.pre_bits[0]);
         amr::K2Args q{};                              // qt null: a question, not a launch
         q.g = h->sg; q.n_tiles = s.n_tiles;
@@ -421,7 +421,7 @@ amr_status submit(amr_handle *h, const uint8_t *d_iq, size_t n_blocks, bool sear
             amr::launch_k1_coop(h->geom.chip_length, full * 64u, rem, st, k1_last, full ? nullptr : e0, e1);
     }
     HIP_TRY(hipGetLastError());
-    AMR_DBG(st, "k1_demod");
+    AMR_DBG(st, "k1");
     // The tail of the previous batch (its K3, K4, K5 and the kernel that publishes its ticket), enqueued NOW on the second
     // stream behind a gate that opens when this batch's K1 has every wave on the chip.  K1 holds all LDS and all but 16
     // registers per SIMD, so the tail's workgroups get on the chip only where K1 waves retire: they fill the ragged end

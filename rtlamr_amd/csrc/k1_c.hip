@@ -1,5 +1,8 @@
 #define AMR_K1_UNIT launch_k1_c
 #define AMR_K1_CASES(X) X(80) X(88) X(96)
+#ifdef AMR_K1T_DUMP_C
+#define AMR_K1T_DUMP_HERE 1     // diagnostic builds: the timeline dump of this unit's kernels (chip 80 .. 96) instead of k1_b.hip's
+#endif
 #include "k1_launch.inc"
 namespace amr {
 bool launch_k1_a(int, dim3, hipStream_t, const K1Args &, hipEvent_t, hipEvent_t);

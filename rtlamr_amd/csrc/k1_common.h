@@ -1,5 +1,5 @@
-// What the K1 kernels share -- k1_tile.h (whole wave-tiles, chip length 8 .. 88), k1_demod.h (whole wave-tiles, chip length
-// 96: the first generation), k1_coop.h (one wave per block) --: the launch arguments, the "tiled4" output layout, where a
+// What the K1 kernels share -- k1_tile.h (whole wave-tiles), k1_coop.h (one wave per block), and in the harness the first
+// generation (tools/k1_demod_gen1.h; K1Geom's RING / NW and AMR_K1_PIPE below are its) --: the launch arguments, the "tiled4" output layout, where a
 // wave-tile's rows start, the announcement to the gate, and the LDS-DMA of one staging tile.
 //
 // Output layout ("tiled4"): word w of block b is stored at
@@ -17,7 +17,7 @@
 #endif
 
 #ifndef AMR_K1_PIPE
-#define AMR_K1_PIPE 0   // first-generation kernel only (k1_demod.h); K1Geom::NW below depends on it
+#define AMR_K1_PIPE 0   // first-generation kernel only (tools/k1_demod_gen1.h); K1Geom::NW below depends on it
 #endif
 
 // diagnostic builds (make EXTRA=-DAMR_K1T_CLK=1, tools/build_variant.sh): per-workgroup clock stamps of k1t_demod

@@ -1,7 +1,7 @@
 // K1 for the blocks that do not fill a wave-tile -- the last < 64 blocks of a batch, every block of a small batch -- as ONE
 // WAVE PER BLOCK instead of one lane per block.
 //
-// The tile kernels (k1_tile.h, k1_demod.h) give a lane a whole reference block because the reference's running sum is
+// The tile kernel (k1_tile.h) gives a lane a whole reference block because the reference's running sum is
 // sequential float32 (decode.go:232-236) and 64 lanes = 64 blocks fill a wave; a lone block then costs a whole wave
 // life, 150-175 us, with 63 lanes idle.  Here the 64 lanes of a wave share ONE block:
 //   * the first 256 samples of the Signal, 64 at a time: magnitudes in parallel (two LUT gathers from LDS, one float add:

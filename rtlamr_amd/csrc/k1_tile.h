@@ -1,6 +1,5 @@
-// K1 (second generation) -- the same computation as k1_demod.h (MagLUT.Execute + Decoder.Filter + pack,
-// protocol/decode.go:219-245, one lane = one reference block, same operation order and roundings), reorganised
-// around what bounded the first kernel on MI355X: with two waves per SIMD nothing hides a stall, so the kernel
+// K1 -- MagLUT.Execute + Decoder.Filter + pack (protocol/decode.go:219-245; one lane = one reference block, same operation
+// order and roundings), organised around what bounded the first kernel (tools/k1_demod_gen1.h) on MI355X: with two waves per SIMD nothing hides a stall, so the kernel
 //   1. keeps the staging tile in REGISTERS.  A tile (64 rows x 128 B) that has landed in LDS is drained into 32 VGPRs in
 //      one burst at the tile boundary (the same eight ds_read_b128 the old kernel spread over the tile), which frees its
 //      LDS buffer a whole tile-time early: the DMA of the tile after next goes out at once and is in flight during the
@@ -13,7 +12,7 @@
 //      per-group branches, three instructions per DMA piece.
 //   3. lets the two waves of a SIMD swap s_setprio every 8 tiles (PRIO below): the arbiter's preference for the older
 //      wave made it finish 9 % earlier and leave the other one alone for the rest of the launch.
-// Output layout, arguments and the halo/carry conventions are those of k1_demod.h (K1Args, "tiled4" bitstream).
+// Output layout, arguments and the halo/carry conventions: k1_common.h (K1Args, "tiled4" bitstream).
 #pragma once
 #include "k1_common.h"
 
@@ -26,6 +25,13 @@
 // harness only (AMR_K1T_CLK, k1_common.h): lane 0 of workgroup 0 leaves (shader clock ticks, 100 MHz real-time ticks) of its run in qt[0..3]
 #ifndef AMR_K1T_LUT_DMA
 #define AMR_K1T_LUT_DMA 1     // 0: the round-2 table fill (global load + ds_write in front of the first tile), for A/B builds
+#endif
+
+// chip length 80: rings of 88 slots (a super-body of 11 tiles).  Rounds 2-4 used 96 (3 tiles) and paid for the 16 extra slots
+// with a third of the hd ring in LDS and four store bursts per block; in the pipelined product (where the bitstream of four
+// slots does not stay in the Infinity Cache as the harness's one does) that cost 6 % of K1: 0.210-0.213 -> 0.199-0.201 ms.
+#ifndef AMR_K1T_RING80
+#define AMR_K1T_RING80 88
 #endif
 
 namespace amr {
@@ -56,11 +62,12 @@ __device__ unsigned long long k1t_timeline[kK1TLaunches][kK1TWgs][3];
 //        priority 0 / 1 every tile / 4 tiles / 16 tiles (the wave in the odd slot starts high).  5: priority 2 from the
 //        wait for the next tile to the issue of the following DMA (the memory-critical stretch), 0 otherwise; 6 = 5 on
 //        top of the per-tile swap of 2 (levels 0 / 1, boundary 3).  10 + k: swap every 2^k tiles.
-// HDL    slots of the hd ring that live in LDS instead of registers (chip length 80 / 88: rings of 96 slots do not fit
-//        256 VGPRs next to the register tile; a value of the ring is written once and read once, chip-length steps
-//        later, so a third of the ring -- the slots at the ring's upper end -- goes through LDS: two ds_write_b128 when
+// HDL    slots of the hd ring that live in LDS instead of registers (chip length 80 .. 96: two rings of 88 .. 104 slots do
+//        not fit 248 VGPRs next to the register tile; a value of the ring is written once and read once, chip-length steps
+//        later, so part of the ring -- the slots at the ring's upper end -- goes through LDS: two ds_write_b128 when
 //        a group of 8 is produced, two ds_read_b128 one ring turn minus a chip later, fetched next to the LUT gathers).
-//        Costs parking space: 8 KiB of hd leave 3 KiB for output chunks, i.e. four store bursts per 4096-sample block.
+//        Costs parking space: chip 88's 8 KiB of hd leave 3 KiB for output chunks, i.e. four store bursts per 4096-sample
+//        block, chip 96's 10 KiB leave one (eight bursts).
 template <int SCHED_, int DEPTH_, int XCD_, int NW_, int DIAG_ = 0, int STPOL_ = 0, int STORE_AFTER_ = 0, int NLC_ = 0, int PRIO_ = 0, int HDL_ = 0>
 struct K1TCfg {
     static constexpr int SCHED = SCHED_, DEPTH = DEPTH_, XCD = XCD_, NW = NW_, DIAG = DIAG_, STPOL = STPOL_, STORE_AFTER = STORE_AFTER_, NLC = NLC_, PRIO = PRIO_, HDL = HDL_;
@@ -73,10 +80,24 @@ struct K1TCfg {
     static_assert(HDL_ % 8 == 0 && kLds <= 20 * 1024, "20 KiB of LDS per wave at 8 waves per CU");
 };
 typedef K1TCfg<0, 1, 1, 16, 0, 1, 1, 11, 13> K1TDefault;            // chip length <= 72
-typedef K1TCfg<0, 1, 1, 16, 0, 1, 1, 3, 13, 32> K1TLongChip;        // chip length 80 / 88: rings of 96, 32 hd slots in LDS
+typedef K1TCfg<0, 1, 1, 16, 0, 1, 1, 3, 13, 32> K1TLongChip;        // chip length 88: rings of 96, 32 hd slots in LDS
+// chip length 96: rings of 104 (a super-body of 13 tiles), 40 hd slots in LDS, 8 output words in registers and one chunk
+// parked: 247 registers.  (NW 8, NLC 3, HDL 32 is 3 % faster alone -- 24-word store bursts instead of 16 -- but takes 256
+// registers, and a K1 wave of more than 248 leaves no room for the tail's gate kernel next to two of them:
+// amr_pipeline.hip, submit.)
+#ifndef AMR_K1T_96
+#define AMR_K1T_96 8, 0, 1, 1, 1, 13, 40       // NW, DIAG, STPOL, STORE_AFTER, NLC, PRIO, HDL (harness / variant builds override)
+#endif
+typedef K1TCfg<0, 1, 1, AMR_K1T_96> K1TChip96;
+// chip length 80: 8 hd slots in LDS, 9 parked chunks: store bursts of 48 words (241 registers)
+#ifndef AMR_K1T_80
+#define AMR_K1T_80 8, 0, 1, 1, 9, 13, 8
+#endif
+typedef K1TCfg<0, 1, 1, AMR_K1T_80> K1TChip80;
 template <int CL> struct K1TCfgFor { typedef K1TDefault type; };
-template <> struct K1TCfgFor<80> { typedef K1TLongChip type; };
+template <> struct K1TCfgFor<80> { typedef K1TChip80 type; };
 template <> struct K1TCfgFor<88> { typedef K1TLongChip type; };
+template <> struct K1TCfgFor<96> { typedef K1TChip96 type; };
 
 constexpr int k1t_gcd(int a, int b) { return b == 0 ? a : k1t_gcd(b, a % b); }
 
@@ -89,12 +110,12 @@ struct K1TGeom {
     static constexpr int WARM = HBA / 2;               // = SKIP + SL: first sample of the block proper, tile aligned
     static constexpr int NPT = HBA / kTileBytes;       // halo tiles
     // csum rings: slot t % RING is written at step t and holds c[t] / d[t] until step t + CL reads it.  RING is the
-    // smallest multiple of 8 above CL whose super-body stays small (chip 64: 80, not 72 -> 5 tiles instead of 9).
-    static constexpr int RING = (CL == 64) ? 80 : (CL == 80) ? 96 : CL + 8;
+    // smallest multiple of 8 above CL (chip 64: 80, not 72 -> a super-body of 5 tiles instead of 9; kept from round 2).
+    static constexpr int RING = (CL == 64) ? 80 : (CL == 80) ? AMR_K1T_RING80 : CL + 8;
     static constexpr int SPB = RING / k1t_gcd(RING, 64) * 64;   // samples per super-body
     static constexpr int TPS = SPB / 64;                         // tiles per super-body
-    static constexpr int HDL = K1TCfgFor<CL>::type::HDL;        // hd slots in LDS (the ring's upper end)
-    static constexpr bool supported = (TPS <= 7) && (2 * RING - HDL <= 160);
+    // (every legal chip length, flags.go:127-132, has a configuration: K1TCfgFor.  Round 2 stopped at 7 tiles per super-body
+    // for fear of the instruction footprint; chip 96 runs 13 and is no slower per sample than chip 88 with 3.)
 };
 
 typedef const __attribute__((address_space(3))) float *k1t_lds_f;
@@ -311,7 +332,7 @@ __device__ __forceinline__ void k1t_word(K1TLane<CL, C> &L, K1TUni &U)
 // Steady-state DMA of one tile into the buffer at LDS offset `par`: eight pieces of 8 rows, SGPR base per piece
 // (constant per wave), the tile's byte offset inside the lane offsets vt_e / vt_o (the instruction's immediate offset
 // would also shift the LDS destination, so it stays 0), M0 = par + piece * 1 KiB.
-// Issued from inline asm so that hipcc does not guard later LDS reads with vmcnt(0) (see k1_demod.h).
+// Issued from inline asm so that hipcc does not guard later LDS reads with vmcnt(0) (see k1_prefetch, k1_common.h).
 __device__ __forceinline__ void k1t_dma_fast(const uint8_t *const (&sb)[8], uint32_t vt_e, uint32_t vt_o, uint32_t par)
 {
     par = __builtin_amdgcn_readfirstlane(par);   // wave-uniform by construction; makes it an SGPR for the asm operand

@@ -1,9 +1,9 @@
 """One pipeline mode, several search kernels.  The library has no run-time switches between kernel generations any more
 (round 2's AMR_K1_IMPL / AMR_K2_IMPL / AMR_K3_IMPL / AMR_TAIL_MODE / AMR_TAIL_OVERLAP / AMR_HIST_FOLD are gone); which
 kernel runs follows from the geometry alone:
-  K1   whole wave-tiles: k1t_demod (register tile) for chip <= 88, k1_demod for chip 96; the blocks behind the last whole
-       wave-tile, and small batches throughout: k1c_demod (one wave per block)
-  K2   k2_search_walk<SymbolLength, set> for every set of rtlamr's own preambles (scm, scm+, idm / netidm, r900) at every
+  K1   whole wave-tiles: k1t_demod (register tile; part of the hd ring in LDS for chip 80 .. 96); the blocks behind the last
+       whole wave-tile, and small batches throughout: k1c_demod (one wave per block)
+  K2   k2_search_row for one known preamble (two lanes per row at BlockSize 8192), k2_search_walk<SymbolLength, set> for every set of rtlamr's own preambles (scm, scm+, idm / netidm, r900) at every
        BlockSize from 512 to 8192; k2_search_fast when a set holds any other preamble (a custom protocol entry), up to
        four; k2_search_dense for more than four preambles, rows under 16 words, and as the overflow fallback (test hook
        AMR_DENSE_SEARCH, read at amr_create)
@@ -70,9 +70,12 @@ def _pipeline(dec, iq, sizes, depth=3):
     (["scm", "scm+", "idm", "r900"], 72, False),     # all four preambles, rows of 256 words
     (["r900", "scm+"], 56, False),                   # a two-preamble set, registration order != the kernel's kind order
     (["scm"], 8, False),                             # rows of 16 words
-    (["scm"], 88, False),                            # k1_demod
+    (["scm"], 88, False),                            # hd ring partly in LDS, rings of 96
+    (["scm"], 96, False),                            # rings of 104: a super-body of 13 tiles
+    (["scm"], 80, False),                            # rings of 88: 11 tiles
+    (["idm"], 72, False),                            # k2_search_row, two lanes per row
     (["scm", "idm"], 72, True),                      # k2_search_dense everywhere (AMR_DENSE_SEARCH)
-], ids=["walk", "walk-4pre", "walk-2pre-order", "walk-chip8", "k1-first-gen", "dense"])
+], ids=["walk", "walk-4pre", "walk-2pre-order", "walk-chip8", "k1-chip88", "k1-chip96", "k1-chip80", "row-two-lanes", "dense"])
 def test_three_deep_pipeline_with_every_search_kernel(protos, chip, dense, monkeypatch):
     if dense:
         monkeypatch.setenv("AMR_DENSE_SEARCH", "1")

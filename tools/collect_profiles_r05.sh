@@ -16,6 +16,9 @@ for w in cfg2 cfg3 cfg5; do
   timeout 300 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $O/$w/pmc_fetch -o pmc --output-format csv -- $D > $O/$w.pmc_fetch.log 2>&1
   timeout 300 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $O/$w/pmc_write -o pmc --output-format csv -- $D > $O/$w.pmc_write.log 2>&1
   fi
+  if [ $w = cfg3 ]; then   # the search's reads: two lanes per row read the bitstream once (FETCH <= 1.15 x 268 MB)
+  timeout 300 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $O/$w/pmc_fetch -o pmc --output-format csv -- $D > $O/$w.pmc_fetch.log 2>&1
+  fi
 done
 cd $R
 F=$(find $O/cfg2/stats -name '*kernel_trace.csv' | head -1); python tools/timeline.py $F 6 > $O/timeline_cfg2.txt 2>&1

@@ -14,7 +14,7 @@
 #include <cstdlib>
 #include <string>
 #include <vector>
-#include "k1_demod.h"
+#include "k1_demod_gen1.h"     // the first-generation kernel ("old"): the harness keeps it as a second opinion
 #include "k1_tile.h"
 #include "synth.h"
 

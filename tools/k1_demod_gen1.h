@@ -1,4 +1,5 @@
-// First-generation K1: today the kernel of chip length 96 only (its csum rings do not fit k1_tile.h at 8 waves per CU).
+// First-generation K1 (rounds 1-2; chip length 96's kernel until round 5).  Harness only (tools/k1_bench.hip, variant "old"):
+// an independently written second implementation of the same arithmetic whose checksum every k1_tile.h variant must reproduce.
 // K1 -- fused magnitude LUT + cumulative-sum matched filter + quantize + pack.
 //
 // Computes, for every reference block k of a batch, exactly what
