@@ -28,8 +28,8 @@
 #endif
 
 // chip length 80: rings of 88 slots (a super-body of 11 tiles).  Rounds 2-4 used 96 (3 tiles) and paid for the 16 extra slots
-// with a third of the hd ring in LDS and four store bursts per block; in the pipelined product (where the bitstream of four
-// slots does not stay in the Infinity Cache as the harness's one does) that cost 6 % of K1: 0.210-0.213 -> 0.199-0.201 ms.
+// with a third of the hd ring in LDS and four store bursts per block; equal in the harness, 6 % of K1 in the pipelined
+// product: 0.210-0.213 -> 0.199-0.201 ms (profiles/r05/chip_80_96/k1_long_chips.txt).
 #ifndef AMR_K1T_RING80
 #define AMR_K1T_RING80 88
 #endif
