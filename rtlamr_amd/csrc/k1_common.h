@@ -16,6 +16,13 @@
 #define AMR_K1_LDFLAGS "nt"
 #endif
 
+// ... and of the halo tiles alone (the first NPT tiles of a row = the last NPT tiles of the row before it, which that row's
+// lane reads again at the end of the launch).  Experiment of round 5: left cacheable ("") they could come from the Infinity Cache
+// the second time: +1 % in the harness, -1..2 % in the pipelined bench; the default is the stream's policy.
+#ifndef AMR_K1_HALO_LDFLAGS
+#define AMR_K1_HALO_LDFLAGS AMR_K1_LDFLAGS
+#endif
+
 #ifndef AMR_K1_PIPE
 #define AMR_K1_PIPE 0   // first-generation kernel only (tools/k1_demod_gen1.h); K1Geom::NW below depends on it
 #endif
@@ -138,6 +145,19 @@ __device__ __forceinline__ void k1_prefetch(const K1Args &a, uint32_t lds_base, 
         // (Tried: when the first half of tile 0's line holds none of the 4 * CL halo bytes -- chip 8: 32 needed of 128 --
         // let the lanes of that half sit the DMA out.  Bit-exact, and not a microsecond faster at any chip length: a miss
         // brings the whole 128-byte line whatever part of it is asked for.)
+        if (t < (uint32_t)G::NPT) {                                 // halo tiles: their own cache policy (see AMR_K1_HALO_LDFLAGS)
+#pragma unroll 1
+            for (int q = 0; q < 4; ++q) {
+                asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1 " AMR_K1_HALO_LDFLAGS
+                             :: "v"(voff_e), "s"(base), "s"(m0v) : "memory");
+                base += (size_t)8 * bs2;
+                asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1 " AMR_K1_HALO_LDFLAGS
+                             :: "v"(voff_o), "s"(base), "s"(m0v + 1024) : "memory");
+                base += (size_t)8 * bs2;
+                m0v += 2048;
+            }
+            return;
+        }
 #pragma unroll 1
         for (int q = 0; q < 4; ++q) {                               // a rolled loop: this code sits in every group
             asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1 " AMR_K1_LDFLAGS

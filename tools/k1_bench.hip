@@ -155,17 +155,22 @@ int main(int argc, char **argv)
     CK(hipDeviceSynchronize());
 
     const double gb = 2.0 * n_blocks * bs;
-    for (int ai = 0; ai < n_allocs; ++ai) {
+    // K1B_ROTATE=1: every launch reads another of the n_allocs inputs (nothing of an input survives in a cache from one launch
+    // of it to the next); default: all repetitions on one input, then the next
+    const bool rotate = getenv("K1B_ROTATE") && n_allocs > 1;
+    for (int ai = 0; ai < (rotate ? 1 : n_allocs); ++ai) {
         a.iq = iqs[ai];
         std::vector<std::vector<float>> ms(vs.size());
         for (int r = 0; r < reps; ++r)
             for (size_t vi = 0; vi < vs.size(); ++vi) {
+                if (rotate) a.iq = iqs[(r * vs.size() + vi) % n_allocs];
                 vs[vi].launch(a, full, rem, e0, e1);
                 CK(hipEventSynchronize(e1));
                 float t; CK(hipEventElapsedTime(&t, e0, e1));
                 ms[vi].push_back(t);
             }
         CK(hipGetLastError());
+        a.iq = iqs[ai];
         for (size_t vi = 0; vi < vs.size(); ++vi) {
             CK(hipMemset(d_qt, 0, qt_words * 4));
             vs[vi].launch(a, full, rem, e0, e1);
