@@ -360,7 +360,7 @@ amr_status submit(amr_handle *h, const uint8_t *d_iq, size_t n_blocks, bool sear
     const bool gate_prev = prev.pending && prev.search && prev.tail_split && !prev.tail_enqueued;
     s.dense = h->dense_hold > 0;
     if (s.dense) h->dense_hold--;
-    // EARLY SEARCH: the search of this batch on a stream of its own, next to K1 -- the wave of a tile starts
+    // EARLY SEARCH: the search of this batch off the compute stream (on the tail stream), next to K1 -- the wave of a tile starts
     // as soon as the K1 waves that wrote it are done -- so that the next K1 launch follows this one directly.  For batches of
     // whole wave-tiles through the tile kernel, one preamble with a row kernel, nothing deferred; everything else keeps the
     // search between two K1 launches in stream order.
@@ -453,7 +453,7 @@ amr_status submit(amr_handle *h, const uint8_t *d_iq, size_t n_blocks, bool sear
         hipLaunchKernelGGL(amr::k_gate, dim3(1), dim3(1), 0, h->tail_stream, h->d_k1_started, s.ticket, gate_delay_ticks(),
                            h->gate_timeout_ticks, prev.d_overflow);
         HIP_TRY(hipGetLastError());
-        // (an early search ran on its own stream: nothing but this event orders K3 behind it)
+        // (an early search ran on the search stream -- today the tail stream itself, then this wait is a no-op)
         if (prev.early) HIP_TRY(hipStreamWaitEvent(h->tail_stream, prev.ev_k2done, 0));
         AMR_TRY(launch_tail(h, prev));
         prev.tail_gated = true;

@@ -184,7 +184,7 @@ struct K2Args {
     // no completion ticket (the search is still running
     // when it is done; a ticket from inside the kernel would also need every workgroup to release its writes, an L2
     // write-back each): the host takes "the next search has started" or "the stream is idle" as the signal instead.
-    // Early search: this launch runs on a stream of its own NEXT to the batch's K1 (behind a gate: every K1 wave is on
+    // Early search: this launch runs off the compute stream, NEXT to the batch's K1 (behind a gate: every K1 wave is on
     // the chip by then); the wave of tile T waits for done_flags[T - 1] (its rows) and done_flags[T] (the head of the tile
     // behind it) of K1Args before it loads anything, and loads past its caches (sc1).  null: the launch follows K1 in
     // stream order, as always.
