@@ -155,6 +155,7 @@ struct amr_handle {
     uint32_t n_head = 0;         // deferred blocks waiting in the head buffer
     bool zero_halo = true;
     bool dense_search = false;   // test hook (AMR_DENSE_SEARCH): always use the fallback search kernel
+    uint32_t k1_round_tiles = 0; // test hook AMR_K1_ROUND_TILES: wave-tiles per K1 launch (0: a chip's worth at BlockSize >= 4096, else one launch)
     uint64_t k1_coop_max = 0;    // batches of up to this many blocks run K1 as one wave per block throughout (k1_coop.h):
                                  // from kK1CoopMaxSamples / kK1CoopMaxBlocks; test hook AMR_K1_COOP_MAX (0: only the blocks
                                  // behind the last whole wave-tile -- keeps the tile kernels under the small-batch tests)

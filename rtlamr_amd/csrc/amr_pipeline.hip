@@ -400,7 +400,7 @@ amr_status submit(amr_handle *h, const uint8_t *d_iq, size_t n_blocks, bool sear
     // one launch, 4 x 0.179 ms in four; IDM (BlockSize 8192, 4 GiB) 0.860 -> 0.804 ms.  Short blocks (a round lasts
     // under 0.1 ms) lose more at the extra launch boundaries than they gain: BlockSize 2048 0.182 -> 0.256 ms, so they
     // keep the single launch.
-    const uint32_t round = bs >= 4096 ? (uint32_t)h->n_cus * 8u : full;
+    const uint32_t round = h->k1_round_tiles ? h->k1_round_tiles : bs >= 4096 ? (uint32_t)h->n_cus * 8u : full;
     // Small batches entirely as one wave per block (k1_coop.h): a wave-tile costs a whole wave life (150-175 us) however few
     // tiles there are; a wave per block finishes in ~50 us as long as the waves fit the chip side by side (all_coop).
     // What the previous batch's gate kernel waits for before it comes onto the chip (see below): the end of the K1 round in

@@ -82,7 +82,7 @@ def test_pipelined_decoder_under_a_serialising_runtime(protos, chip, per, n, env
 
 @pytest.mark.parametrize("chip", [72, 8, 32])
 def test_early_search_next_to_k1_equals_oracle(chip):
-    """The search of a batch on its own stream next to the batch's K1, every tile as soon as the K1 waves that wrote it have
+    """The search of a batch off the compute stream, next to the batch's K1, every tile as soon as the K1 waves that wrote it have
     said so (per-wave-tile flags, write-through stores, loads past L1), the next K1 launch no longer behind it: forced with
     AMR_EARLY_SEARCH=1 (by default only BlockSize <= 512 runs this way, where it was measured to pay); also with a gate that
     gives up at once, which must end in a re-search, not in other hits."""
@@ -94,3 +94,20 @@ def test_early_search_next_to_k1_equals_oracle(chip):
         assert {k: got[k] for k in want} == want, f"{env}: other hits than the oracle's"
         assert ("gate-timeouts" in got["describe"]) == ("AMR_GATE_TIMEOUT_US" in env)
         assert got["seconds"] < 2.0
+
+
+@pytest.mark.parametrize("env", [{}, {"AMD_SERIALIZE_KERNEL": "3"}, {"HIP_LAUNCH_BLOCKING": "1"}, {"AMR_GATE_TIMEOUT_US": "0"}, {"AMR_GATE_EVENT": "0"}],
+                         ids=["plain", "serialize-kernel", "launch-blocking", "gate-gives-up", "gate-without-event"])
+@pytest.mark.parametrize("protos,chip", [(["idm"], 72), (["scm"], 72), (["scm", "scm+", "idm", "r900"], 72)], ids=["idm-two-lanes-per-row", "scm", "all"])
+def test_batches_of_several_k1_launches(protos, chip, env):
+    """At full size a batch above a chip's worth of wave-tiles runs K1 in rounds (BlockSize >= 4096), and the previous batch's
+    gate kernel comes onto the chip behind the stop event of the round before the last (amr_pipeline.hip, submit).  Here at
+    test size: AMR_K1_ROUND_TILES=1 makes every wave-tile a launch of its own -- batches of 256 blocks are four launches --,
+    plain, under a serialising runtime, with a gate that gives up, and with round 4's gate placement."""
+    per, n = 256, 6
+    want = oracle_digest(protos, chip, per, n)
+    assert want["n_hits"] > 0
+    got = probe(protos, chip, per, n, env=dict(env, AMR_K1_COOP_MAX="0", AMR_K1_ROUND_TILES="1"))
+    assert {k: got[k] for k in want} == want, f"{env}: other hits than the oracle's"
+    assert ("gate-timeouts" in got["describe"]) == ("AMR_GATE_TIMEOUT_US" in env)
+    assert got["seconds"] < 2.0, f"the pipelined part took {got['seconds']:.2f} s: a device-side wait ran into its time-out"
