@@ -185,9 +185,16 @@ __device__ __forceinline__ void k3_chunk(const K3Args &a, const SearchGeom &g, u
                     A[e][k] = 0; B[e][k] = 0;
                     if (e < nb && p0 + 64 * k < PS) {
                         const uint32_t sy = p0 + 64 * k + sym_lane;
-                        const uint32_t v = v0[e] + (sy < PS ? sy : PS - 1) * SL;   // window = 32 stream bits from bit v
-                        if (LONG && staged) { A[e][k] = rows_lds[v >> 5]; B[e][k] = rows_lds[(v >> 5) + 1]; }
-                        else { A[e][k] = word_at(v); B[e][k] = word_at(v + 32); }
+                        const uint32_t so = (sy < PS ? sy : PS - 1) * SL;
+                        const uint32_t v = v0[e] + so;                             // window = 32 stream bits from bit v
+                        // v0 is word-aligned and SL a multiple of 16: the window is one word, or the halves of two.  The second
+                        // word only where it is needed -- every lane's window lies in a line of its own (symbols are SL bits
+                        // = 4.5 words at chip 72 apart, a row's words in 16-byte pieces a KiB apart), so a load instruction
+                        // costs the texture path as many line requests as it has lanes: half of them at SL = 16 mod 32,
+                        // none at SL = 0 mod 32 (chip 32, 48, 64, 80, 96)
+                        const bool two = (so & 16u) != 0;
+                        if (LONG && staged) { A[e][k] = rows_lds[v >> 5]; B[e][k] = two ? rows_lds[(v >> 5) + 1] : 0u; }
+                        else { A[e][k] = word_at(v); B[e][k] = two ? word_at(v + 32) : 0u; }
                     }
                 }
 #pragma unroll
