@@ -155,6 +155,12 @@ struct amr_handle {
     uint32_t n_head = 0;         // deferred blocks waiting in the head buffer
     bool zero_halo = true;
     bool dense_search = false;   // test hook (AMR_DENSE_SEARCH): always use the fallback search kernel
+    // the tail's gate kernel (submit): ticks of the 100 MHz clock it stays after it has seen the K1 launch's last workgroup
+    // start, for the other XCDs' dispatchers to place theirs (hook AMR_GATE_DELAY_TICKS); whether, in batches of several K1
+    // launches, it comes onto the chip behind the stop event of the round before the last (AMR_GATE_EVENT=0: as in round 4,
+    // as soon as the tail stream reaches it)
+    uint32_t gate_delay_ticks = 600;
+    bool gate_event = true;
     uint32_t k1_round_tiles = 0; // test hook AMR_K1_ROUND_TILES: wave-tiles per K1 launch (0: a chip's worth at BlockSize >= 4096, else one launch)
     uint64_t k1_coop_max = 0;    // batches of up to this many blocks run K1 as one wave per block throughout (k1_coop.h):
                                  // from kK1CoopMaxSamples / kK1CoopMaxBlocks; test hook AMR_K1_COOP_MAX (0: only the blocks

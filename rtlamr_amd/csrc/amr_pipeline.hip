@@ -109,22 +109,6 @@ amr_status ensure_capacity(amr_handle *h, Slot &s, Slot &other, size_t n_blocks)
 // same stream at once (enqueue_search; also every re-run after a capacity overflow) or later on the second stream
 // (pipelined callers: collect() launches it when the next batch's K1 has finished, so that it runs next to that
 // batch's K2 instead of in front of its K1).  `split`: K2 gets a stop event of its own for timing level 2.
-// ticks (100 MHz) the gate stays after it has seen the K1 launch's last workgroup start, for the other XCDs' dispatchers to
-// place theirs; developer hook AMR_GATE_DELAY_TICKS
-static uint32_t gate_delay_ticks()
-{
-    static const uint32_t t = [] { const char *e = getenv("AMR_GATE_DELAY_TICKS"); return e ? (uint32_t)atoi(e) : 600u; }();
-    return t;
-}
-
-// developer hook for A/B runs: AMR_GATE_EVENT=0 leaves the gate kernel where round 4 had it (resident as soon as the tail
-// stream reaches it)
-static bool getenv_off_gate_event(const amr_handle *)
-{
-    static const int off = [] { const char *e = getenv("AMR_GATE_EVENT"); return (e && e[0] == '0') ? 1 : 0; }();
-    return off != 0;
-}
-
 amr_status enqueue_k2(amr_handle *h, Slot &s, hipStream_t st, bool rerun, bool dense, bool split,
                       const amr::HistArgs *fold = nullptr, bool *folded = nullptr, bool early = false)
 {
@@ -409,7 +393,7 @@ amr_status submit(amr_handle *h, const uint8_t *d_iq, size_t n_blocks, bool sear
     // the gate is gone 6 us after the launch's last workgroup has started, a workgroup it displaced starts 7 us late, and
     // the search's end as a stop event costs more than that (1 us of the search, 2 us of the K1 behind it:
     // profiles/r05/k1_gate_fragmentation.txt).
-    const bool gate_ev = gate_prev && !getenv_off_gate_event(h);
+    const bool gate_ev = gate_prev && h->gate_event;
     hipEvent_t gate_wait = nullptr;
     if (all_coop) {
         amr::launch_k1_coop(h->geom.chip_length, 0u, (uint32_t)rows, st, k1_last, e0, e1);
@@ -450,7 +434,7 @@ amr_status submit(amr_handle *h, const uint8_t *d_iq, size_t n_blocks, bool sear
         // gate waits, as an event in front of it, for the end of what precedes the K1 launch it is about (gate_wait above):
         // by then the chip holds nothing but K1 waves (ranges at 0, 248 and 496), or nothing.
         if (gate_wait) HIP_TRY(hipStreamWaitEvent(h->tail_stream, gate_wait, 0));
-        hipLaunchKernelGGL(amr::k_gate, dim3(1), dim3(1), 0, h->tail_stream, h->d_k1_started, s.ticket, gate_delay_ticks(),
+        hipLaunchKernelGGL(amr::k_gate, dim3(1), dim3(1), 0, h->tail_stream, h->d_k1_started, s.ticket, h->gate_delay_ticks,
                            h->gate_timeout_ticks, prev.d_overflow);
         HIP_TRY(hipGetLastError());
         // (an early search ran on the search stream -- today the tail stream itself, then this wait is a no-op)

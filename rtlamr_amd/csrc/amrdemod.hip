@@ -146,6 +146,8 @@ amr_status amr_create(const amr_protocol *protos, int32_t n_protos, int32_t devi
     }
     h->k1_coop_max = std::min<uint64_t>(kK1CoopMaxBlocks, kK1CoopMaxSamples / (uint64_t)h->geom.block_size);
     if (const char *cm = getenv("AMR_K1_COOP_MAX")) h->k1_coop_max = strtoull(cm, nullptr, 10);   // test hook / A-B
+    if (const char *gd = getenv("AMR_GATE_DELAY_TICKS")) h->gate_delay_ticks = (uint32_t)strtoul(gd, nullptr, 10);   // A/B runs
+    if (const char *ge = getenv("AMR_GATE_EVENT")) h->gate_event = ge[0] != '0';
     if (const char *rt = getenv("AMR_K1_ROUND_TILES")) h->k1_round_tiles = (uint32_t)strtoul(rt, nullptr, 10);   // test hook: batches of several K1 launches at test sizes
     // NewMagLUT, decode.go:209-216: float32 divide then float32 square, two roundings per entry.
     for (int i = 0; i < 256; ++i) {
