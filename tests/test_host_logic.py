@@ -167,3 +167,27 @@ def test_message_records_have_the_reference_columns():
     w = R900(ID=1234, Unkn1=0xA3, NoUse=5, BackFlow=1, Consumption=99, Unkn3=2, Leak=3, LeakNow=0, checksum=b"\x01\x02")
     assert w.Record() == ["1234", "163", "5", "1", "99", "2", "3", "0"]
     assert str(w) == "{ID:      1234 Unkn1:0xA3 NoUse: 5 BackFlow:1 Consumption:      99 Unkn3:0x02 Leak: 3 LeakNow:0}"
+
+
+def test_k1_timeline_report_finds_late_workgroups(tmp_path):
+    """tools/k1_timeline_report.py (the diagnostic of profiles/r05/k1_gate_fragmentation.txt) on a synthetic dump: two launches per
+    batch, in every first one four workgroups of one XCC start 330 us late."""
+    import os, subprocess, sys
+    rows = []
+    t = 1_000_000
+    for launch in range(6):
+        for w in range(2048):
+            late = 33_000 if (launch % 2 == 0 and w in (2019, 2027, 2035, 2043)) else 0
+            st = t + (w % 8) * 3 + late
+            rows.append(f"{launch} {w} {st} {st + 38_000 + (0 if late else w % 50)} {w % 8} 0")
+        t += 41_000
+    p = tmp_path / "tl.txt"
+    p.write_text("# slot wg start end xcc hw\n" + "\n".join(rows) + "\n")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, os.path.join(root, "tools", "k1_timeline_report.py"), str(p), "2"], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, out.stderr
+    summary = [l for l in out.stdout.splitlines() if l.startswith("# launch ")]
+    assert len(summary) == 2
+    assert "late>2us 4" in summary[0] and "late>2us 0" in summary[1], summary
+    first = float(summary[0].split("span mean")[1].split()[0]); second = float(summary[1].split("span mean")[1].split()[0])
+    assert first > second + 300
