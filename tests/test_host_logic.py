@@ -186,7 +186,7 @@ def test_k1_timeline_report_finds_late_workgroups(tmp_path):
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     out = subprocess.run([sys.executable, os.path.join(root, "tools", "k1_timeline_report.py"), str(p), "2"], capture_output=True, text=True, timeout=120)
     assert out.returncode == 0, out.stderr
-    summary = [l for l in out.stdout.splitlines() if l.startswith("# launch ")]
+    summary = [l for l in out.stdout.splitlines() if l.startswith("# launch ") and " per batch:" in l]
     assert len(summary) == 2
     assert "late>2us 4" in summary[0] and "late>2us 0" in summary[1], summary
     first = float(summary[0].split("span mean")[1].split()[0]); second = float(summary[1].split("span mean")[1].split()[0])
