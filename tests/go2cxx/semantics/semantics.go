@@ -1,0 +1,293 @@
+// Package semantics: small Go programs whose results are fixed by the Go specification.  tests/test_go2cxx.py
+// translates this file with oracle/go2cxx, compiles the C++ and compares what every function returns with the value
+// the specification prescribes (written next to each function).  Nothing here resembles the rtlamr sources on
+// purpose: the point is that the translator handles the LANGUAGE, not one program.
+package semantics
+
+import (
+	"fmt"
+	"strconv"
+	"strings"
+	"sync"
+)
+
+// uint8 arithmetic wraps and never widens: (200+100)>>1 is 22 in uint8, 150 with C integer promotion.  Want "22 156 255 1".
+func Wrap() string {
+	var a, b uint8 = 200, 100
+	c := (a + b) >> 1
+	d := a - b - b - b // 200-300 mod 256 = 156
+	var z uint8
+	z--
+	var i8 int8 = 127
+	i8++ // -128
+	return fmt.Sprintf("%d %d %d %d", c, d, z, i8/-128)
+}
+
+// Shifts by >= width give 0 (or the sign), unlike C.  Want "0 -1 0 2147483648 1".
+func Shifts() string {
+	var u uint32 = 0x80000000
+	var s int32 = -5
+	n := uint(40)
+	a := u >> n
+	b := s >> n
+	c := u << n
+	var one uint64 = 1
+	return fmt.Sprintf("%d %d %d %d %d", a, b, c, one<<31, 1<<(n-40))
+}
+
+// Untyped constants take the type of the other operand; := gives int / float64.  Want "0.1 3 3.5 127.5 int".
+func Constants() string {
+	const k = 1
+	var f float32 = 0.1
+	g := f * k
+	x := 7 / 2   // integer division of constants
+	y := 7 / 2.0 // floating-point constant
+	var lut float32 = (127.5 - float32(0)) / 1
+	kind := "float"
+	if (k<<3)/3 == 2 {
+		kind = "int"
+	}
+	return fmt.Sprintf("%.1f %d %.1f %.1f %s", g, x, y, lut, kind)
+}
+
+// float32 accumulates in float32 (one rounding per operation).  Want "16777216 16777218".
+func Float32Sum() string {
+	var s float32 = 16777216
+	t := s + 1 // rounds back to 2^24
+	u := s + 2
+	return fmt.Sprintf("%.0f %.0f", t, u)
+}
+
+// Slices share their backing array until append outgrows the capacity.  Want "[9 2 3] [9 2] 3 [9 2 7] [9 2 3 4] 3".
+func SliceAliasing() string {
+	a := []int{1, 2, 3}
+	b := a[:2]
+	b[0] = 9
+	first := show(a) + " " + show(b) + " " + strconv.Itoa(cap(b))
+	c := append(b, 7) // fits: overwrites a[2]
+	second := show(a)
+	a[2] = 3
+	d := append(a, 4) // does not fit: new array
+	d[0] = 9
+	_ = c
+	return first + " " + second + " " + show(d) + " " + strconv.Itoa(len(a))
+}
+
+func show(s []int) string {
+	parts := make([]string, 0, len(s))
+	for _, v := range s {
+		parts = append(parts, strconv.Itoa(v))
+	}
+	return "[" + strings.Join(parts, " ") + "]"
+}
+
+// copy is a memmove; ranging evaluates the slice once; appends within capacity write the shared array.  Want "[1 1 2 0 0] 3".
+func CopyOverlap() string {
+	a := []int{1, 2, 3, 4, 5}
+	copy(a[1:], a)
+	n := 0
+	s := a[:3]
+	for range s {
+		s = append(s, 0)
+		n++
+	}
+	return show(a[:5]) + " " + strconv.Itoa(n)
+}
+
+// The list-swapping idiom: functions returning their arguments in another order, assigned crosswise.  Want "[2 4] [] 2".
+func keepEven(a, b []int) ([]int, []int) {
+	for _, v := range a {
+		if v%2 == 0 {
+			b = append(b, v)
+		}
+	}
+	return a, b
+}
+
+func SwapLists() string {
+	x := []int{1, 2, 3, 4}
+	y := make([]int, 0, 4)
+	y, x = keepEven(x, y[:0])
+	y = y[:0]
+	return show(x) + " " + show(y) + " " + strconv.Itoa(len(x))
+}
+
+// Value receivers work on a copy, pointer receivers on the object; arrays are values.  Want "1 2 [0 0] [5 0]".
+type counter struct {
+	n    int
+	arr  [2]int
+	tags []string
+}
+
+func (c counter) bumpCopy()  { c.n++; c.arr[0] = 5 }
+func (c *counter) bumpReal() { c.n++; c.arr[0] = 5 }
+
+func Receivers() string {
+	var c counter
+	c.n = 1
+	c.bumpCopy()
+	first := c.n
+	before := c.arr
+	c.bumpReal()
+	return fmt.Sprintf("%d %d [%d %d] [%d %d]", first, c.n, before[0], before[1], c.arr[0], c.arr[1])
+}
+
+// Interfaces hold values or pointers; a map of slices appends through the zero value.  Want "sq:9 ci:12 a=2 b=1 c=0 true false".
+type shape interface {
+	Area() int
+	Name() string
+}
+type square struct{ s int }
+type circle struct{ r int }
+
+func (q square) Area() int    { return q.s * q.s }
+func (q square) Name() string { return "sq" }
+func (c *circle) Area() int   { return 3 * c.r * c.r }
+func (c *circle) Name() string { return "ci" }
+
+func Interfaces() string {
+	shapes := []shape{square{3}, &circle{2}}
+	out := ""
+	for _, s := range shapes {
+		out += s.Name() + ":" + strconv.Itoa(s.Area()) + " "
+	}
+	groups := make(map[string][]int)
+	groups["a"] = append(groups["a"], 1)
+	groups["a"] = append(groups["a"], 2)
+	groups["b"] = append(groups["b"], 3)
+	_, okA := groups["a"]
+	_, okZ := groups["z"]
+	var nilShape shape
+	_ = nilShape == nil
+	return out + fmt.Sprintf("a=%d b=%d c=%d %t %t", len(groups["a"]), len(groups["b"]), len(groups["c"]), okA, okZ)
+}
+
+// Strings are bytes; range decodes UTF-8; conversion from []byte copies.  Want "4 3 195 0:104 1:233 3:33 hx hé!".
+func Strings() string {
+	s := "hé!"
+	b := []byte(s)
+	n := 0
+	out := ""
+	for i, r := range s {
+		out += fmt.Sprintf("%d:%d ", i, r)
+		n++
+	}
+	b[1] = 'x'
+	t := string(b[:2])
+	return fmt.Sprintf("%d %d %d %s%s %s", len(s), n, s[1], out, t, s)
+}
+
+// Labelled break / continue, switch without fallthrough, break inside switch inside for.  Want "1,3 2,3 x one many many done".
+func Control() string {
+	out := ""
+outer:
+	for i := 1; i < 4; i++ {
+		for j := 1; j < 4; j++ {
+			if j < 3 {
+				continue
+			}
+			if i == 3 {
+				break outer
+			}
+			out += fmt.Sprintf("%d,%d ", i, j)
+			continue outer
+		}
+	}
+	out += "x "
+	for i := 1; i <= 3; i++ {
+		switch {
+		case i == 1:
+			out += "one "
+		default:
+			if i > 3 {
+				break
+			}
+			out += "many "
+		}
+	}
+	switch out[0] {
+	case 'z', '1':
+		out += "done"
+	default:
+		out += "no"
+	}
+	return out
+}
+
+// Named results, defer order, closures capturing by value what they read.  Want "3 cba 10".
+func named(a int) (r int, log string) {
+	r = a
+	for _, c := range []string{"a", "b", "c"} {
+		c := c
+		defer func() { trace += c }()
+	}
+	r += 2
+	return
+}
+
+var trace string
+
+func Defers() string {
+	trace = ""
+	r, _ := named(1)
+	add := func(x int) func(int) int { return func(y int) int { return x + y } }
+	return fmt.Sprintf("%d %s %d", r, trace, add(3)(7))
+}
+
+// Goroutines, an unbuffered channel closed by a WaitGroup waiter, range over the channel.  Want "285 10".
+func Channels() string {
+	ch := make(chan int)
+	wg := new(sync.WaitGroup)
+	wg.Add(10)
+	for i := 0; i < 10; i++ {
+		go func(k int) {
+			ch <- k * k
+			wg.Done()
+		}(i)
+	}
+	go func() {
+		wg.Wait()
+		close(ch)
+	}()
+	sum, n := 0, 0
+	for v := range ch {
+		sum += v
+		n++
+	}
+	return fmt.Sprintf("%d %d", sum, n)
+}
+
+// Generic function with a type-parameter list; integer parsing in odd bases; %b / %x / %q verbs.  Want "2.5 7 15 00101 ff \"a\\\"b\" 44".
+func absOf[F float32 | float64 | int](x F) F {
+	if x < 0 {
+		return -x
+	}
+	return x
+}
+
+func Formats() string {
+	v, _ := strconv.ParseInt("23", 6, 32)
+	_, err := strconv.ParseUint("19", 8, 8)
+	bad := 0
+	if err != nil {
+		bad = 44
+	}
+	return fmt.Sprintf("%.1f %d %d %05b %x %q %d", absOf(float32(-2.5)), absOf(-7), v, 5, 255, "a\"b", bad)
+}
+
+// Struct literals (keyed, positional, nested, pointer), struct copies, arrays of structs.  Want "7 0 9 [1 2] 3 8".
+type inner struct{ a, b int }
+type outer struct {
+	in  inner
+	p   *inner
+	arr [2]inner
+}
+
+func Structs() string {
+	o := outer{in: inner{a: 7}, p: &inner{9, 1}}
+	o.arr[1] = inner{1, 2}
+	cp := o
+	cp.in.a = 3
+	cp.p.b = 8 // shared through the pointer
+	return fmt.Sprintf("%d %d %d [%d %d] %d %d", o.in.a, o.in.b, o.p.a, o.arr[1].a, o.arr[1].b, cp.in.a, o.p.b)
+}
