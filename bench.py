@@ -322,6 +322,34 @@ def sharded_gather_check(ra, shard, wl, local_rank, rank, world, n_blocks=256):
         dec.close()
 
 
+def device_state(index: int) -> dict:
+    """What the box's management interface says about device `index` right now: current shader / memory / fabric clocks,
+    socket power and its cap, performance level, compute / memory partition mode (rocm-smi --json).  Recorded before and
+    after the timed region -- never inside it -- so that a slow line can be told from a regression:
+    the same binary measured 0.62 ... 0.72 of the roofline on different boxes of the pool."""
+    import subprocess
+    try:
+        r = subprocess.run(["rocm-smi", "-d", str(index), "--showclocks", "--showpower", "--showmaxpower", "--showperflevel",
+                            "--showcomputepartition", "--showmemorypartition", "--json"], capture_output=True, text=True, timeout=30)
+        cards = json.loads(r.stdout[r.stdout.index("{"):])
+        card = cards.get(f"card{index}") or next(iter(cards.values()))
+        keep = {}
+        for k, v in card.items():
+            kl = k.lower()
+            if any(t in kl for t in ("sclk", "mclk", "fclk", "socclk", "power", "partition", "performance level")):
+                keep[k] = v
+        return keep
+    except Exception as e:   # noqa: BLE001 -- a missing tool must not fail the bench
+        return {"unavailable": f"{type(e).__name__}: {str(e)[:120]}"}
+
+
+def n_cus_of(describe: str):
+    """compute units from amr_describe's line ("... gfx950:sramecc+:xnack- 256 CUs clock ...")."""
+    import re
+    m = re.search(r"(\d+) CUs", describe)
+    return int(m.group(1)) if m else None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -586,6 +614,12 @@ def main():
     # for search_ms); measured: on every step 2 % of the step, on every 4th 0.5 %, the averages are the same.
     warm = run(max(args.warmup, 1), 2) if args.warmup else []
     sync_all()
+    state_before = device_state(local_rank) if rank == 0 else None     # ~0.5 s of rocm-smi, outside the timed region
+    sync_all()                           # (the other ranks wait for rank 0's snapshot)
+    run(2, 0, 0)                         # the snapshot idled the device for a moment: two untimed steps bring the clocks back
+    if distributed:
+        gatherer.wait()
+    sync_all()
     c0, r0 = gstat["consumed"], gstat["records"]
     t0 = time.perf_counter()
     res = run(args.steps, 2, args.k1_events)
@@ -593,6 +627,7 @@ def main():
         gatherer.wait()
     sync_all()
     dt = time.perf_counter() - t0
+    state_after = device_state(local_rank) if rank == 0 else None
     consumed_timed, records_timed = gstat["consumed"] - c0, gstat["records"] - r0
     tms = [t for _, t in res if t is not None] or [t for _, t in warm]
     demod_ms = [t["demod_ms"] for t in tms] or [float("nan")]
@@ -700,6 +735,10 @@ def main():
                                            "fill its ragged end and the start of that batch's K2; steady_ms_per_step - k1_ms is "
                                            "everything a step costs besides K1)"),
                          "algorithmic_bytes_per_launch": alg_bytes},
+            # the box this line was measured on (the pool's boxes differ by +-7 % with one binary: profiles/r05/fresh_runs*.txt)
+            "device": {"library": dec.describe(), "compute_units": n_cus_of(dec.describe()),
+                       "xcds": (n_cus_of(dec.describe()) or 0) // 32 or None,
+                       "before_timed_region": state_before, "after_timed_region": state_after},
         }
         if distributed:
             # what amr_gather_hits put on the wire for the last step: small slots (validated hits) whole, large ones as a

@@ -80,10 +80,9 @@ typedef struct amr_geometry {
  *                 every bit of it: when PacketSymbols%8 != 0 (r900 alone or with
  *                 scm) Go never clears the high bits of the last byte, which then
  *                 hold symbols of the hits sliced before -- reproduced here in the
- *                 order call, preamble id, idx, across calls and batches.  (A
- *                 shard primed with amr_prime starts that chain from zero, like a
- *                 fresh Decoder: its first hit's stale bits are the one thing a
- *                 block-range split cannot know.)
+ *                 order call, preamble id, idx, across calls and batches, and across
+ *                 shards when the caller hands the byte on (amr_get_stale_carry /
+ *                 amr_set_stale_carry below).
  */
 typedef struct amr_result {
     uint32_t n_preambles;
@@ -264,6 +263,20 @@ amr_status amr_result_device(const amr_handle *h, const void **d_packed, uint64_
  * at the aligned-halo bytes (amr_halo_bytes) that precede it in the stream.
  */
 amr_status amr_prime(amr_handle *h, const uint8_t *lead, const uint8_t *halo_iq, size_t n_blocks, int on_device);
+/*
+ * The one piece of Decoder state a block-range split cannot rebuild from the blocks in front of a shard: d.pkt, which
+ * Decoder.Slice (decode.go:353-375) never clears.  With PacketSymbols % 8 = r != 0 (r900 alone or with scm: r = 4) the
+ * last byte of a packet holds, above its r fresh bits, bits of the hits sliced before it -- possibly found long before
+ * the shard begins.  amr_get_stale_carry returns the last byte of the last hit this decoder has sliced so far (0 for a
+ * fresh one); amr_set_stale_carry makes it the predecessor of the next batch's first hit.  A caller that runs its shards
+ * one after another passes the byte from shard r-1 to shard r (after amr_prime) and gets the single decoder's bytes,
+ * every bit.  Shards that run at the same time cannot know it in advance: they start from zero and the caller patches
+ * afterwards -- only the first ceil(8/r) - 1 hits of a shard (in slicing order: call, preamble id, idx) are affected,
+ * hit i of them by   last_byte |= (carry << (r * (i + 1))) & 0xff   (rtlamr_amd/dist.py: patch_stale_carry).
+ * No batch may be in flight.  With PacketSymbols % 8 == 0 the byte is never used.
+ */
+amr_status amr_get_stale_carry(amr_handle *h, uint8_t *last_byte);
+amr_status amr_set_stale_carry(amr_handle *h, uint8_t last_byte);
 size_t amr_halo_bytes(const amr_handle *h);
 size_t amr_prime_blocks(const amr_handle *h);
 

@@ -141,6 +141,8 @@ struct amr_handle {
     uint64_t *d_k1_started = nullptr;  // device word: ticket of the last batch whose K1 has all its waves on the chip (k_gate)
     uint64_t gate_timeout_ticks = 400000000ull;   // k_gate gives up after this many 100 MHz ticks (4 s; test hook AMR_GATE_TIMEOUT_US)
     uint64_t gate_timeouts = 0;   // batches searched again because their gate gave up (amr_describe)
+    uint64_t researches = 0;      // batches searched again at collect, for any reason (amr_describe)
+    uint64_t stale_reruns = 0;    // batches whose k_stale_bits pass alone ran again behind an older batch's re-search
     uint64_t *h_flags = nullptr;  // pinned: [0] ticket of the last batch whose search has started, [1] whose stream-A part is done
     bool timing_valid = false;
     amr_timing timing{};

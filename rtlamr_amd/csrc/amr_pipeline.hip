@@ -109,6 +109,19 @@ amr_status ensure_capacity(amr_handle *h, Slot &s, Slot &other, size_t n_blocks)
 // same stream at once (enqueue_search; also every re-run after a capacity overflow) or later on the second stream
 // (pipelined callers: collect() launches it when the next batch's K1 has finished, so that it runs next to that
 // batch's K2 instead of in front of its K1).  `split`: K2 gets a stop event of its own for timing level 2.
+// The bits Decoder.Slice never clears in a last byte of fewer than 8 symbols (k3_stale.h), for the hits of slot s.
+amr_status enqueue_stale(amr_handle *h, Slot &s, hipStream_t st)
+{
+    amr::StaleArgs sa{};
+    sa.out = s.d_out; sa.offs_pre = s.d_offs_pre; sa.overflow = s.d_overflow; sa.cap = s.out_cap;
+    sa.carry_in = h->d_pkt_carry + s.carry_in_slot; sa.carry_out = h->d_pkt_carry + (&s - h->slot);
+    sa.n_pre = h->sg.n_pre; sa.pkt_bytes = h->sg.pkt_bytes; sa.r = h->sg.packet_symbols & 7u;
+    hipLaunchKernelGGL(amr::k_stale_bits, dim3((unsigned)((s.out_cap + 255) / 256)), dim3(256), 0, st, sa);
+    HIP_TRY(hipGetLastError());
+    AMR_DBG(st, "k_stale_bits");
+    return AMR_OK;
+}
+
 amr_status enqueue_k2(amr_handle *h, Slot &s, hipStream_t st, bool rerun, bool dense, bool split,
                       const amr::HistArgs *fold = nullptr, bool *folded = nullptr, bool early = false)
 {
@@ -217,15 +230,7 @@ amr_status enqueue_tail(amr_handle *h, Slot &s, hipStream_t st, bool split)
     hipExtLaunchKernelGGL(amr::k3_slice_words, dim3(s.n_tiles - k3.fold, n_pre), dim3(256), k3lds, st, k3e0, k3e1, 0, k3);
     HIP_TRY(hipGetLastError());
     AMR_DBG(st, "k3_slice");
-    if (h->sg.packet_symbols & 7u) {   // the bits Decoder.Slice never clears in a last byte of fewer than 8 symbols (k3_stale.h)
-        amr::StaleArgs sa{};
-        sa.out = s.d_out; sa.offs_pre = s.d_offs_pre; sa.overflow = s.d_overflow; sa.cap = s.out_cap;
-        sa.carry_in = h->d_pkt_carry + s.carry_in_slot; sa.carry_out = h->d_pkt_carry + (&s - h->slot);
-        sa.n_pre = n_pre; sa.pkt_bytes = h->sg.pkt_bytes; sa.r = h->sg.packet_symbols & 7u;
-        hipLaunchKernelGGL(amr::k_stale_bits, dim3((unsigned)((s.out_cap + 255) / 256)), dim3(256), 0, st, sa);
-        HIP_TRY(hipGetLastError());
-        AMR_DBG(st, "k_stale_bits");
-    }
+    if (h->sg.packet_symbols & 7u) AMR_TRY(enqueue_stale(h, s, st));
     if (h->r900_pid >= 0) {
         amr::K4Args k4{};
         k4.iq = s.d_iq; k4.hist = h->d_iqhist[s.iqhist_buf]; k4.lut = h->d_lut; k4.out_packed = s.d_out;
@@ -716,6 +721,7 @@ amr_status collect(amr_handle *h, amr_result *res)
     if (h->n_pending == 1) h->lazy_tail = false;   // nothing else in flight: the caller is not pipelining (any more)
     uint64_t total = 0, searched = 0;
     bool use_dense = s.dense;
+    bool stale_redone = false;    // the result on the device is newer than what a one-launch batch wrote to its pinned mirror
     if (s.search) {
         bool searched_again = false;
         for (int attempt = 0;; ++attempt) {
@@ -723,9 +729,6 @@ amr_status collect(amr_handle *h, amr_result *res)
             total = s.h_off[n_pre];
             if (attempt > 8) return fail(AMR_EOVERFLOW, "hit capacity could not be grown");
             bool rerun = false;
-            // an older batch was searched again after this one's tail had run: the byte its last hit hands on (k3_stale.h) was
-            // not there yet -- this batch's tail once more, on the compute stream, behind that re-search
-            if (s.force_rerun && attempt == 0) rerun = true;
             // sparse hit list overflowed (e.g. the zero history of a fresh stream matches r900's 16 leading zeros):
             // this batch is searched again with the dense kernel; the next one starts sparse again unless
             // overflows keep coming
@@ -761,10 +764,29 @@ amr_status collect(amr_handle *h, amr_result *res)
             AMR_TRY(sync_compute(h));
             searched_again = true;
         }
+        // k3_stale.h across batches in flight.  A batch that was searched again wrote its carry byte (the last byte of its
+        // last hit) only now; a younger batch whose tail had ALREADY been enqueued read the byte before that.  Such a batch
+        // gets k_stale_bits alone once more when it is collected (the pass is idempotent: it only reads the fresh low bits),
+        // on the compute stream behind the re-search -- not a second search -- and hands the duty on only if its own carry
+        // byte really changed.  Batches whose tail is not enqueued yet read the corrected byte anyway.
+        bool carry_changed = searched_again;
+        if (s.force_rerun && !searched_again) {
+            uint8_t before = 0, after = 0;
+            uint8_t *cb = h->d_pkt_carry + (&s - h->slot);
+            AMR_TRY(sync_compute(h));
+            HIP_TRY(hipMemcpy(&before, cb, 1, hipMemcpyDeviceToHost));
+            AMR_TRY(enqueue_stale(h, s, h->stream));
+            AMR_TRY(sync_compute(h));
+            HIP_TRY(hipMemcpy(&after, cb, 1, hipMemcpyDeviceToHost));
+            carry_changed = before != after;
+            stale_redone = true;
+            h->stale_reruns++;
+        }
+        if (searched_again) h->researches++;
         s.force_rerun = false;
-        if (searched_again && (h->sg.packet_symbols & 7u))
+        if (carry_changed && (h->sg.packet_symbols & 7u))
             for (Slot &o : h->slot)
-                if (&o != &s && o.pending && o.search) o.force_rerun = true;
+                if (&o != &s && o.pending && o.search && o.tail_enqueued) o.force_rerun = true;
         if (use_dense && !s.dense) {
             if (++h->dense_streak >= 4) { h->dense_hold = 32; h->dense_streak = 0; }
         } else if (!use_dense) {
@@ -779,7 +801,7 @@ amr_status collect(amr_handle *h, amr_result *res)
             s.host_cap = nc;
         }
         // (the one-launch path for a single block wrote the pinned mirror itself, k1_single.h)
-        if (total && !(s.single && !searched_again)) {   // on the copy stream: overlaps the next batch's kernels
+        if (total && !(s.single && !searched_again && !stale_redone)) {   // on the copy stream: overlaps the next batch's kernels
             HIP_TRY(hipMemcpyAsync(s.h_out, h->validate ? s.d_val : s.d_out, total * (12 + h->sg.pkt_bytes),
                                    hipMemcpyDeviceToHost, h->copy_stream));
             if (h->r900_pid >= 0) {
@@ -1063,6 +1085,27 @@ amr_status amr_prime(amr_handle *h, const uint8_t *lead, const uint8_t *halo_iq,
     }
     AMR_TRY(submit(h, src, n_blocks, false));
     return collect(h, nullptr);
+}
+
+// The byte Decoder.Slice's never-cleared d.pkt carries from one hit to the next (k3_stale.h), across a shard boundary.
+amr_status amr_get_stale_carry(amr_handle *h, uint8_t *last_byte)
+{
+    if (!h || !last_byte) return fail(AMR_EINVAL, "null argument");
+    if (h->n_pending) return fail(AMR_EINVAL, "amr_get_stale_carry: batches in flight: collect them first");
+    HIP_TRY(hipSetDevice(h->device));
+    AMR_TRY(drain(h));
+    HIP_TRY(hipMemcpy(last_byte, h->d_pkt_carry + h->carry_slot, 1, hipMemcpyDeviceToHost));
+    return AMR_OK;
+}
+
+amr_status amr_set_stale_carry(amr_handle *h, uint8_t last_byte)
+{
+    if (!h) return fail(AMR_EINVAL, "null argument");
+    if (h->n_pending) return fail(AMR_EINVAL, "amr_set_stale_carry: batches in flight: collect them first");
+    HIP_TRY(hipSetDevice(h->device));
+    AMR_TRY(drain(h));
+    HIP_TRY(hipMemcpy(h->d_pkt_carry + h->carry_slot, &last_byte, 1, hipMemcpyHostToDevice));
+    return AMR_OK;
 }
 
 amr_status amr_copy_quantized(amr_handle *h, uint8_t *out, size_t out_bytes)

@@ -429,7 +429,10 @@ amr_status amr_describe(const amr_handle *h, char *buf, size_t buf_bytes)
             n += snprintf(buf + n, buf_bytes - (size_t)n, " | K1 %s |", name);
     }
     if (h->gate_timeouts && n > 0 && (size_t)n < buf_bytes)
-        snprintf(buf + n, buf_bytes - (size_t)n, " gate-timeouts %llu", (unsigned long long)h->gate_timeouts);
+        n += snprintf(buf + n, buf_bytes - (size_t)n, " gate-timeouts %llu", (unsigned long long)h->gate_timeouts);
+    if ((h->researches || h->stale_reruns) && n > 0 && (size_t)n < buf_bytes)
+        snprintf(buf + n, buf_bytes - (size_t)n, " re-searches %llu stale-reruns %llu", (unsigned long long)h->researches,
+                 (unsigned long long)h->stale_reruns);
     return AMR_OK;
 }
 

@@ -31,6 +31,23 @@ def prime_range(k0: int, prime_blocks: int) -> Tuple[int, int]:
     return p0, k0
 
 
+def patch_stale_carry(rows: np.ndarray, pkt: np.ndarray, packet_symbols: int, carry: int) -> np.ndarray:
+    """Packet bytes of a shard that was decoded AT THE SAME TIME as the shard before it (so its decoder started from a zero
+    d.pkt, amr_prime) made equal to the single decoder's: `carry` = last byte of the last hit the preceding shards
+    sliced (Decoder.stale_carry() of shard r-1, itself patched).  Decoder.Slice never clears d.pkt (decode.go:363-366): with
+    r = PacketSymbols % 8 != 0 the last byte of hit i (0-based, in slicing order: call, preamble id, idx) still holds
+    carry << r*(i+1) above the bits the shard itself put there.  rows int64[n,3] = (preamble id, call, idx) in any order;
+    returns a patched copy of pkt (same order)."""
+    r = packet_symbols % 8
+    out = np.array(pkt, np.uint8, copy=True)
+    if r == 0 or carry == 0 or len(rows) == 0:
+        return out
+    order = np.lexsort((rows[:, 2], rows[:, 0], rows[:, 1]))          # slicing order: call, preamble id, idx
+    for i, j in enumerate(order[: (8 + r - 1) // r - 1]):
+        out[j, -1] |= (carry << (r * (i + 1))) & 0xFF
+    return out
+
+
 def pack_hits(hits: np.ndarray, cap: int) -> np.ndarray:
     """hits int64[n,3] -> int64[cap,3] padded with -1."""
     out = np.full((cap, 3), -1, np.int64)

@@ -91,7 +91,9 @@ def _netidm(m) -> Tuple[List[str], str]:
         ("SerialNumberCRC", _hx(m.SerialNumberCRC, 4), None), ("PacketCRC", _hx(m.PacketCRC, 4), None)])
 
 
-_BY_TYPE: Dict[str, Callable] = {"SCM": _scm, "SCM+": _scmplus, "IDM": _idm, "NetIDM": _netidm, "R900": _r900}
+# R900BCD embeds r900.R900 (r900bcd/r900bcd.go:39-41): Record() and String() are R900's, promoted
+_BY_TYPE: Dict[str, Callable] = {"SCM": _scm, "SCM+": _scmplus, "IDM": _idm, "NetIDM": _netidm, "R900": _r900,
+                                 "R900BCD": _r900}
 
 
 def _generic(m) -> Tuple[List[str], str]:

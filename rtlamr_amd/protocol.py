@@ -502,6 +502,17 @@ class Decoder:
         _lib.check(_lib.lib().amr_prime(self._require(), C.c_void_p(d_lead) if d_lead else None,
                                         C.c_void_p(d_halo), n_blocks, 1), "amr_prime")
 
+    def stale_carry(self) -> int:
+        """Last byte of the last hit sliced so far: what Decoder.Slice's never-cleared d.pkt hands to the next hit
+        (decode.go:363-366; matters when PacketSymbols % 8 != 0).  amr_get_stale_carry."""
+        b = C.c_uint8(0)
+        _lib.check(_lib.lib().amr_get_stale_carry(self._require(), C.byref(b)), "amr_get_stale_carry")
+        return int(b.value)
+
+    def set_stale_carry(self, last_byte: int) -> None:
+        """Continue another decoder's d.pkt: the next batch's first hit is sliced on top of `last_byte` (after prime())."""
+        _lib.check(_lib.lib().amr_set_stale_carry(self._require(), int(last_byte) & 0xFF), "amr_set_stale_carry")
+
     def reset(self) -> None:
         _lib.check(_lib.lib().amr_reset(self._require()), "amr_reset")
         self._calls = 0

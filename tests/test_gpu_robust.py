@@ -111,3 +111,125 @@ def test_batches_of_several_k1_launches(protos, chip, env):
     assert {k: got[k] for k in want} == want, f"{env}: other hits than the oracle's"
     assert ("gate-timeouts" in got["describe"]) == ("AMR_GATE_TIMEOUT_US" in env)
     assert got["seconds"] < 2.0, f"the pipelined part took {got['seconds']:.2f} s: a device-side wait ran into its time-out"
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("protos,depth", [(["r900"], 3), (["scm", "r900"], 3), (["r900"], 2)])
+def test_pipelined_r900_searches_every_batch_once(protos, depth):
+    """ADVICE r05 (amr_pipeline.hip collect): with PacketSymbols % 8 != 0 a re-search of one batch (a fresh r900 stream
+    overflows its first batch's sparse list: the zero history matches the preamble's 16 leading zeros) used to mark every
+    other batch in flight for a full second search, which marked the next ones, for the rest of the stream.  Now a younger
+    batch whose tail had already run gets k_stale_bits alone once more, and hands the duty on only when its carry byte
+    changed.  Every byte equals the oracle's, and the counters of amr_describe stay small over 40 pipelined batches."""
+    import ctypes as C
+    import re
+    from rtlamr_amd import _lib, synth
+    from rtlamr_amd.parsers import r900 as pr900
+    from oracle.oracle import PROTOCOLS
+    L = _lib.lib()
+    chip = 72
+    dec = util.make_decoder(protos, chip)
+    bufs = []
+    try:
+        bs, bs2 = dec.Cfg.BlockSize, dec.Cfg.BlockSize2
+        n_batches, nb = 40, 64
+        iq, _ = util.synth_stream(["scm"], chip, n_batches * nb, bs, seed=77, n_packets=30, edge_every=3)
+        for j in range(12):            # r900 bursts all along the stream: hits (and carry bytes) in most batches
+            chips = synth.r900_chips(PROTOCOLS["r900"][0], pr900.build_r900_symbols(1000 + j, consumption=j))
+            synth.plant_chips(iq, (3 + 200 * j) * bs + 31 * j, chips, chip, 34, -29)
+        want = util.oracle_run(protos, chip, iq)
+        got, inflight = [], 0
+        for k in range(n_batches):
+            part = np.ascontiguousarray(iq[k * nb * bs2:(k + 1) * nb * bs2])
+            d = C.c_void_p()
+            _lib.check(L.amr_dev_alloc(0, part.size, C.byref(d)), "alloc")
+            _lib.check(L.amr_dev_upload(0, d, part.ctypes.data, part.size), "upload")
+            bufs.append(d)
+            dec.submit_device(d.value, nb)
+            inflight += 1
+            if inflight == depth:
+                got.append(dec.collect()); inflight -= 1
+        while inflight:
+            got.append(dec.collect()); inflight -= 1
+        hs, ps = [], []
+        for br in got:
+            for pid in range(dec.n_preambles):
+                blk, idx, pk = br.for_preamble(pid)
+                hs.append(np.stack([np.full(len(blk), pid, np.int64), blk.astype(np.int64), idx.astype(np.int64)], axis=1))
+                ps.append(pk)
+        h, p = np.concatenate(hs), np.concatenate(ps)
+        order = np.lexsort((h[:, 2], h[:, 1], h[:, 0]))
+        assert np.array_equal(h[order], want[2]) and len(h) > 200
+        assert np.array_equal(p[order], want[3]), "packet bytes (stale high bits included) differ from the oracle's"
+        m = re.search(r"re-searches (\d+) stale-reruns (\d+)", dec.describe())
+        researches, stale = (int(m.group(1)), int(m.group(2))) if m else (0, 0)
+        assert researches <= 3, f"{researches} of {n_batches} pipelined batches were searched twice"
+        assert stale <= 2 * researches + 2, f"{stale} stale-bit passes re-run for {researches} re-searches"
+    finally:
+        dec.close()
+        for d in bufs:
+            L.amr_dev_free(0, d)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("protos,chip", [(["r900"], 72), (["scm", "r900"], 32)])
+def test_sharded_run_equals_single_decoder_every_byte(protos, chip):
+    """the last asterisk on "bit-exact bytes".  A block-range shard primed with amr_prime cannot know the
+    byte Decoder.Slice's never-cleared d.pkt carries into its first hit (decode.go:363-366, PacketSymbols % 8 = 4 here).
+    (a) shards run one after another hand it on with amr_get_stale_carry / amr_set_stale_carry; (b) shards run at the
+    same time start from zero and are patched afterwards (dist.patch_stale_carry).  Both: every byte of every packet
+    equals the single decoder's, i.e. the oracle's."""
+    from rtlamr_amd import dist as shard
+    from rtlamr_amd import synth
+    from rtlamr_amd.parsers import r900 as pr900
+    from oracle.oracle import PROTOCOLS
+    probe = util.make_decoder(protos, chip)
+    bs, bs2, ps = probe.Cfg.BlockSize, probe.Cfg.BlockSize2, probe.Cfg.PacketSymbols
+    pb, hb = probe.prime_blocks(), probe.halo_bytes()
+    probe.close()
+    n_blocks, world = 256, 4
+    iq, _ = util.synth_stream(["scm"], chip, n_blocks, bs, seed=19, n_packets=10, edge_every=2)
+    for j in range(6):
+        chips = synth.r900_chips(PROTOCOLS["r900"][0], pr900.build_r900_symbols(500 + j, consumption=j))
+        synth.plant_chips(iq, (9 + 40 * j) * bs + 13 * j, chips, chip, 34, -29)
+    want = util.oracle_run(protos, chip, iq)
+    assert (want[3][:, -1] & 0xF0).any()
+
+    def run_shard(r, carry_in):
+        k0, k1 = shard.shard_range(n_blocks, world, r)
+        p0, _ = shard.prime_range(k0, pb)
+        dec = util.make_decoder(protos, chip)
+        try:
+            if k0 > 0:
+                lead = iq[p0 * bs2 - hb:p0 * bs2] if p0 * bs2 >= hb else None
+                dec.prime(iq[p0 * bs2:k0 * bs2], lead)
+            dec.set_block_base(k0)
+            if carry_in is not None:
+                dec.set_stale_carry(carry_in)
+            q, h, p = util.gpu_run(dec, iq[k0 * bs2:k1 * bs2])
+            return h, p, dec.stale_carry()
+        finally:
+            dec.close()
+
+    # (a) sequential hand-over
+    hs, ps_, carry = [], [], 0
+    for r in range(world):
+        h, p, carry = run_shard(r, carry)
+        hs.append(h); ps_.append(p)
+    h, p = np.concatenate(hs), np.concatenate(ps_)
+    order = np.lexsort((h[:, 2], h[:, 1], h[:, 0]))
+    assert np.array_equal(h[order], want[2]) and np.array_equal(p[order], want[3])
+    # (b) concurrent shards (zero start), patched afterwards in shard order
+    hs, ps_, carry, differed = [], [], 0, False
+    for r in range(world):
+        h, p, own = run_shard(r, None)
+        fixed = shard.patch_stale_carry(h, p, ps, carry)
+        differed |= not np.array_equal(fixed, p)
+        if len(h):                                    # what this shard hands on: its last hit's byte, patched
+            last = np.lexsort((h[:, 2], h[:, 0], h[:, 1]))[-1]
+            carry = int(fixed[last, -1])
+        hs.append(h); ps_.append(fixed)
+    h, p = np.concatenate(hs), np.concatenate(ps_)
+    order = np.lexsort((h[:, 2], h[:, 1], h[:, 0]))
+    assert np.array_equal(h[order], want[2]) and np.array_equal(p[order], want[3])
+    assert differed, "no shard boundary carried a stale bit: the test tests nothing"

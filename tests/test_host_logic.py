@@ -167,6 +167,9 @@ def test_message_records_have_the_reference_columns():
     w = R900(ID=1234, Unkn1=0xA3, NoUse=5, BackFlow=1, Consumption=99, Unkn3=2, Leak=3, LeakNow=0, checksum=b"\x01\x02")
     assert w.Record() == ["1234", "163", "5", "1", "99", "2", "3", "0"]
     assert str(w) == "{ID:      1234 Unkn1:0xA3 NoUse: 5 BackFlow:1 Consumption:      99 Unkn3:0x02 Leak: 3 LeakNow:0}"
+    from rtlamr_amd.parsers.r900 import R900BCD
+    b = R900BCD(ID=1234, Unkn1=0xA3, NoUse=5, BackFlow=1, Consumption=99, Unkn3=2, Leak=3, LeakNow=0, checksum=b"\x01\x02")
+    assert b.MsgType() == "R900BCD" and b.Record() == w.Record() and str(b) == str(w)     # r900bcd.go:39-45: embedded R900
 
 
 def test_k1_timeline_report_finds_late_workgroups(tmp_path):
@@ -191,3 +194,30 @@ def test_k1_timeline_report_finds_late_workgroups(tmp_path):
     assert "late>2us 4" in summary[0] and "late>2us 0" in summary[1], summary
     first = float(summary[0].split("span mean")[1].split()[0]); second = float(summary[1].split("span mean")[1].split()[0])
     assert first > second + 300
+
+
+def test_patch_stale_carry_rule():
+    """dist.patch_stale_carry against a literal replay of Decoder.Slice's d.pkt (decode.go:363-366) over two shards."""
+    from rtlamr_amd import dist as shard
+    rng = np.random.default_rng(4)
+    for psym in (116, 117, 99, 96):
+        r, nb = psym % 8, (psym + 7) // 8
+        n = 9
+        bits = rng.integers(0, 2, (n, psym), dtype=np.uint8)
+        rows = np.stack([rng.integers(0, 2, n), np.sort(rng.integers(0, 5, n)), rng.integers(0, 4096, n)], axis=1).astype(np.int64)
+        order = np.lexsort((rows[:, 2], rows[:, 0], rows[:, 1]))
+
+        def slice_all(idxs, pkt):
+            out = {}
+            for j in idxs:
+                for p in range(psym):
+                    pkt[p >> 3] = ((pkt[p >> 3] << 1) | bits[j, p]) & 0xFF
+                out[j] = pkt.copy()
+            return out
+        whole = slice_all(order, np.zeros(nb, np.int64))
+        first, second = order[:4], order[4:]
+        a = slice_all(first, np.zeros(nb, np.int64))
+        b = slice_all(second, np.zeros(nb, np.int64))                 # a concurrent shard: zero start
+        pk = np.array([b[j] for j in second], np.uint8)
+        fixed = shard.patch_stale_carry(rows[second], pk, psym, int(a[first[-1]][-1]))
+        assert np.array_equal(fixed, np.array([whole[j] for j in second], np.uint8)), psym
