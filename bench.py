@@ -322,24 +322,67 @@ def sharded_gather_check(ra, shard, wl, local_rank, rank, world, n_blocks=256):
         dec.close()
 
 
-def device_state(index: int) -> dict:
-    """What the box's management interface says about device `index` right now: current shader / memory / fabric clocks,
-    socket power and its cap, performance level, compute / memory partition mode (rocm-smi --json).  Recorded before and
-    after the timed region -- never inside it -- so that a slow line can be told from a regression:
-    the same binary measured 0.62 ... 0.72 of the roofline on different boxes of the pool."""
-    import subprocess
+def _hip_pci_bus_id(index: int):
+    """PCI address of HIP device `index` ("0000:05:00.0") through the runtime that is loaded anyway, or None."""
     try:
-        r = subprocess.run(["rocm-smi", "-d", str(index), "--showclocks", "--showpower", "--showmaxpower", "--showperflevel",
-                            "--showcomputepartition", "--showmemorypartition", "--json"], capture_output=True, text=True, timeout=30)
-        cards = json.loads(r.stdout[r.stdout.index("{"):])
-        card = cards.get(f"card{index}") or next(iter(cards.values()))
-        keep = {}
-        for k, v in card.items():
-            kl = k.lower()
-            if any(t in kl for t in ("sclk", "mclk", "fclk", "socclk", "power", "partition", "performance level")):
-                keep[k] = v
-        return keep
-    except Exception as e:   # noqa: BLE001 -- a missing tool must not fail the bench
+        hip = C.CDLL("libamdhip64.so")
+        buf = C.create_string_buffer(64)
+        if hip.hipDeviceGetPCIBusId(buf, 64, int(index)) == 0:
+            return buf.value.decode().lower()
+    except Exception:   # noqa: BLE001
+        pass
+    return None
+
+
+def device_state(index: int) -> dict:
+    """What the kernel driver says about device `index` right now: current shader / memory clock, socket power and its
+    cap, the DPM tables with the active level, compute / memory partition mode -- read from sysfs
+    (/sys/class/drm/card*/device: hwmon freq1_input, freq2_input, power1_input, power1_cap; pp_dpm_*; current_*_partition).
+    Recorded while the pipeline is busy, before and after the timed region, never inside it, so that a slow line can be
+    told from a regression (one binary measured 0.62 ... 0.72 of the roofline on different boxes).
+    Plain file reads on purpose: `rocm-smi` as a child process costs the parent 0.45 ms inside the NEXT timed region
+    (copy-on-write faults after the fork; measured A/B, profiles/r06/README.md)."""
+    import glob
+    try:
+        want = _hip_pci_bus_id(index)
+        cards = []
+        for d in sorted(glob.glob("/sys/class/drm/card[0-9]*/device"), key=lambda p: int(p.split("card")[1].split("/")[0])):
+            if os.path.exists(os.path.join(d, "pp_dpm_sclk")):
+                cards.append(d)
+        if not cards:
+            return {"unavailable": "no amdgpu card with pp_dpm_sclk under /sys/class/drm"}
+        dev = None
+        for d in cards:
+            if want and os.path.basename(os.path.realpath(d)).lower() == want:
+                dev = d
+        how = "matched by PCI address" if dev else "by ordinal"
+        dev = dev or cards[min(index, len(cards) - 1)]
+
+        def rd(rel):
+            try:
+                with open(os.path.join(dev, rel)) as f:
+                    return f.read().strip()
+            except OSError:
+                return None
+        hw = glob.glob(os.path.join(dev, "hwmon", "hwmon*"))
+        hwd = os.path.relpath(hw[0], dev) if hw else None
+
+        def num(rel, scale):
+            v = rd(os.path.join(hwd, rel)) if hwd else None
+            return round(int(v) / scale, 1) if v and v.lstrip("-").isdigit() else None
+
+        def active(table):
+            for line in (table or "").splitlines():
+                if line.rstrip().endswith("*"):
+                    return line.replace("*", "").strip()
+            return None
+        return {"card": os.path.basename(os.path.dirname(dev)), "selected": how, "pci": os.path.basename(os.path.realpath(dev)),
+                "sclk_mhz": num("freq1_input", 1e6), "mclk_mhz": num("freq2_input", 1e6),
+                "power_w": num("power1_input", 1e6), "power_cap_w": num("power1_cap", 1e6),
+                "sclk_level": active(rd("pp_dpm_sclk")), "sclk_levels": (rd("pp_dpm_sclk") or "").replace("\n", " | "),
+                "fclk_level": active(rd("pp_dpm_fclk")), "socclk_level": active(rd("pp_dpm_socclk")),
+                "compute_partition": rd("current_compute_partition"), "memory_partition": rd("current_memory_partition")}
+    except Exception as e:   # noqa: BLE001 -- a missing file must not fail the bench
         return {"unavailable": f"{type(e).__name__}: {str(e)[:120]}"}
 
 
@@ -364,6 +407,8 @@ def main():
     ap.add_argument("--spinup-ms", type=float, default=250.0, help="untimed passes before the warm-up (shader clock ramp)")
     ap.add_argument("--depth", type=int, default=3, help="batches in flight (1..3)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--device-state", choices=["load", "off"], default="load",
+                    help="sysfs snapshots (clocks, power, partition) under load before and after the timed region")
     ap.add_argument("--no-verify", action="store_true", help="skip the golden hit count / planted message check")
     ap.add_argument("--k1-events", type=int, default=4,
                     help="HIP events around the K1 dispatch of every N-th timed step (0 = none: roofline fields are NaN)")
@@ -564,7 +609,7 @@ def main():
                     consume(seq - 1)               # posted one step ago: normally there already
         return br
 
-    def run(n, level, every=1):
+    def run(n, level, every=1, at_half=None):
         """n steps through the pipeline, --depth batches in flight (3: the GPU runs batches i+1 and i+2 while the host
         reads back batch i, and K3 of batch i runs next to the search of batch i+1).
         Steps 0, every, 2*every, ... carry timing events of the given level (every=0: none)."""
@@ -582,6 +627,8 @@ def main():
         done = 0
         for i in range(depth - 1, n):
             submit(i)
+            if at_half is not None and i == n // 2:
+                at_half()
             out.append((finish(), dec.timing() if timed[done] else None))
             done += 1
         while done < n:
@@ -595,7 +642,14 @@ def main():
         chunk = max(8, int(8e-3 / max(1e-6, 0.28e-3 * nbytes / GIB)))     # ~8 ms of batches per chunk
         t_spin = time.perf_counter()
         pairs = []                       # (ms for c steps, ms for 2c steps): the slope is the steady step, fill excluded
-        while (time.perf_counter() - t_spin) * 1e3 < args.spinup_ms:
+        def more_spin():
+            go = (time.perf_counter() - t_spin) * 1e3 < args.spinup_ms
+            if distributed:          # one decision for all ranks: every step posts a collective gather
+                tg = torch.tensor([1 if go else 0], dtype=torch.int32, device=dev)
+                dist.all_reduce(tg, op=dist.ReduceOp.MAX)
+                go = bool(tg.item())
+            return go
+        while more_spin():
             t_pair = []
             for n in (chunk, 2 * chunk):
                 sync_all()
@@ -612,13 +666,21 @@ def main():
     # Timing events ride on the kernel dispatches (a separate event record costs a ~5 us stream bubble each): the warm-up
     # steps and every --k1-events-th timed step carry the full set (K1 start/stop for the roofline figure, K2 and K3..
     # for search_ms); measured: on every step 2 % of the step, on every 4th 0.5 %, the averages are the same.
+    def state_under_load():
+        """device_state() of this rank's GPU read WHILE the pipeline is busy: 64 untimed steps, the files are read when half of
+        them have been submitted (an idle device drops its shader clock within milliseconds: a snapshot of an idle device
+        says nothing about the timed steps)."""
+        if args.device_state == "off":
+            return None
+        box = {}
+        run(64, 0, 0, at_half=lambda: box.update(device_state(local_rank)))
+        if distributed:
+            gatherer.wait()
+        sync_all()
+        return box
+
+    state_before = state_under_load()
     warm = run(max(args.warmup, 1), 2) if args.warmup else []
-    sync_all()
-    state_before = device_state(local_rank) if rank == 0 else None     # ~0.5 s of rocm-smi, outside the timed region
-    sync_all()                           # (the other ranks wait for rank 0's snapshot)
-    run(2, 0, 0)                         # the snapshot idled the device for a moment: two untimed steps bring the clocks back
-    if distributed:
-        gatherer.wait()
     sync_all()
     c0, r0 = gstat["consumed"], gstat["records"]
     t0 = time.perf_counter()
@@ -627,7 +689,6 @@ def main():
         gatherer.wait()
     sync_all()
     dt = time.perf_counter() - t0
-    state_after = device_state(local_rank) if rank == 0 else None
     consumed_timed, records_timed = gstat["consumed"] - c0, gstat["records"] - r0
     tms = [t for _, t in res if t is not None] or [t for _, t in warm]
     demod_ms = [t["demod_ms"] for t in tms] or [float("nan")]
@@ -672,6 +733,8 @@ def main():
         check["planted"] = (f"{n_want} planted messages recovered, none missing, none unexpected" if ok else
                             f"MISMATCH: {n_missing} of {n_want} planted messages missing, {n_extra} unexpected")
         rc = rc or (0 if ok else 4)
+
+    state_after = state_under_load()      # (after every check of the timed steps' results: it reuses their buffers)
 
     if rank == 0:
         total_samples = float(world) * args.steps * n_samples
@@ -718,7 +781,7 @@ def main():
                        "block_size": bs, "bytes_per_gpu_per_step": nbytes, "planted_packets_per_gpu": len(pk),
                        "hits_per_step_rank0": n_hits, "hits_searched_per_step_rank0": n_searched,
                        "gpu_validation": bool(validating), "deferral": deferral,
-                       "spin_up": f"{spin_steps} untimed steps (~{args.spinup_ms:.0f} ms) before the warm-up: shader clock ramp",
+                       "spin_up": f"{spin_steps} untimed steps (~{args.spinup_ms:.0f} ms) before the warm-up: shader clock ramp; 64 more untimed steps on either side of warm-up + timed region while the driver's sysfs files are read (device.before / after)",
                        "checks": check,
                        "iq_buffer": "first device allocation", "parallelism": f"block-range shards x{world}",
                        "hit_gather": gather_kind},

@@ -367,6 +367,15 @@ amr_status amr_comm_destroy(amr_handle *h);
 amr_status amr_comm_init_all(amr_handle **hs, int32_t n, int32_t root, uint64_t cap_hits);
 amr_status amr_gather_hits_all(amr_handle **hs, int32_t n, uint64_t *seq);
 amr_status amr_comm_check_all(amr_handle *const *hs, const int32_t *devices, int32_t n, int32_t root, uint64_t cap_hits);
+/*
+ * TEST HOOK, not for production: enable != 0 replaces RCCL by an in-process loopback transport (same point-to-point
+ * semantics: FIFO matching per rank pair, sizes must match, group calls; a matched pair is one device copy) for every
+ * communicator made afterwards, and lets amr_comm_check_all / amr_comm_init_all accept several handles on ONE device.
+ * It exists so that the code around the transport -- the root's n receives, the two-phase header wait, truncation, the
+ * inconsistent-header path, the mirror kernel -- runs with 2 and 3 ranks on a one-GPU box (tests/test_gpu_comm.py).
+ * Off (the default) nothing is relaxed: two handles on one device stay AMR_EINVAL.
+ */
+amr_status amr_comm_test_loopback(int32_t enable);
 /* ranks the RCCL communicator spans (ncclCommCount): lets a bench line prove the gather ran over N ranks */
 amr_status amr_comm_ranks(const amr_handle *h, int32_t *n_ranks);
 /* Enqueue the gather of the result amr_collect / amr_flush returned last (with amr_set_validation: of its surviving

@@ -16,7 +16,7 @@ AMR_OK, AMR_EINVAL, AMR_ENOMEM, AMR_EHIP, AMR_ENODEV, AMR_EOVERFLOW = 0, -1, -2,
 SYMBOLS = [
     "amr_create", "amr_plan", "amr_destroy", "amr_device_count", "amr_reset", "amr_get_geometry", "amr_preamble_id", "amr_get_mag_lut", "amr_r900_enable", "amr_set_validation",
     "amr_set_stream", "amr_set_block_base", "amr_decode_batch", "amr_decode_batch_device", "amr_submit_device", "amr_collect", "amr_set_deferral", "amr_flush", "amr_submit_host", "amr_host_alloc", "amr_host_free", "amr_result_device", "amr_prime",
-    "amr_halo_bytes", "amr_prime_blocks", "amr_get_stale_carry", "amr_set_stale_carry", "amr_copy_quantized", "amr_set_timing", "amr_get_timing", "amr_strerror",
+    "amr_comm_test_loopback", "amr_halo_bytes", "amr_prime_blocks", "amr_get_stale_carry", "amr_set_stale_carry", "amr_copy_quantized", "amr_set_timing", "amr_get_timing", "amr_strerror",
     "amr_last_error", "amr_describe", "amr_dev_alloc", "amr_dev_free", "amr_dev_upload", "amr_dev_download",
     "amr_dev_sync", "amr_synth_noise", "amr_synth_uniform", "amr_synth_plant",
     "amr_comm_unique_id", "amr_comm_init", "amr_comm_init_all", "amr_gather_hits_all", "amr_comm_check_all", "amr_comm_destroy", "amr_comm_ranks", "amr_gather_hits", "amr_gather_wait", "amr_gather_fetch",
@@ -112,6 +112,7 @@ def lib() -> C.CDLL:
     L.amr_set_deferral.argtypes = [vp, C.c_int32]
     L.amr_flush.argtypes = [vp, C.POINTER(AmrResult)]
     L.amr_prime.argtypes = [vp, vp, vp, C.c_size_t, C.c_int]
+    L.amr_comm_test_loopback.argtypes = [C.c_int32]
     L.amr_get_stale_carry.argtypes = [vp, C.POINTER(C.c_uint8)]
     L.amr_set_stale_carry.argtypes = [vp, C.c_uint8]
     L.amr_halo_bytes.argtypes = [vp]
@@ -161,7 +162,7 @@ def lib() -> C.CDLL:
     L.amr_gather_unpack.argtypes = [vp, C.c_size_t, C.POINTER(AmrGathered)]
     for name in SYMBOLS:
         fn = getattr(L, name)
-        if name not in ("amr_preamble_id", "amr_halo_bytes", "amr_prime_blocks", "amr_get_stale_carry", "amr_set_stale_carry", "amr_strerror", "amr_last_error",
+        if name not in ("amr_preamble_id", "amr_comm_test_loopback", "amr_halo_bytes", "amr_prime_blocks", "amr_get_stale_carry", "amr_set_stale_carry", "amr_strerror", "amr_last_error",
                         "amr_gather_slot_bytes", "amr_gather_wire_bytes", "amr_gather_two_phase"):
             fn.restype = C.c_int
     _lib = L

@@ -38,7 +38,10 @@ using namespace amr_host;
 // RCCL is bound at run time (dlopen): libamrdemod.so has no link-time dependency on it, and a process that already
 // carries a copy (PyTorch ships one) keeps using that one.
 // =====================================================================================================================
+#include <algorithm>
+#include <deque>
 #include <mutex>
+#include <vector>
 
 namespace {
 
@@ -57,8 +60,123 @@ struct Rccl {
     const char *(*GetErrorString)(int) = nullptr;
 };
 
+// ---------------------------------------------------------------------------------------------------------------------
+// TEST HOOK (amr_comm_test_loopback): an in-process stand-in for the RCCL entry points above, so that the logic AROUND
+// the transport -- the root's n receives, the two-phase header wait, truncation, the inconsistent-header path, the
+// mirror kernel -- runs with n = 2, 3 ranks on a ONE-GPU box (first contact with n > 1 must not be the
+// 8-GPU lease).  Semantics kept: point-to-point, FIFO matching per (source, destination) pair, a send completes on its
+// stream only after the matching receive has been posted, sizes must match (a mismatch is an error, like RCCL's), calls
+// inside ncclGroupStart/End take effect at the outermost ncclGroupEnd.  A matched pair is one hipMemcpyAsync on the
+// receiver's stream between two cross-stream events.  Every "rank" may sit on the same device: nothing else is relaxed.
+namespace loop {
+struct World;
+struct LComm { World *w; int rank; };
+struct Op { bool send; void *buf; size_t bytes; int peer; LComm *c; hipStream_t st; };
+struct World { Id128 id; int n; std::deque<Op> sends, recvs; int members = 0; };
+std::mutex mu;
+std::vector<World *> worlds;
+std::vector<Op> group_ops;
+int depth = 0;
+uint64_t next_id = 1;
+uint64_t mismatches = 0;
+
+int get_unique_id(void *out)
+{
+    std::lock_guard<std::mutex> lk(mu);
+    memset(out, 0, 128);
+    memcpy(out, &next_id, 8);
+    memcpy((char *)out + 8, "amr-loopback", 12);
+    ++next_id;
+    return 0;
+}
+int comm_init_rank(void **comm, int n, Id128 id, int rank)
+{
+    std::lock_guard<std::mutex> lk(mu);
+    World *w = nullptr;
+    for (World *x : worlds) if (memcmp(x->id.b, id.b, 128) == 0) w = x;
+    if (!w) { w = new World(); w->id = id; w->n = n; worlds.push_back(w); }
+    if (w->n != n || rank < 0 || rank >= n) return 4;   // ncclInvalidArgument
+    w->members++;
+    *comm = new LComm{w, rank};
+    return 0;
+}
+int comm_destroy(void *comm)
+{
+    std::lock_guard<std::mutex> lk(mu);
+    LComm *c = (LComm *)comm;
+    if (--c->w->members == 0) {
+        worlds.erase(std::remove(worlds.begin(), worlds.end(), c->w), worlds.end());
+        delete c->w;
+    }
+    delete c;
+    return 0;
+}
+int comm_count(void *comm, int *n) { *n = ((LComm *)comm)->w->n; return 0; }
+// match what can be matched: receives in posting order, each with the oldest send of its (source -> destination) pair
+int match(World *w)
+{
+    int rc = 0;
+    for (auto r = w->recvs.begin(); r != w->recvs.end();) {
+        auto s = w->sends.begin();
+        for (; s != w->sends.end(); ++s) if (s->c->rank == r->peer && s->peer == r->c->rank) break;
+        if (s == w->sends.end()) { ++r; continue; }
+        size_t bytes = s->bytes;
+        if (s->bytes != r->bytes) { ++mismatches; rc = 4; bytes = std::min(s->bytes, r->bytes); }
+        hipEvent_t e0 = nullptr, e1 = nullptr;
+        const bool cross = s->st != r->st;
+        if (cross) {
+            if (hipEventCreateWithFlags(&e0, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&e1, hipEventDisableTiming) != hipSuccess) return 1;
+            if (hipEventRecord(e0, s->st) != hipSuccess || hipStreamWaitEvent(r->st, e0, 0) != hipSuccess) return 1;
+        }
+        if (bytes && hipMemcpyAsync(r->buf, s->buf, bytes, hipMemcpyDeviceToDevice, r->st) != hipSuccess) return 1;
+        if (cross) {   // the sender's stream goes on (and may reuse the buffer) only behind the copy
+            if (hipEventRecord(e1, r->st) != hipSuccess || hipStreamWaitEvent(s->st, e1, 0) != hipSuccess) return 1;
+            (void)hipEventDestroy(e0);
+            (void)hipEventDestroy(e1);
+        }
+        w->sends.erase(s);
+        r = w->recvs.erase(r);
+    }
+    return rc;
+}
+int flush()
+{
+    int rc = 0;
+    std::vector<World *> touched;
+    for (const Op &o : group_ops) {
+        (o.send ? o.c->w->sends : o.c->w->recvs).push_back(o);
+        if (std::find(touched.begin(), touched.end(), o.c->w) == touched.end()) touched.push_back(o.c->w);
+    }
+    group_ops.clear();
+    for (World *w : touched) { const int r = match(w); if (r) rc = r; }
+    return rc;
+}
+int group_start() { std::lock_guard<std::mutex> lk(mu); ++depth; return 0; }
+int group_end() { std::lock_guard<std::mutex> lk(mu); if (depth > 0 && --depth == 0) return flush(); return 0; }
+int post(bool send, void *buf, size_t bytes, int peer, void *comm, hipStream_t st)
+{
+    std::lock_guard<std::mutex> lk(mu);
+    LComm *c = (LComm *)comm;
+    if (peer < 0 || peer >= c->w->n) return 4;
+    group_ops.push_back(Op{send, buf, bytes, peer, c, st});
+    return depth == 0 ? flush() : 0;
+}
+int send(const void *buf, size_t n, int, int peer, void *comm, hipStream_t st) { return post(true, const_cast<void *>(buf), n, peer, comm, st); }
+int recv(void *buf, size_t n, int, int peer, void *comm, hipStream_t st) { return post(false, buf, n, peer, comm, st); }
+const char *error_string(int rc) { return rc == 4 ? "loopback transport: invalid argument / send and receive sizes differ" : "loopback transport: HIP call failed"; }
+bool enabled = false;
+}  // namespace loop
+
 Rccl *rccl()
 {
+    if (loop::enabled) {
+        static Rccl l;
+        l.so = &l;
+        l.GetUniqueId = loop::get_unique_id; l.CommInitRank = loop::comm_init_rank; l.CommDestroy = loop::comm_destroy;
+        l.CommCount = loop::comm_count; l.GroupStart = loop::group_start; l.GroupEnd = loop::group_end;
+        l.Send = loop::send; l.Recv = loop::recv; l.GetErrorString = loop::error_string;
+        return &l;
+    }
     static Rccl r;
     static std::once_flag once;
     std::call_once(once, [] {
@@ -215,6 +333,12 @@ amr_status amr_gather_unpack(const void *slot, size_t slot_bytes, amr_gathered *
     return gather_unpack(slot, slot_bytes, out);
 }
 
+amr_status amr_comm_test_loopback(int32_t enable)
+{
+    loop::enabled = enable != 0;
+    return AMR_OK;
+}
+
 amr_status amr_comm_unique_id(void *id128)
 {
     if (!id128) return fail(AMR_EINVAL, "null argument");
@@ -276,7 +400,7 @@ amr_status amr_comm_check_all(amr_handle *const *hs, const int32_t *devices, int
         for (int32_t j = 0; j < i; ++j) {
             if (hs && hs[j] == hs[i]) return fail(AMR_EINVAL, "amr_comm_init_all: the same handle twice");
             // one rank per device: two ranks of one communicator on one GPU deadlock in RCCL's point-to-point kernels
-            if ((devices ? devices[j] : hs[j]->device) == di) return fail(AMR_EINVAL, "amr_comm_init_all: two handles on one device");
+            if (!loop::enabled && (devices ? devices[j] : hs[j]->device) == di) return fail(AMR_EINVAL, "amr_comm_init_all: two handles on one device");
         }
         if (hs && hs[i]->comm) return fail(AMR_EINVAL, "amr_comm_init_all: a handle has a communicator already");
     }
@@ -376,6 +500,19 @@ amr_status gather_many(amr_handle *const *hs, int n, uint64_t *seq_out)
     std::vector<GatherStep> g((size_t)n);
     const size_t hdr_bytes = (size_t)kGatherHdr * 8;
     amr_handle *root_h = nullptr;
+    // nothing is touched before every handle is known to be in step (a refusal half way through left the
+    // sequence numbers of the first handles advanced for good)
+    for (int i = 1; i < n; ++i)
+        if (hs[i]->comm->next_seq != hs[0]->comm->next_seq) return fail(AMR_EINVAL, "amr_gather_hits_all: the handles' gathers are out of step");
+    // an RCCL group that was opened is closed on every path: an error inside it would otherwise leave this thread inside an
+    // open group, and every later RCCL call of the process would be queued into it
+    struct Group {
+        Rccl *r; bool open = false;
+        explicit Group(Rccl *rr) : r(rr) {}
+        int start() { const int rc = r->GroupStart(); open = rc == 0; return rc; }
+        int end() { open = false; return r->GroupEnd(); }
+        ~Group() { if (open) (void)r->GroupEnd(); }
+    };
     // ---- every rank: the pack kernel on its communicator's stream, behind the sends (and the root's mirror kernel) that
     // last used buffer set k ----
     for (int i = 0; i < n; ++i) {
@@ -401,7 +538,6 @@ amr_status gather_many(amr_handle *const *hs, int n, uint64_t *seq_out)
             s->pack_pending = true;
         }
         if (c->rank == c->root) root_h = h;
-        if (g[(size_t)i].seq != g[0].seq) return fail(AMR_EINVAL, "amr_gather_hits_all: the handles' gathers are out of step");
     }
     const uint64_t seq = g[0].seq;
     const int k = g[0].k;
@@ -415,7 +551,8 @@ amr_status gather_many(amr_handle *const *hs, int n, uint64_t *seq_out)
     };
     if (!gather_two_phase(hs[0]->comm->slot_bytes)) {
         // ---- small slots: the whole slot in one message, no host wait anywhere ----
-        NCCL_TRY(r->GroupStart());
+        Group grp(r);
+        NCCL_TRY(grp.start());
         for (int i = 0; i < n; ++i) {
             Comm *c = hs[i]->comm;
             HIP_TRY(hipSetDevice(hs[i]->device));
@@ -424,14 +561,15 @@ amr_status gather_many(amr_handle *const *hs, int n, uint64_t *seq_out)
                 for (int p = 0; p < c->world; ++p)
                     NCCL_TRY(r->Recv(c->d_recv[k] + (size_t)p * c->slot_bytes, c->slot_bytes, kNcclUint8, p, c->comm, c->stream));
         }
-        NCCL_TRY(r->GroupEnd());
+        NCCL_TRY(grp.end());
         if (rc) AMR_TRY(finish_root(nullptr));
         for (int i = 0; i < n; ++i) hs[i]->comm->seq_of[k] = seq;
         if (seq_out) *seq_out = seq;
         return AMR_OK;
     }
     // ---- phase 1: the headers ----
-    NCCL_TRY(r->GroupStart());
+    Group grp(r);
+    NCCL_TRY(grp.start());
     for (int i = 0; i < n; ++i) {
         Comm *c = hs[i]->comm;
         HIP_TRY(hipSetDevice(hs[i]->device));
@@ -440,7 +578,7 @@ amr_status gather_many(amr_handle *const *hs, int n, uint64_t *seq_out)
             for (int p = 0; p < c->world; ++p)
                 NCCL_TRY(r->Recv(c->d_hdr[k] + (size_t)p * hdr_bytes, hdr_bytes, kNcclUint8, p, c->comm, c->stream));
     }
-    NCCL_TRY(r->GroupEnd());
+    NCCL_TRY(grp.end());
     // ---- phase 2: the records, sized by their count.  A rank that is not the root knows its count on the host and never
     // waits; the root needs every peer's count before it can post its receives (RCCL point-to-point wants matching
     // sizes) and waits for the 128-byte headers -- with all ranks in one thread, that wait comes first for everybody ----
@@ -461,7 +599,7 @@ amr_status gather_many(amr_handle *const *hs, int n, uint64_t *seq_out)
             if (hp[1] > rc->cap || hp[1] > hp[0] || hp[12] != seq) consistent = false;
         }
     }
-    NCCL_TRY(r->GroupStart());
+    NCCL_TRY(grp.start());
     for (int i = 0; i < n; ++i) {
         Comm *c = hs[i]->comm;
         HIP_TRY(hipSetDevice(hs[i]->device));
@@ -473,9 +611,12 @@ amr_status gather_many(amr_handle *const *hs, int n, uint64_t *seq_out)
                 if (m_p) NCCL_TRY(r->Recv(c->d_recv[k] + (size_t)p * c->slot_bytes + hdr_bytes, gather_wire_bytes(m_p), kNcclUint8, p, c->comm, c->stream));
             }
     }
-    NCCL_TRY(r->GroupEnd());
+    // (a receive sized by a clamped count against a sender that believes in a larger capacity: the transport may refuse the
+    // pair -- the gather is failed below either way, which is the error the caller must see)
+    const int rc_p2 = grp.end();
     for (int i = 0; i < n; ++i) hs[i]->comm->seq_of[k] = seq;
     if (seq_out) *seq_out = seq;
+    if (rc_p2 != 0 && !(rc && !consistent)) return nccl_fail("ncclGroupEnd (records)", rc_p2);
     if (rc && !consistent) {
         rc->failed[k] = true;
         HIP_TRY(hipSetDevice(root_h->device));

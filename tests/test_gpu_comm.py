@@ -260,3 +260,146 @@ def test_single_process_group_of_two_devices():
         pytest.skip("needs two gfx950 devices")
     _group_case([0, 1], cap_hits=1 << 12)
     _group_case([1, 0], protos=("scm",), n_blocks=333, cap_hits=1 << 16)
+
+
+# ---- n > 1 on ONE GPU: the loopback transport (amr_comm_test_loopback) ----------------------------------------------------
+
+@pytest.fixture
+def loopback():
+    from rtlamr_amd import _lib
+    L = _lib.lib()
+    _lib.check(L.amr_comm_test_loopback(1), "loopback on")
+    yield L
+    _lib.check(L.amr_comm_test_loopback(0), "loopback off")
+
+
+def _group_rows(grp, iq):
+    rows = grp.decode(iq)
+    return rows[np.lexsort((rows[:, 2], rows[:, 1], rows[:, 0]))]
+
+
+@pytest.mark.parametrize("world,root,cap", [(2, 0, 1 << 12), (3, 1, 1 << 12), (2, 1, 1 << 16), (3, 0, 1 << 16), (3, 2, 1 << 16)])
+def test_loopback_group_equals_single_decoder(loopback, world, root, cap):
+    """the root side of the gather with n = 2, 3 ranks -- n receives, (cap 65 536: slots > 256 KiB) the
+    two-phase header wait and count-sized records, (cap 4 096) whole slots in one message -- through amr_comm_init_all /
+    amr_gather_hits_all on handles that all sit on device 0, against the single decoder's (= the oracle's) hit list;
+    three streams in a row so that the two buffer sets alternate and the sequence numbers advance."""
+    from rtlamr_amd import _lib, dist
+    protos, chip = ["scm", "idm"], 72
+    assert bool(loopback.amr_gather_two_phase(cap)) == (cap > (1 << 14))
+    grp = dist.DeviceGroup(lambda d: util.make_decoder(protos, chip), devices=[0] * world, root=root, cap_hits=cap)
+    try:
+        assert grp.decoders[root].comm_ranks() == world
+        bs = grp.decoders[0].Cfg.BlockSize
+        for seed, n_blocks in ((51, 150), (52, 97), (53, 210)):
+            iq, _ = util.synth_stream(protos, chip, n_blocks, bs, seed=seed, n_packets=6, edge_every=2)
+            want = util.oracle_run(protos, chip, iq)[2]
+            assert 0 < len(want) <= cap
+            got = _group_rows(grp, iq)
+            assert np.array_equal(got, want), f"world {world} root {root} cap {cap}: gathered rows differ from the single decoder's"
+        # only the root holds records
+        other = (root + 1) % world
+        with pytest.raises(_lib.AmrError):
+            grp.decoders[other].gather_fetch(0, grp.last_seq)
+    finally:
+        grp.close()
+
+
+@pytest.mark.parametrize("cap", [40, 20000])
+def test_loopback_truncation_is_reported_per_rank(loopback, cap):
+    """A rank with more records than the capacity sends `cap` of them and its true count (both wire forms)."""
+    from rtlamr_amd import dist
+    protos, chip, world = ["scm"], 8, 3
+    grp = dist.DeviceGroup(lambda d: util.make_decoder(protos, chip), devices=[0] * world, root=0, cap_hits=cap)
+    try:
+        bs = grp.decoders[0].Cfg.BlockSize
+        n_blocks = 3 * 4096 if cap == 40 else 3 * 16384
+        iq, _ = util.synth_stream(protos, chip, n_blocks, bs, seed=7, n_packets=60 if cap == 40 else 9000, edge_every=3)
+        want = util.oracle_run(protos, chip, iq, hits_cap=1 << 20)[2]
+        bs2 = grp.decoders[0].Cfg.BlockSize2
+        per_rank = []
+        for dec, (k0, k1, p0) in zip(grp.decoders, grp.plan(n_blocks)):
+            dec.reset()
+            if k0 > p0:
+                dec.prime(iq[p0 * bs2: k0 * bs2], iq[p0 * bs2 - dec.halo_bytes(): p0 * bs2] if p0 > 0 else None)
+            dec.set_block_base(k0)
+            dec.decode_batch(iq[k0 * bs2: k1 * bs2])
+            per_rank.append(want[(want[:, 1] >= k0) & (want[:, 1] < k1)])
+        seq = grp.post()
+        truncated = 0
+        for r in range(world):
+            n_true, off, blk, idx = grp.decoders[0].gather_fetch(r, seq)
+            assert n_true == len(per_rank[r])
+            assert len(blk) == min(n_true, cap)
+            assert np.array_equal(blk.astype(np.int64), per_rank[r][: len(blk), 1]) and np.array_equal(idx.astype(np.int64), per_rank[r][: len(blk), 2])
+            truncated += n_true > cap
+        assert truncated >= 1, "no rank exceeded the capacity: the test tests nothing"
+        with pytest.raises(OverflowError):
+            grp.result(seq)
+    finally:
+        grp.close()
+
+
+def test_loopback_ranks_with_their_own_communicators_and_an_inconsistent_header(loopback):
+    """One communicator per handle (amr_comm_init, the one-process-per-GPU form) over the loopback transport: the peers
+    post first and never wait, the root then finds their sends.  Then the error path: a peer whose capacity is larger
+    than the root's advertises more records than a root slot holds -- the root still posts its phase-2 receives (nobody
+    hangs), fails the gather, and amr_gather_fetch refuses its records."""
+    from rtlamr_amd import _lib, dist
+    protos, chip = ["scm"], 8
+    bs = util.make_decoder(protos, chip)
+    B, bs2 = bs.Cfg.BlockSize, bs.Cfg.BlockSize2
+    bs.close()
+    n_blocks = 2 * 32768
+    iq, _ = util.synth_stream(protos, chip, n_blocks, B, seed=9, n_packets=12000, edge_every=3)
+    want = util.oracle_run(protos, chip, iq, hits_cap=1 << 21)[2]
+    half = n_blocks // 2
+    assert (want[:, 1] >= half).sum() > 30000
+
+    def make(rank, uid, cap):
+        dec = util.make_decoder(protos, chip)
+        dec.comm_init(uid, rank, 2, 0, cap_hits=cap)
+        k0, k1 = dist.shard_range(n_blocks, 2, rank)
+        p0, _ = dist.prime_range(k0, dec.prime_blocks())
+        if k0 > p0:
+            dec.prime(iq[p0 * bs2: k0 * bs2], iq[p0 * bs2 - dec.halo_bytes(): p0 * bs2] if p0 > 0 else None)
+        dec.set_block_base(k0)
+        dec.decode_batch(iq[k0 * bs2: k1 * bs2])
+        return dec
+
+    # (a) equal capacities (two-phase): consistent, equal to the single decoder
+    uid = dist.comm_unique_id()
+    d0, d1 = make(0, uid, 1 << 17), make(1, uid, 1 << 17)
+    try:
+        s1 = d1.gather_hits()            # the peer first: returns at once, its sends wait for the root
+        s0 = d0.gather_hits()
+        assert s0 == s1 == 0
+        rows = []
+        for r in range(2):
+            n_true, off, blk, idx = d0.gather_fetch(r, s0)
+            assert n_true == len(blk)
+            rows.append(dist.rows_from_gathered(off, blk, idx))
+        rows = np.concatenate(rows)
+        assert np.array_equal(rows[np.lexsort((rows[:, 2], rows[:, 1], rows[:, 0]))], want)
+    finally:
+        d0.close(); d1.close()
+    # (b) the peer believes in a larger capacity than the root's slots have
+    uid = dist.comm_unique_id()
+    d0, d1 = make(0, uid, 25000), make(1, uid, 1 << 17)
+    try:
+        d1.gather_hits()
+        with pytest.raises(_lib.AmrError, match="inconsistent"):
+            d0.gather_hits()
+        with pytest.raises(_lib.AmrError, match="failed"):
+            d0.gather_fetch(1, 0)
+        d0.gather_wait(); d1.gather_wait()      # nobody hangs: every enqueued send and receive has completed
+    finally:
+        d0.close(); d1.close()
+
+
+def test_two_handles_on_one_device_stay_refused_without_the_hook():
+    from rtlamr_amd import _lib, dist
+    _lib.check(_lib.lib().amr_comm_test_loopback(0), "loopback off")
+    with pytest.raises(_lib.AmrError):
+        dist.check_device_group([0, 0])
+    dist.check_device_group([0, 1])

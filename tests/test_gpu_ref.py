@@ -35,6 +35,13 @@ def test_hip_equals_translated_reference(protos, chip, n_blocks, batches):
         iq, _ = util.synth_stream(protos, chip, n_blocks, dec.Cfg.BlockSize, seed=31 + chip, n_packets=5, edge_every=2)
         a = iq.size // 3
         iq[a:a + 60_000] = np.random.default_rng(chip).integers(0, 256, 60_000, dtype=np.uint8)
+        if "r900" in protos:          # bursts with the r900 preamble (the packet builders above cover the other protocols)
+            from oracle.oracle import PROTOCOLS
+            from rtlamr_amd import synth
+            from rtlamr_amd.parsers import r900 as pr900
+            for j in range(4):
+                chips = synth.r900_chips(PROTOCOLS["r900"][0], pr900.build_r900_symbols(300 + j, consumption=j))
+                synth.plant_chips(iq, (7 + 45 * j) * dec.Cfg.BlockSize + 5 * j, chips, chip, 34, -29)
         _, q, h, p, msgs = ref_run(protos, chip, iq)
         gq, gh, gp = util.gpu_run(dec, iq, batches)
         assert np.array_equal(q, gq), "quantized bitstream differs from the translated reference"
