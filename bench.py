@@ -66,8 +66,8 @@ def workload(spec: str) -> dict:
 
 
 def packet_builders():
-    from rtlamr_amd.parsers.idm import build_idm_packet, build_scmplus_packet
-    from rtlamr_amd.parsers.scm import build_packet
+    from rtlamr_amd.contrib.parsers.idm import build_idm_packet, build_scmplus_packet
+    from rtlamr_amd.contrib.parsers.scm import build_packet
     return {
         "scm": (lambda i: build_packet(100000 + i, (i % 12) + 1, i * 37), 96),
         "idm": (lambda i: build_idm_packet(200000 + i, consumption=i * 31), 736),
@@ -195,9 +195,9 @@ def measure_traffic(spec: str, blocks: int, k1_full: str):
             out = os.path.join(tmp, ctr)
             cmd = [rp, "--kernel-trace", "--pmc", ctr, "-d", out, "-o", "pmc", "--output-format", "csv", "--", sys.executable,
                    os.path.abspath(__file__), "--workload", spec, "--steps", "3", "--warmup", "1", "--depth", "1", "--k1-events", "0",
-                   "--no-cpu-baseline", "--no-verify", "--spinup-ms", "0"] + (["--blocks", str(blocks)] if blocks else [])
+                   "--no-cpu-baseline", "--no-verify", "--spinup-ms", "0", "--device-state", "off", "--no-measure-traffic"] + (["--blocks", str(blocks)] if blocks else [])
             try:
-                subprocess.run(cmd, cwd="/tmp", env=env, capture_output=True, timeout=600)
+                subprocess.run(cmd, cwd="/tmp", env=env, capture_output=True, timeout=240)
             except Exception as e:
                 return None, f"rocprofv3 --pmc {ctr} failed: {e}"
             got = collections.defaultdict(list)
@@ -415,7 +415,9 @@ def main():
     ap.add_argument("--measure-traffic", action="store_true",
                     help="N = 1: after the timed region, measure K1's HBM bytes per launch in THIS run: two rocprofv3 --pmc passes "
                          "(FETCH_SIZE, WRITE_SIZE; kernel trace only) of a short --depth 1 run of the same workload; needs rocprofv3 "
-                         "on the box and takes about a minute.  Off: roofline.traffic is the committed figure of the same kernel")
+                         "on the box and takes about a minute.  On by default for the full line (N = 1, CPU baseline not skipped); "
+                         "when it cannot be measured roofline.traffic falls back to the committed figure of the same kernel and says so")
+    ap.add_argument("--no-measure-traffic", action="store_true", help="never start the rocprofv3 passes")
     ap.add_argument("--validate", action="store_true",
                     help="also run the parsers' checksum tests + repeat removal on the GPU (K5); only surviving hits are read back")
     ap.add_argument("--gather", choices=["validated", "raw"], default="validated",
@@ -758,7 +760,8 @@ def main():
                     traffic, rc = None, rc or 8
             except Exception:
                 traffic = None
-        if args.measure_traffic and world == 1:
+        full_line = world == 1 and not args.no_cpu_baseline and not distributed
+        if (args.measure_traffic or full_line) and not args.no_measure_traffic and world == 1:
             t_now, how = measure_traffic(args.workload, args.blocks, k1_full)
             if t_now is not None:
                 traffic, traffic_src = t_now, how

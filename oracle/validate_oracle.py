@@ -1,7 +1,7 @@
 """TEST INFRASTRUCTURE ONLY -- CPU restatement of the first steps of every rtlamr Parse loop, used to check the
 GPU's per-hit validation (rtlamr_amd/csrc/k5_validate.h).  Never imported by the product path.
 
-What is restated (bitwise CRC, no table, so it shares nothing with the kernel or with rtlamr_amd/parsers/crc.py):
+What is restated (bitwise CRC, no table, so it shares nothing with the kernel or with rtlamr_amd/contrib/parsers/crc.py):
   crc.Checksum / crc.NewTable   crc/crc.go:34-55   MSB-first CRC-16, no reflection, no final xor
   scm.Parser.Parse              scm/scm.go:61-90       seen[string(Bytes)], Checksum(Bytes[2:12]) != 0
   scmplus.Parser.Parse          scmplus/scmplus.go:62-92   Checksum(Bytes[2:16]) != Residue

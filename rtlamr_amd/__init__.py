@@ -8,6 +8,6 @@ library, and fails loudly otherwise.
 """
 from .protocol import (Data, Decoder, Message, PacketConfig, Parser, new_data, new_decoder,  # noqa: F401
                        new_parser, next_power_of_2, register_parser)
-from . import parsers  # noqa: F401  (registers scm, scm+, idm, netidm, r900, r900bcd configs)
+from .contrib import parsers  # noqa: F401  (registers scm, scm+, idm, netidm, r900, r900bcd configs)
 
 __version__ = "0.1.0"

@@ -1,6 +1,7 @@
-// What the K1 kernels share -- k1_tile.h (whole wave-tiles), k1_coop.h (one wave per block), and in the harness the first
-// generation (tools/k1_demod_gen1.h; K1Geom's RING / NW and AMR_K1_PIPE below are its) --: the launch arguments, the "tiled4" output layout, where a
-// wave-tile's rows start, the announcement to the gate, and the LDS-DMA of one staging tile.
+// What the K1 kernels share -- k1_tile.h (whole wave-tiles), k1_coop.h (one wave per block) --: the launch arguments, the
+// "tiled4" output layout, where a wave-tile's rows start, the announcement to the gate, and the LDS-DMA of one staging
+// tile.  (K1Geom's RING / NW and AMR_K1_PIPE are left from the first-generation kernel of rounds 1-2, which is in the
+// history: git log -- tools/k1_demod_gen1.h; the product uses K1Geom's halo arithmetic only.)
 //
 // Output layout ("tiled4"): word w of block b is stored at
 //     qt[(b/64 + 1) * 64*WPB + (w/4)*256 + (b%64)*4 + w%4],   WPB = BlockSize/32,
@@ -24,7 +25,7 @@
 #endif
 
 #ifndef AMR_K1_PIPE
-#define AMR_K1_PIPE 0   // first-generation kernel only (tools/k1_demod_gen1.h); K1Geom::NW below depends on it
+#define AMR_K1_PIPE 0   // first-generation kernel only (in the history); K1Geom::NW below depends on it
 #endif
 
 // diagnostic builds (make EXTRA=-DAMR_K1T_CLK=1, tools/build_variant.sh): per-workgroup clock stamps of k1t_demod

@@ -1,5 +1,5 @@
 // K1 -- MagLUT.Execute + Decoder.Filter + pack (protocol/decode.go:219-245; one lane = one reference block, same operation
-// order and roundings), organised around what bounded the first kernel (tools/k1_demod_gen1.h) on MI355X: with two waves per SIMD nothing hides a stall, so the kernel
+// order and roundings), organised around what bounded the first-generation kernel (rounds 1-2; in the history) on MI355X: with two waves per SIMD nothing hides a stall, so the kernel
 //   1. keeps the staging tile in REGISTERS.  A tile (64 rows x 128 B) that has landed in LDS is drained into 32 VGPRs in
 //      one burst at the tile boundary (the same eight ds_read_b128 the old kernel spread over the tile), which frees its
 //      LDS buffer a whole tile-time early: the DMA of the tile after next goes out at once and is in flight during the

@@ -77,13 +77,13 @@ class Message:
     def Checksum(self) -> bytes: raise NotImplementedError
 
     # csv.Recorder (parse.go:83) and fmt.Stringer: the columns main.go's CSV / JSON / plain encoders print.  Off the hot
-    # path and optional: the formats live in rtlamr_amd/parsers/record.py, loaded on first use
+    # path and optional: the formats live in rtlamr_amd/contrib/parsers/record.py, loaded on first use
     def Record(self) -> List[str]:
-        from .parsers import record
+        from .contrib.parsers import record
         return record.record(self)
 
     def __str__(self):
-        from .parsers import record
+        from .contrib.parsers import record
         return record.string(self)
 
 

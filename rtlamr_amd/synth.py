@@ -143,7 +143,7 @@ def plant_chips(iq: np.ndarray, start: int, chips: Sequence[int], chip_length: i
 
 def r900_chips(preamble: str, symbols: Sequence[int]) -> List[int]:
     """Chips of one r900 burst: Manchester preamble (bit 1 = high,low) followed by the 6-ary payload symbols."""
-    from .parsers.r900 import symbols_to_chips
+    from .contrib.parsers.r900 import symbols_to_chips
     chips: List[int] = []
     for b in preamble:
         chips.extend((1, 0) if b == "1" else (0, 1))

@@ -43,7 +43,7 @@ def sample_bin_vectors():
     d = OracleDecoder(["scm"], 78)
     nb = raw.size // d.geom.block_size2
     q, hits, hb = d.decode_stream(raw[: nb * d.geom.block_size2], mode=1)
-    from rtlamr_amd.parsers.crc import CRC
+    from rtlamr_amd.contrib.parsers.crc import CRC
     bch = CRC("BCH", 0, 0x6F63, 0)
     valid = sorted({bytes(b).hex() for b in hb if bch.Checksum(bytes(b[2:12])) == 0})
     out["chip78_semantic"] = {"ones": int(np.unpackbits(q).sum()), "qsha": sha(q), "n_hits": int(len(hits)),

@@ -8,7 +8,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 import rtlamr_amd as ra
 from rtlamr_amd import _lib, synth
-from rtlamr_amd.parsers import r900
+from rtlamr_amd.contrib.parsers import r900
 from oracle.oracle import OracleDecoder, R900Filter, PROTOCOLS
 
 chip, reps = 72, 8

@@ -91,7 +91,7 @@ def test_end_to_end_messages_scm():
         msgs = dec.Decode(iq)
         ids = {m.ID for m in msgs}
         want = {int.from_bytes(p.data, "big") for p in pkts}
-        from rtlamr_amd.parsers.scm import SCM
+        from rtlamr_amd.contrib.parsers.scm import SCM
         import rtlamr_amd as ra
         want_ids = {SCM.from_data(ra.new_data(p.data)).ID for p in pkts}
         assert want_ids <= ids, f"planted meters not all recovered: missing {want_ids - ids}"
@@ -126,7 +126,7 @@ def test_committed_golden_fixtures():
 def test_device_generator_matches_numpy_twin():
     import ctypes as C
     from rtlamr_amd import _lib, synth
-    from rtlamr_amd.parsers.scm import build_packet
+    from rtlamr_amd.contrib.parsers.scm import build_packet
     L = _lib.lib()
     n = 1 << 18
     first = 123456

@@ -6,7 +6,7 @@ import pytest
 
 from oracle import r900_oracle
 from rtlamr_amd import synth
-from rtlamr_amd.parsers import r900
+from rtlamr_amd.contrib.parsers import r900
 from tests import util
 
 pytestmark = pytest.mark.gpu

@@ -38,7 +38,7 @@ def test_hip_equals_translated_reference(protos, chip, n_blocks, batches):
         if "r900" in protos:          # bursts with the r900 preamble (the packet builders above cover the other protocols)
             from oracle.oracle import PROTOCOLS
             from rtlamr_amd import synth
-            from rtlamr_amd.parsers import r900 as pr900
+            from rtlamr_amd.contrib.parsers import r900 as pr900
             for j in range(4):
                 chips = synth.r900_chips(PROTOCOLS["r900"][0], pr900.build_r900_symbols(300 + j, consumption=j))
                 synth.plant_chips(iq, (7 + 45 * j) * dec.Cfg.BlockSize + 5 * j, chips, chip, 34, -29)

@@ -124,7 +124,7 @@ def test_pipelined_r900_searches_every_batch_once(protos, depth):
     import ctypes as C
     import re
     from rtlamr_amd import _lib, synth
-    from rtlamr_amd.parsers import r900 as pr900
+    from rtlamr_amd.contrib.parsers import r900 as pr900
     from oracle.oracle import PROTOCOLS
     L = _lib.lib()
     chip = 72
@@ -181,7 +181,7 @@ def test_sharded_run_equals_single_decoder_every_byte(protos, chip):
     equals the single decoder's, i.e. the oracle's."""
     from rtlamr_amd import dist as shard
     from rtlamr_amd import synth
-    from rtlamr_amd.parsers import r900 as pr900
+    from rtlamr_amd.contrib.parsers import r900 as pr900
     from oracle.oracle import PROTOCOLS
     probe = util.make_decoder(protos, chip)
     bs, bs2, ps = probe.Cfg.BlockSize, probe.Cfg.BlockSize2, probe.Cfg.PacketSymbols

@@ -10,7 +10,7 @@ import rtlamr_amd as ra
 from oracle import r900_oracle, validate_oracle as vo
 from oracle.oracle import PROTOCOLS
 from rtlamr_amd import _lib, synth
-from rtlamr_amd.parsers import r900
+from rtlamr_amd.contrib.parsers import r900
 from tests import util
 
 pytestmark = pytest.mark.gpu

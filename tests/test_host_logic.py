@@ -4,9 +4,9 @@ import pytest
 
 import rtlamr_amd as ra
 from rtlamr_amd import dist, synth
-from rtlamr_amd.parsers.crc import CRC
-from rtlamr_amd.parsers.idm import IdmParser, NetIdmParser, ScmPlusParser, build_idm_packet, build_scmplus_packet
-from rtlamr_amd.parsers.scm import SCM, ScmParser, build_packet
+from rtlamr_amd.contrib.parsers.crc import CRC
+from rtlamr_amd.contrib.parsers.idm import IdmParser, NetIdmParser, ScmPlusParser, build_idm_packet, build_scmplus_packet
+from rtlamr_amd.contrib.parsers.scm import SCM, ScmParser, build_packet
 
 
 def test_new_data_bits_and_copy():  # parse.go:61-69
@@ -143,9 +143,9 @@ def test_message_records_have_the_reference_columns():
     intervals; netidm (netidm/netidm.go:186-235): 15 + 27; hex fields zero-padded upper case, byte-slice fields as plain
     hex, the serial right-aligned in String; scm (scm/scm.go:139-154), scm+ (scmplus/scmplus.go:129-150), r900
     (r900/r900.go:278-302): Record uses strconv's lower-case unpadded hex, String fmt's padded upper case."""
-    from rtlamr_amd.parsers.idm import IDM, NetIDM, SCMPlus
-    from rtlamr_amd.parsers.r900 import R900
-    from rtlamr_amd.parsers.scm import SCM
+    from rtlamr_amd.contrib.parsers.idm import IDM, NetIDM, SCMPlus
+    from rtlamr_amd.contrib.parsers.r900 import R900
+    from rtlamr_amd.contrib.parsers.scm import SCM
     m = IDM(0x555516A3, 0x1C, 0x5C, 0xC6, 4, 7, 12345678, 3, 0xBC, bytes([1, 2, 3, 4, 5, 6]), 0x12, bytes(6), 99,
             list(range(47)), 17, 0xABCD, 0x1D0F)
     r = m.Record()
@@ -167,7 +167,7 @@ def test_message_records_have_the_reference_columns():
     w = R900(ID=1234, Unkn1=0xA3, NoUse=5, BackFlow=1, Consumption=99, Unkn3=2, Leak=3, LeakNow=0, checksum=b"\x01\x02")
     assert w.Record() == ["1234", "163", "5", "1", "99", "2", "3", "0"]
     assert str(w) == "{ID:      1234 Unkn1:0xA3 NoUse: 5 BackFlow:1 Consumption:      99 Unkn3:0x02 Leak: 3 LeakNow:0}"
-    from rtlamr_amd.parsers.r900 import R900BCD
+    from rtlamr_amd.contrib.parsers.r900 import R900BCD
     b = R900BCD(ID=1234, Unkn1=0xA3, NoUse=5, BackFlow=1, Consumption=99, Unkn3=2, Leak=3, LeakNow=0, checksum=b"\x01\x02")
     assert b.MsgType() == "R900BCD" and b.Record() == w.Record() and str(b) == str(w)     # r900bcd.go:39-45: embedded R900
 

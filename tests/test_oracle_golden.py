@@ -93,7 +93,7 @@ def test_sample_bin_true_chip_length_decodes_crc_valid_packets():
     q, hits, hb = d.decode_stream(raw[: nb * d.geom.block_size2], mode=1)
     assert sha(q) == "fd3c816bf2dad42c8566115024f5430a76ee83fad93fccd95b36f26f884303bf"
     assert len(hits) == 853
-    from rtlamr_amd.parsers.crc import CRC
+    from rtlamr_amd.contrib.parsers.crc import CRC
     bch = CRC("BCH", 0, 0x6F63, 0)
     valid = {bytes(b).hex() for b in hb if bch.Checksum(bytes(b[2:12])) == 0}
     assert len(valid) == 14

@@ -4,7 +4,7 @@ import numpy as np
 
 from oracle import r900_oracle
 from rtlamr_amd import synth
-from rtlamr_amd.parsers import gf, r900
+from rtlamr_amd.contrib.parsers import gf, r900
 
 
 def test_gf32_tables_and_syndrome_of_built_codeword():
@@ -90,7 +90,7 @@ def test_r900bcd_parser_rereads_consumption_as_bcd():
     """r900bcd/r900bcd.go:47-72: same parser, Consumption = decimal reading of its hex digits; MsgType R900BCD."""
     import numpy as np
     import rtlamr_amd as ra
-    from rtlamr_amd.parsers import r900
+    from rtlamr_amd.contrib.parsers import r900
     syms = r900.build_r900_symbols(987654, consumption=0x123456)
     digits = np.array([d for s in syms for d in (s // 6, s % 6)], np.uint8)
     pkt = ra.new_data(bytes(15))

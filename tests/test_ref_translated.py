@@ -86,7 +86,7 @@ def test_lut_geometry_next_power_of_2_crc():
     for v in list(range(1, 5000)) + [2 ** k + d for k in range(12, 30) for d in (-1, 0, 1)]:
         assert ref.next_power_of_2(v) == next_power_of_2(v), v
     from oracle import validate_oracle as vo
-    from rtlamr_amd.parsers.crc import CRC
+    from rtlamr_amd.contrib.parsers.crc import CRC
     rng = np.random.default_rng(1)
     for init, poly in ((0, 0x6F63), (0xFFFF, 0x1021)):
         for _ in range(200):
@@ -232,7 +232,7 @@ def test_stale_bits_of_slice_come_from_the_translated_source():
     byte of a packet carries bits of earlier hits.  The translated Slice must show the effect, and the oracle -- and
     with it the GPU's k_stale_bits -- must reproduce every one of those bytes."""
     from rtlamr_amd import synth
-    from rtlamr_amd.parsers import r900 as pr900
+    from rtlamr_amd.contrib.parsers import r900 as pr900
     for protos, chip in ((["r900"], 8), (["scm", "r900"], 32), (["r900", "scm"], 72)):
         g = OracleDecoder(protos, chip).geom
         assert g.packet_symbols % 8 == 4
@@ -276,8 +276,8 @@ def test_r900_filter_every_call_and_signal_history():
     gf/gf.go) against the Python mirror fed with the numpy oracle's digits (what the GPU's K4 is checked with)."""
     from oracle import r900_oracle
     from rtlamr_amd import synth
-    from rtlamr_amd.parsers import gf
-    from rtlamr_amd.parsers import r900 as pr900
+    from rtlamr_amd.contrib.parsers import gf
+    from rtlamr_amd.contrib.parsers import r900 as pr900
     field = gf.Field(32, 37, 2)
     mids = (11111, 22222222, 3333333333)
     for protos, chip in ((["r900"], 72), (["scm", "r900"], 8), (["r900", "idm"], 32)):
@@ -314,7 +314,7 @@ def test_r900_filter_every_call_and_signal_history():
 
 def test_messages_of_translated_parsers_equal_the_python_mirrors():
     """a13 + the parsers behind it: what the translated scm / scm+ / idm / netidm parsers send on the message channel
-    (MsgType, MeterID, MeterType, Checksum, Record()) against rtlamr_amd/parsers run over the ORACLE's hit lists --
+    (MsgType, MeterID, MeterType, Checksum, Record()) against rtlamr_amd/contrib/parsers run over the ORACLE's hit lists --
     the mirrors every GPU test and every bench.py run use to recover their planted packets."""
     import rtlamr_amd as ra
     for protos, chip in ((["scm"], 72), (["scm+", "scm"], 32), (["idm", "netidm"], 72), (["scm", "scm+", "idm", "r900"], 8)):

@@ -3,9 +3,9 @@ own test property and known values, the host-side table CRC against it, and the 
 import numpy as np
 
 from oracle import validate_oracle as vo
-from rtlamr_amd.parsers.crc import CRC
-from rtlamr_amd.parsers.idm import build_idm_packet, build_scmplus_packet
-from rtlamr_amd.parsers.scm import build_packet
+from rtlamr_amd.contrib.parsers.crc import CRC
+from rtlamr_amd.contrib.parsers.idm import build_idm_packet, build_scmplus_packet
+from rtlamr_amd.contrib.parsers.scm import build_packet
 
 
 def test_identity_property_of_reference_crc_test():
@@ -59,7 +59,7 @@ def test_filter_drops_failed_and_adjacent_repeats_only():
 
 
 def test_parser_validators_state_the_same_rules_as_the_oracle():
-    """rtlamr_amd/parsers/*.VALIDATOR (what Decoder.EnableValidation hands to amr_set_validation) against the
+    """rtlamr_amd/contrib/parsers/*.VALIDATOR (what Decoder.EnableValidation hands to amr_set_validation) against the
     independently written rule table of oracle/validate_oracle.py."""
     import rtlamr_amd as ra
     for name, (nbytes, checks) in vo.RULES.items():
@@ -72,7 +72,7 @@ def test_parser_validators_state_the_same_rules_as_the_oracle():
 def test_netidm_message_layout():
     """netidm.NewNetIDM (netidm/netidm.go:133-161) on a packet with known field bytes."""
     import rtlamr_amd as ra
-    from rtlamr_amd.parsers.idm import NetIdmParser
+    from rtlamr_amd.contrib.parsers.idm import NetIdmParser
     pkt = bytearray(build_idm_packet(0x01020304, ert_type=7))
     pkt[25:28] = (0x0A0B0C).to_bytes(3, "big")     # LastConsumption
     pkt[28:31] = (0x0D0E0F).to_bytes(3, "big")     # LastGeneration

@@ -6,8 +6,8 @@ import numpy as np
 import rtlamr_amd as ra
 from oracle.oracle import PROTOCOLS, OracleDecoder
 from rtlamr_amd import synth
-from rtlamr_amd.parsers.idm import build_idm_packet, build_scmplus_packet
-from rtlamr_amd.parsers.scm import build_packet
+from rtlamr_amd.contrib.parsers.idm import build_idm_packet, build_scmplus_packet
+from rtlamr_amd.contrib.parsers.scm import build_packet
 
 
 def load_capture() -> np.ndarray:

@@ -14,7 +14,6 @@
 #include <cstdlib>
 #include <string>
 #include <vector>
-#include "k1_demod_gen1.h"     // the first-generation kernel ("old"): the harness keeps it as a second opinion
 #include "k1_tile.h"
 #include "synth.h"
 
@@ -50,20 +49,11 @@ void launch_tile(const amr::K1Args &a0, uint32_t full, uint32_t rem, hipEvent_t 
     if (full) { a.wg_first = 0; hipExtLaunchKernelGGL((amr::k1t_demod<CL, false, C>), dim3(full), dim3(64), C::kLds, 0, e0, rem ? nullptr : e1, 0, a); }
     if (rem) { a.wg_first = full; hipExtLaunchKernelGGL((amr::k1t_demod<CL, true, C>), dim3(1), dim3(64), C::kLds, 0, full ? nullptr : e0, e1, 0, a); }
 }
-void launch_old(const amr::K1Args &a0, uint32_t full, uint32_t rem, hipEvent_t e0, hipEvent_t e1)
-{
-    amr::K1Args a = a0;
-    constexpr int CL = K1B_CL;
-    if (full) { a.wg_first = 0; hipExtLaunchKernelGGL((amr::k1_demod<CL, false>), dim3(full), dim3(64), 0, 0, e0, rem ? nullptr : e1, 0, a); }
-    if (rem) { a.wg_first = full; hipExtLaunchKernelGGL((amr::k1_demod<CL, true>), dim3(1), dim3(64), 0, 0, full ? nullptr : e0, e1, 0, a); }
-}
-
 // name = s<SCHED>p<DEPTH>x<XCD>n<NW>
 #ifndef K1B_VARIANTS
 #define K1B_VARIANTS V(1,1,1,16) V(1,1,0,16) V(0,1,1,16) V(1,2,1,16) V(1,1,1,32) V(1,1,1,8)
 #endif
 static const Variant kVariants[] = {
-    {"old", launch_old},
 #define V(S, P, X, N) {"s" #S "p" #P "x" #X "n" #N, launch_tile<amr::K1TCfg<S, P, X, N>>},
 #define D(S, P, X, N, DG) {"s" #S "p" #P "x" #X "n" #N "d" #DG, launch_tile<amr::K1TCfg<S, P, X, N, DG>>},
 #define W(S, P, X, N, POL, AFT) {"s" #S "p" #P "x" #X "n" #N "w" #POL "a" #AFT, launch_tile<amr::K1TCfg<S, P, X, N, 0, POL, AFT>>},
