@@ -5,10 +5,13 @@
  * cpu_baseline leg of bench.py may load this.  The product path
  * (rtlamr_amd/, libamrdemod.so) never links, imports or calls it.
  *
- * PARITY UNPINNED BY THE REFERENCE: the reference ships no test, golden vector
- * or known-answer fixture for protocol/decode.go, and there
- * is no Go toolchain in the build image, so the Go code itself cannot be run.
- * This restatement is pinned instead against
+ * PARITY UNPINNED BY THE REFERENCE'S OWN TESTS: the reference ships no test,
+ * golden vector or known-answer fixture for protocol/decode.go (SURVEY.md
+ * section 4), and there is no Go toolchain in the build image, so the Go binary
+ * itself cannot be run.  This restatement is pinned instead against
+ *   (o)  oracle/_ref: the reference's OWN Go sources translated mechanically to
+ *        C++ (oracle/go2cxx) -- every committed golden and 1 040 random streams,
+ *        tests/test_ref_translated.py (round 6; not the Go toolchain: DESIGN.md 2),
  *   (i)  the derived golden hashes of SURVEY.md section 8c (two independent
  *        restatements, numpy and C, agreed on them during the survey),
  *   (ii) an independent numpy restatement (oracle/np_oracle.py), and

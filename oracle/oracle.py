@@ -5,8 +5,9 @@ tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg; never by the
 product package rtlamr_amd.
 
 Parity status: UNPINNED by the reference's own tests (there are none for
-protocol/decode.go); pinned against SURVEY.md section 8c derived vectors and the
-numpy restatement in np_oracle.py.
+protocol/decode.go); pinned against oracle/_ref (the reference's Go sources,
+translated mechanically: oracle/go2cxx, tests/test_ref_translated.py), SURVEY.md
+section 8c derived vectors and the numpy restatement in np_oracle.py.
 """
 from __future__ import annotations
 
