@@ -83,7 +83,7 @@ type Decoder struct {
 	// (the reference caller is one process, main.go:59-128): Allocate opens a handle per device and joins them in one
 	// RCCL communicator (amr_comm_init_all: the grouped form a single thread needs), and every Decode call's blocks are
 	// cut into len(Devices) contiguous ranges, range r decoded on Devices[r] after priming it with the blocks in front of
-	// the range (amr_prime) -- the split SURVEY.md 8e describes, results identical to one device's.  Empty: Device alone.  (KeepQuantized reads back handle 0's range only: a
+	// the range (amr_prime) -- the split SURVEY.md 8e describes, results identical to one device's (except the never-cleared high bits of a range's first packet's last byte when PacketSymbols%8 != 0: decodeOnDevices).  Empty: Device alone.  (KeepQuantized reads back handle 0's range only: a
 	// diagnostic, use one device for it.)
 	Devices []int
 
@@ -346,6 +346,13 @@ func (d Decoder) Decode(input []byte) chan Message {
 // any is collected: the devices run side by side, driven by this one thread.  The hit records come back per handle
 // (host memory, `take`); a host that wants them merged on one device instead -- a replay loop that consumes validated
 // records one step behind, like bench.py -- posts amr_gather_hits_all on the same handles (INTEGRATION.md).
+//
+// Cost and limits.  Every call re-primes every device that has blocks (amr_prime_blocks blocks each): Devices is for
+// callers that hand Decode MANY blocks per call (nBlocks >> len(Devices) * amr_prime_blocks); with the unchanged
+// one-block-per-call loop of main.go:235 use one device.  One thing differs from a single device: amr_reset zeroes the
+// byte Decoder.Slice never clears (decode.go:363-366), so with PacketSymbols%8 != 0 (r900 alone or with scm) the high bits
+// of the LAST byte of each range's first hit start from zero instead of continuing the previous hit's -- parsers never
+// read those bits; a caller that needs them patches with the rule of amr_set_stale_carry (include/amrdemod.h).
 func (d Decoder) decodeOnDevices(input []byte, nBlocks int, first uint64, take func(*C.amr_result)) {
 	s := d.st
 	bs2 := d.Cfg.BlockSize2
@@ -381,6 +388,9 @@ func (d Decoder) decodeOnDevices(input []byte, nBlocks int, first uint64, take f
 	}
 	for r, h := range s.hs {
 		k0, k1 := ranges[r][0], ranges[r][1]
+		if k1 == k0 { // fewer blocks than devices: nothing to reset, prime or submit on this one (ADVICE r05)
+			continue
+		}
 		if st := C.amr_reset(h); st != C.AMR_OK {
 			fatal("amr_reset", st)
 		}
