@@ -294,6 +294,7 @@ class Emitter:
         self.fn = None
         self.tmp = 0
         self.iota = None
+        self.embedded_names = set()
 
     # ---------- helpers
     def fresh(self, base="_t"):
@@ -476,6 +477,8 @@ class Emitter:
             p = self.resolve_pkg(n.x)
             if p is not None:
                 return f"{p[0]}::{mangle(n.sel)}"
+            if n.sel in self.embedded_names:
+                return f"go_sel_{mangle(n.sel)}(go::deref({self.ex(n.x, True)}))"
             return f"go::deref({self.ex(n.x, True)}).{mangle(n.sel)}"
         if k == "index":
             inner = f"{self.ex(n.x, True)}[{self.ex(n.index)}]"
@@ -1224,6 +1227,8 @@ class Emitter:
             for f in t.fields:
                 if f.embedded and f.type.kind == "tname":
                     bases.append(self.ty(f.type))
+                    # the embedded field selected by NAME (x.T): a cast to the base, found through this typedef (go_sel_T below)
+                    fields.append(f"    using go_emb_{mangle(f.name)} = {bases[-1]};")
                 elif f.name == "_":
                     continue
                 else:
@@ -1348,10 +1353,28 @@ class Emitter:
         return "\n".join(out)
 
     # ---------- whole program
+    def find_embedded_names(self):
+        names = set()
+        for k in self.reach.keys:
+            if k[0] == "type":
+                t = self.prog.packages[k[1]].types[k[2]].type
+                if t.kind == "tstruct":
+                    names |= {f.name for f in t.fields if f.embedded and f.type.kind == "tname"}
+        return names
+
     def emit(self, banner):
         keys = self.reach.keys
+        self.embedded_names = self.find_embedded_names()
         pkgs = self.package_order()
         out = [banner, "#pragma once", '#include "gort.hpp"', ""]
+        # x.T where T names an embedded VALUE field of some struct: embedded structs / interfaces are C++ bases (that is what
+        # promotes their fields and methods), so the selection is a cast to the base; where T is an ordinary member it is that
+        for nm in sorted(self.embedded_names):
+            m = mangle(nm)
+            out.append(f"template <class T_> decltype(auto) go_sel_{m}(T_&& o) {{\n"
+                       f"    if constexpr (requires {{ o.{m}; }}) return (o.{m});\n"
+                       f"    else return static_cast<std::conditional_t<std::is_const_v<std::remove_reference_t<T_>>, "
+                       f"const typename std::remove_cvref_t<T_>::go_emb_{m}, typename std::remove_cvref_t<T_>::go_emb_{m}>&>(o);\n}}")
         # A. forward declarations
         for pkg in pkgs:
             names = sorted(k[2] for k in keys if k[0] == "type" and k[1] == pkg.path and not pkg.types[k[2]].alias)

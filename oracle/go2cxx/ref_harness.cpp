@@ -65,6 +65,7 @@ P_protocol::Parser make_parser(const std::string& name, int chip, Ref* r) {
         r->r900 = go::type_assert<P_r900::Parser*>(p);
         return p;
     }
+    if (name == "r900bcd") return P_r900bcd::NewParser(cl);   // wraps r900.NewParser (r900bcd.go:35-37); its r900 buffers are not exposed
     return P_protocol::Parser();
 }
 

@@ -1,5 +1,5 @@
 """ctypes front-end of oracle/_ref/libref.so: the reference's OWN Go sources (protocol/, scm/, scmplus/, idm/, netidm/,
-r900/, r900/gf/, crc/), translated mechanically to C++ by oracle/go2cxx and built by `make -C oracle _ref`.
+r900/, r900/gf/, r900bcd/, crc/), translated mechanically to C++ by oracle/go2cxx and built by `make -C oracle _ref`.
 
 TEST INFRASTRUCTURE ONLY.  Loaded by tests/test_ref_translated.py to hold oracle/decode_oracle.c (and through it the
 HIP path) to code that DESCENDS FROM THE REFERENCE SOURCE TEXT rather than from a reading of it.  Never imported by
@@ -108,7 +108,7 @@ def parse_messages(text: str) -> List[Tuple[int, str, int, int, str, List[str]]]
 
 class RefDecoder:
     """protocol.NewDecoder + <pkg>.NewParser per protocol + RegisterProtocol + Allocate, all translated reference code.
-    protocols: names among scm, scm+, idm, netidm, r900 (the reference's own parser packages supply their configs)."""
+    protocols: names among scm, scm+, idm, netidm, r900, r900bcd (the reference's own parser packages supply their configs)."""
 
     def __init__(self, protocols, chip_length: int):
         L = lib()

@@ -291,3 +291,25 @@ func Structs() string {
 	cp.p.b = 8 // shared through the pointer
 	return fmt.Sprintf("%d %d %d [%d %d] %d %d", o.in.a, o.in.b, o.p.a, o.arr[1].a, o.arr[1].b, cp.in.a, o.p.b)
 }
+
+// Embedded structs and interfaces: promoted fields and methods, the embedded field selected by name, an outer method
+// shadowing a promoted one, a type assertion back to the concrete type.  Want "sq 9 sq! 9 7 7 8 true".
+type namer interface{ Name() string }
+type tagged struct {
+	square
+	tag int
+}
+type loud struct{ namer }
+
+func (l loud) Name() string { return l.namer.Name() + "!" }
+
+func Embedding() string {
+	t := tagged{square{3}, 7}
+	var n namer = t // tagged has Name() through the embedded square
+	l := loud{n}
+	back := n.(tagged)
+	t.s = 1        // promoted field; `back` is a copy made before
+	t.square.s = 8 // the same field through the embedded struct's name
+	_, isCircle := n.(*circle)
+	return fmt.Sprintf("%s %d %s %d %d %d %d %t", n.Name(), back.Area(), l.Name(), back.square.Area(), back.tag, t.tag, t.s, !isCircle)
+}

@@ -345,3 +345,47 @@ def test_messages_of_translated_parsers_equal_the_python_mirrors():
             assert got == sorted(want), (protos, chip, k)
             n_msgs += len(got)
         assert n_msgs >= 6
+
+
+def test_r900bcd_wrapper_parser():
+    """r900bcd/r900bcd.go: a parser that embeds the protocol.Parser interface value of r900.NewParser, runs it on a channel
+    of its own in two goroutines, asserts its messages back to r900.R900 and re-reads Consumption's hex digits as decimal
+    (a hex letter: ParseUint fails and Go keeps 0).  Translated source vs the Python mirror fed with the numpy oracle's digits."""
+    from oracle import r900_oracle
+    from rtlamr_amd import synth
+    from rtlamr_amd.contrib.parsers import gf
+    from rtlamr_amd.contrib.parsers import r900 as pr900
+    import rtlamr_amd as ra
+    chip = 72
+    r = ref.RefDecoder(["r900bcd"], chip)
+    g = OracleDecoder(["r900"], chip).geom
+    assert r.geom["packet_symbols"] == 116 and r.preambles == [PROTOCOLS["r900"][0]]      # it reports r900's configuration
+    burst = (64 + 168) * chip
+    cons = (0x123456, 0x2b67, 0x000999)                                                  # decimal digits / a hex letter / leading zeros
+    n_blocks = (10 * burst + 2 * g.packet_length) // g.block_size + 4
+    iq = synth.noise(n_blocks * g.block_size, 77)
+    for j, c in enumerate(cons):
+        chips = synth.r900_chips(PROTOCOLS["r900"][0], pr900.build_r900_symbols(9000 + j, consumption=c))
+        synth.plant_chips(iq, burst // 2 + 3 * j * burst + 11 * j, chips, chip, 34, -29)
+    _, _, _, msgs = r.decode_stream(iq)
+    got = [(m[0], m[1], m[2], tuple(m[5])) for m in msgs]
+    hits, digits = r900_oracle.digits_for_stream(["r900"], chip, iq)
+    p = ra.new_parser("r900bcd", chip)
+    want, last, batch = [], -1, []
+
+    def flush(k, batch):
+        for m in p.Parse(batch):
+            want.append((k, m.MsgType(), m.MeterID(), tuple(m.Record())))
+    for (k, _), d in zip(hits.tolist(), digits):
+        if k != last and batch:
+            flush(last, batch)
+            batch = []
+        last = k
+        pkt = ra.new_data(bytes(15))
+        pkt.Digits = d
+        batch.append(pkt)
+    if batch:
+        flush(last, batch)
+    assert got == want and {m[1] for m in got} == {"R900BCD"}
+    by_id = {m[2]: m[3][4] for m in got}                                                 # Record()[4] = Consumption
+    assert by_id == {9000: "123456", 9001: "0", 9002: "999"}
