@@ -197,7 +197,7 @@ def measure_traffic(spec: str, blocks: int, k1_full: str):
                    os.path.abspath(__file__), "--workload", spec, "--steps", "3", "--warmup", "1", "--depth", "1", "--k1-events", "0",
                    "--no-cpu-baseline", "--no-verify", "--spinup-ms", "0", "--device-state", "off", "--no-measure-traffic"] + (["--blocks", str(blocks)] if blocks else [])
             try:
-                subprocess.run(cmd, cwd="/tmp", env=env, capture_output=True, timeout=240)
+                subprocess.run(cmd, cwd="/tmp", env=env, capture_output=True, timeout=150)
             except Exception as e:
                 return None, f"rocprofv3 --pmc {ctr} failed: {e}"
             got = collections.defaultdict(list)
@@ -760,7 +760,9 @@ def main():
                     traffic, rc = None, rc or 8
             except Exception:
                 traffic = None
-        full_line = world == 1 and not args.no_cpu_baseline and not distributed
+        # (never from inside a profiler: a nested rocprofv3 inherits the outer one's tool libraries)
+        profiled = any(k.startswith(("ROCPROF", "ROCP_")) for k in os.environ) or "rocprofiler" in os.environ.get("LD_PRELOAD", "")
+        full_line = world == 1 and not args.no_cpu_baseline and not distributed and not profiled
         if (args.measure_traffic or full_line) and not args.no_measure_traffic and world == 1:
             t_now, how = measure_traffic(args.workload, args.blocks, k1_full)
             if t_now is not None:
