@@ -139,6 +139,8 @@ struct amr_handle {
     bool lazy_tail = false;
     uint64_t *d_tail_done = nullptr;   // device word: ticket of the last batch whose second-stream part has finished
     uint64_t *d_k1_started = nullptr;  // device word: ticket of the last batch whose K1 has all its waves on the chip (k_gate)
+    uint32_t *d_k1_ctr = nullptr;      // K1Args::started_ctr
+    uint32_t k1_ctr_total = 0;         // what the announcing launches so far add up to (wraps with the device word)
     uint64_t gate_timeout_ticks = 400000000ull;   // k_gate gives up after this many 100 MHz ticks (4 s; test hook AMR_GATE_TIMEOUT_US)
     uint64_t gate_timeouts = 0;   // batches searched again because their gate gave up (amr_describe)
     uint64_t researches = 0;      // batches searched again at collect, for any reason (amr_describe)
@@ -163,6 +165,8 @@ struct amr_handle {
     // as soon as the tail stream reaches it)
     uint32_t gate_delay_ticks = 600;
     bool gate_event = true;
+    int gate_end_mode = 0;       // A/B hook AMR_GATE_END (round 6, lost: profiles/r06/bs2048/): the tail behind the END of a one-launch K1 instead of
+                                 // behind a gate: 1 every one-launch batch, -1 those with more wave-tiles than the chip has slots, 0 never
     uint32_t k1_round_tiles = 0; // test hook AMR_K1_ROUND_TILES: wave-tiles per K1 launch (0: a chip's worth at BlockSize >= 4096, else one launch)
     uint64_t k1_coop_max = 0;    // batches of up to this many blocks run K1 as one wave per block throughout (k1_coop.h):
                                  // from kK1CoopMaxSamples / kK1CoopMaxBlocks; test hook AMR_K1_COOP_MAX (0: only the blocks

@@ -400,20 +400,39 @@ amr_status submit(amr_handle *h, const uint8_t *d_iq, size_t n_blocks, bool sear
     // profiles/r05/k1_gate_fragmentation.txt).
     const bool gate_ev = gate_prev && h->gate_event;
     hipEvent_t gate_wait = nullptr;
+    const uint32_t n_launches = all_coop ? 1u : (full ? (full + round - 1) / round : 0u) + (rem ? 1u : 0u);
+    // A batch whose ONE K1 launch runs several rounds (BlockSize <= 2048: 4096 .. 16384 wave-tiles on 2048 slots): its last
+    // workgroup starts with the last round, so a gate kernel would sit on the chip through all the rounds before it -- a
+    // one-wave kernel somewhere in a SIMD's register file while the dispatcher places K1 workgroups round after round (the
+    // fragmentation above, every round) -- and K3 would come in next to the last round's waves, which at these chip lengths
+    // leave it registers.  Measured at chip 40 (profiles/r06/bs2048/): K1 191 .. 254 us in the pipeline for 178 alone.  Here the
+    // tail waits for the END of that launch instead (its stop event, no gate kernel): K3.. then run next to this batch's search.
+    const bool gate_end = gate_prev && !all_coop && n_launches == 1 && !rem &&
+                          (h->gate_end_mode > 0 || (h->gate_end_mode < 0 && full > (uint32_t)h->n_cus * 8u));
+    // the announcing launch's share of the counter its last workgroups meet at (K1Args::started_ctr)
+    auto arm = [&](uint32_t grid) {
+        if (!k1_last.started) return;
+        h->k1_ctr_total += std::min(8u, grid);
+        k1_last.started_ctr = h->d_k1_ctr;
+        k1_last.started_target = h->k1_ctr_total;
+    };
     if (all_coop) {
+        arm((uint32_t)rows);
         amr::launch_k1_coop(h->geom.chip_length, 0u, (uint32_t)rows, st, k1_last, e0, e1);
     } else {
-        const uint32_t n_launches = (full ? (full + round - 1) / round : 0u) + (rem ? 1u : 0u);
         uint32_t li = 0;
         for (uint32_t w0 = 0; w0 < full; w0 += round, ++li) {
             const uint32_t n = std::min(round, full - w0);
             const bool last = w0 + n == full && !rem;
+            if (last) arm(n);
             amr::K1Args &kk = last ? k1_last : k1;
             kk.wg_first = w0;
             hipEvent_t stop = last ? e1 : nullptr;
             if (li + 2 == n_launches && gate_ev) { stop = s.ev_gate; gate_wait = s.ev_gate; }   // the launch in front of the announcing one
+            if (gate_end) { if (!stop) stop = s.ev_gate; gate_wait = stop; }                    // (one launch: this one)
             amr::launch_k1(h->geom.chip_length, dim3(n), st, kk, w0 == 0 ? e0 : nullptr, stop);
         }
+        if (rem) arm(rem);
         if (rem)     // the blocks behind the last whole wave-tile (sync callers, flush): a wave each
             amr::launch_k1_coop(h->geom.chip_length, full * 64u, rem, st, k1_last, full ? nullptr : e0, e1);
     }
@@ -439,9 +458,15 @@ amr_status submit(amr_handle *h, const uint8_t *d_iq, size_t n_blocks, bool sear
         // gate waits, as an event in front of it, for the end of what precedes the K1 launch it is about (gate_wait above):
         // by then the chip holds nothing but K1 waves (ranges at 0, 248 and 496), or nothing.
         if (gate_wait) HIP_TRY(hipStreamWaitEvent(h->tail_stream, gate_wait, 0));
-        hipLaunchKernelGGL(amr::k_gate, dim3(1), dim3(1), 0, h->tail_stream, h->d_k1_started, s.ticket, h->gate_delay_ticks,
-                           h->gate_timeout_ticks, prev.d_overflow);
-        HIP_TRY(hipGetLastError());
+        // (Round 6 tried hipStreamWaitValue64 on a signal word in its place, hoping for a wait the queue's packet processor does
+        // with nothing on the chip: this runtime implements it as a polling KERNEL of its own, __amd_rocclr_streamOpsWait --
+        // the same one wave, without this gate's timeout; cfg3 0.87 -> 0.99 ms per step without the event above.
+        // tools/waitvalue_probe.hip, profiles/r06/gate/.)
+        if (!gate_end) {
+            hipLaunchKernelGGL(amr::k_gate, dim3(1), dim3(1), 0, h->tail_stream, h->d_k1_started, s.ticket, h->gate_delay_ticks,
+                               h->gate_timeout_ticks, prev.d_overflow);
+            HIP_TRY(hipGetLastError());
+        }
         // (an early search ran on the search stream -- today the tail stream itself, then this wait is a no-op)
         if (prev.early) HIP_TRY(hipStreamWaitEvent(h->tail_stream, prev.ev_k2done, 0));
         AMR_TRY(launch_tail(h, prev));

@@ -148,6 +148,7 @@ amr_status amr_create(const amr_protocol *protos, int32_t n_protos, int32_t devi
     if (const char *cm = getenv("AMR_K1_COOP_MAX")) h->k1_coop_max = strtoull(cm, nullptr, 10);   // test hook / A-B
     if (const char *gd = getenv("AMR_GATE_DELAY_TICKS")) h->gate_delay_ticks = (uint32_t)strtoul(gd, nullptr, 10);   // A/B runs
     if (const char *ge = getenv("AMR_GATE_EVENT")) h->gate_event = ge[0] != '0';
+    if (const char *ge = getenv("AMR_GATE_END")) h->gate_end_mode = atoi(ge);   // A/B runs
     if (const char *rt = getenv("AMR_K1_ROUND_TILES")) h->k1_round_tiles = (uint32_t)strtoul(rt, nullptr, 10);   // test hook: batches of several K1 launches at test sizes
     // NewMagLUT, decode.go:209-216: float32 divide then float32 square, two roundings per entry.
     for (int i = 0; i < 256; ++i) {
@@ -172,9 +173,10 @@ amr_status amr_create(const amr_protocol *protos, int32_t n_protos, int32_t devi
     if (const char *es = getenv("AMR_EARLY_SEARCH")) h->early_mode = atoi(es) != 0 ? 1 : 0;
     if (e == hipSuccess) e = hipHostMalloc((void **)&h->h_flags, 16, hipHostMallocCoherent);
     if (e == hipSuccess) { h->h_flags[0] = 0; h->h_flags[1] = 0; }
-    if (e == hipSuccess) e = hipMalloc((void **)&h->d_tail_done, 16);
-    if (e == hipSuccess) e = hipMemset(h->d_tail_done, 0, 16);
+    if (e == hipSuccess) e = hipMalloc((void **)&h->d_tail_done, 32);
+    if (e == hipSuccess) e = hipMemset(h->d_tail_done, 0, 32);
     if (e == hipSuccess) h->d_k1_started = h->d_tail_done + 1;
+    if (e == hipSuccess) h->d_k1_ctr = reinterpret_cast<uint32_t *>(h->d_tail_done + 2);
     h->stream = h->own_stream;
     for (Slot &sl : h->slot) {
         if (e == hipSuccess) e = hipEventCreate(&sl.ev0);

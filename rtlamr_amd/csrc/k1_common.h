@@ -58,6 +58,12 @@ struct K1Args {
     // end of this launch instead of standing in front of it.  null: no announcement.
     uint64_t *started;
     uint64_t started_value;
+    // (round 6) ... when EVERY XCD has placed its last workgroup of the launch: the last min(8, grid) workgroups (one per XCD:
+    // workgroups go round the XCDs) count themselves in `started_ctr`, a device word that only ever grows; the one that
+    // brings it to `started_target` (the host adds up what each announcing launch contributes) stores the ticket.  The XCDs'
+    // dispatchers do not run in step: the last workgroup of the grid alone said nothing about the other seven.
+    uint32_t *started_ctr;
+    uint32_t started_target;
     // Early search (amr_pipeline.hip): the search of this batch runs off the compute stream, NEXT to this launch,
     // and takes a tile as soon as the waves that wrote it are done.  Every wave, at its end, waits for its stores (sc1:
     // written through, nothing stays dirty in the XCD's L2) and then stores done_value into done_flags[wave-tile]; the wave of
@@ -73,14 +79,20 @@ struct K1Args {
 
 __device__ __forceinline__ void k1_announce(const K1Args &a, uint32_t lane)
 {
-    // A store the optimiser cannot see (no "memory" clobber: it touches nothing this kernel reads), write-through (sc1) so
-    // that the gate's agent-scope load on another XCD finds it.  Written as __hip_atomic_store it makes hipcc give up
+    // A store the optimiser cannot see (no "memory" clobber: it touches nothing this kernel reads), system scope (sc0 sc1):
+    // the gate kernel reads the word with agent-scope loads on another XCD.  Written as __hip_atomic_store it makes hipcc give up
     // the scalar loads of the kernel arguments behind it: the DMA's base pointers then arrive in VGPR pairs, which the
     // "s" operands of the inline asm cannot take.
-    if (a.started && blockIdx.x == gridDim.x - 1 && lane == 0) {
-        uint64_t *p = a.started;
-        const uint64_t v = a.started_value;
-        asm volatile("global_store_dwordx2 %0, %1, off sc1" :: "v"(p), "v"(v));
+    if (a.started && blockIdx.x + 8 >= gridDim.x && lane == 0) {
+        uint32_t *c = a.started_ctr;
+        uint32_t old;
+        // (device-scope atomic with return, issued before any of the wave's DMA: the counted waits of the tile loop never see it)
+        asm volatile("global_atomic_add %0, %1, %2, off sc0 sc1\n\ts_waitcnt vmcnt(0)" : "=v"(old) : "v"(c), "v"(1u));
+        if (old + 1u == a.started_target) {
+            uint64_t *p = a.started;
+            const uint64_t v = a.started_value;
+            asm volatile("global_store_dwordx2 %0, %1, off sc0 sc1" :: "v"(p), "v"(v));
+        }
     }
 }
 

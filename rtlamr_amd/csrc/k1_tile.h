@@ -33,13 +33,19 @@
 #ifndef AMR_K1T_RING80
 #define AMR_K1T_RING80 88
 #endif
+#ifndef AMR_K1T_RING_OVR
+#define AMR_K1T_RING_OVR 0      // harness builds: any multiple of 8 above the chip length, for every chip length of the binary
+#endif
 
 namespace amr {
 
 #if AMR_K1T_CLK
 // diagnostic builds only: per workgroup of the last kK1TLaunches launches (K1Args::tl_seq picks the slot): 100 MHz start
 // tick, end tick, (XCC_ID << 32 | HW_ID)
-constexpr int kK1TLaunches = 64, kK1TWgs = 2048;
+#ifndef AMR_K1T_WGS
+#define AMR_K1T_WGS 2048    // workgroups stamped per launch (launches of several rounds: raise it)
+#endif
+constexpr int kK1TLaunches = 64, kK1TWgs = AMR_K1T_WGS;
 __device__ unsigned long long k1t_timeline[kK1TLaunches][kK1TWgs][3];
 #endif
 
@@ -111,7 +117,7 @@ struct K1TGeom {
     static constexpr int NPT = HBA / kTileBytes;       // halo tiles
     // csum rings: slot t % RING is written at step t and holds c[t] / d[t] until step t + CL reads it.  RING is the
     // smallest multiple of 8 above CL (chip 64: 80, not 72 -> a super-body of 5 tiles instead of 9; kept from round 2).
-    static constexpr int RING = (CL == 64) ? 80 : (CL == 80) ? AMR_K1T_RING80 : CL + 8;
+    static constexpr int RING = AMR_K1T_RING_OVR ? AMR_K1T_RING_OVR : (CL == 64) ? 80 : (CL == 80) ? AMR_K1T_RING80 : CL + 8;
     static constexpr int SPB = RING / k1t_gcd(RING, 64) * 64;   // samples per super-body
     static constexpr int TPS = SPB / 64;                         // tiles per super-body
     // (every legal chip length, flags.go:127-132, has a configuration: K1TCfgFor.  Round 2 stopped at 7 tiles per super-body
