@@ -74,9 +74,14 @@ __device__ unsigned long long k1t_timeline[kK1TLaunches][kK1TWgs][3];
 //        a group of 8 is produced, two ds_read_b128 one ring turn minus a chip later, fetched next to the LUT gathers).
 //        Costs parking space: chip 88's 8 KiB of hd leave 3 KiB for output chunks, i.e. four store bursts per 4096-sample
 //        block, chip 96's 10 KiB leave one (eight bursts).
-template <int SCHED_, int DEPTH_, int XCD_, int NW_, int DIAG_ = 0, int STPOL_ = 0, int STORE_AFTER_ = 0, int NLC_ = 0, int PRIO_ = 0, int HDL_ = 0>
+// HS     (round 6) halo shift, for chip lengths whose halo is ONE staging tile (4 * chip length <= 128: chip 8 .. 32).  The halo
+//        tile of row r is the LAST tile of row r - 1 -- and lane r - 1 of the same wave walks that row: every wave read 64 lines
+//        twice, at its start as halos and at its end as last tiles (chip 8: 9 tiles per 1 KiB row, 12.5 % of the traffic).
+//        1: a lane keeps its halo tile in 32 registers, and the wave's last tile comes from them -- lane r takes lane r + 1's
+//        (v_mov_b32 dpp wave_shl:1), only rows 56 .. 63 are fetched again (one DMA piece of eight) for lane 63.
+template <int SCHED_, int DEPTH_, int XCD_, int NW_, int DIAG_ = 0, int STPOL_ = 0, int STORE_AFTER_ = 0, int NLC_ = 0, int PRIO_ = 0, int HDL_ = 0, int HS_ = 0>
 struct K1TCfg {
-    static constexpr int SCHED = SCHED_, DEPTH = DEPTH_, XCD = XCD_, NW = NW_, DIAG = DIAG_, STPOL = STPOL_, STORE_AFTER = STORE_AFTER_, NLC = NLC_, PRIO = PRIO_, HDL = HDL_;
+    static constexpr int SCHED = SCHED_, DEPTH = DEPTH_, XCD = XCD_, NW = NW_, DIAG = DIAG_, STPOL = STPOL_, STORE_AFTER = STORE_AFTER_, NLC = NLC_, PRIO = PRIO_, HDL = HDL_, HS = HS_;
     static constexpr int CAP = NLC_ + NW_ / 4 + 1;               // chunks per full burst (LDS, registers, staging)
     static constexpr uint32_t kLut = DEPTH_ * kTileBuf;          // LDS byte offset of the LUT behind the tile buffer(s)
     static constexpr uint32_t kPark = DEPTH_ * kTileBuf + 1024;  // parked output chunks: chunk c of lane l at kPark + c * 1024 + l * 16
@@ -100,7 +105,17 @@ typedef K1TCfg<0, 1, 1, AMR_K1T_96> K1TChip96;
 #define AMR_K1T_80 8, 0, 1, 1, 9, 13, 8
 #endif
 typedef K1TCfg<0, 1, 1, AMR_K1T_80> K1TChip80;
+#ifndef AMR_K1T_HS
+#define AMR_K1T_HS 1      // 0: chip 8 without the halo shift (A/B builds)
+#endif
+typedef K1TCfg<0, 1, 1, 16, 0, 1, 1, 11, 13, 0, AMR_K1T_HS> K1TChip8;   // chip length 8: rows of 1 KiB, the halo tile is 12.5 % of them
 template <int CL> struct K1TCfgFor { typedef K1TDefault type; };
+template <> struct K1TCfgFor<8> { typedef K1TChip8 type; };
+#ifndef AMR_K1T_HS32
+#define AMR_K1T_HS32 1      // 0: chip 32 without the halo shift (A/B builds)
+#endif
+typedef K1TCfg<0, 1, 1, 16, 0, 1, 1, 11, 13, 0, AMR_K1T_HS32> K1TChip32;   // chip length 32: the halo tile is 3 % of a 4 KiB row
+template <> struct K1TCfgFor<32> { typedef K1TChip32 type; };
 template <> struct K1TCfgFor<80> { typedef K1TChip80 type; };
 template <> struct K1TCfgFor<88> { typedef K1TLongChip type; };
 template <> struct K1TCfgFor<96> { typedef K1TChip96 type; };
@@ -135,6 +150,7 @@ struct K1TLane {
     float hd[G::RING - C::HDL > 0 ? G::RING - C::HDL : 1];   // hd[t % RING] = c[t] - c[t-CL]; slots >= RING - HDL live in LDS
     float hdt[C::HDL ? 8 : 1];   // the eight hd values of the current group when they come from LDS
     uint32_t tl[32];     // the staging tile of this lane's row: 128 B = 64 IQ samples
+    uint32_t keep[C::HS ? 32 : 1];   // HS: the row's halo tile = the last tile of the row before it
     float lv[16];        // LUT values of 8 samples (lut[I], lut[Q] interleaved)
     uint32_t acc, prev;  // sign bits of f, newest in bit 0 (inverted decisions); acc at the last word boundary
     uint32_t xs;
@@ -350,6 +366,24 @@ __device__ __forceinline__ void k1t_dma_fast(const uint8_t *const (&sb)[8], uint
     }
 }
 
+// HS: the wave's LAST tile -- only the piece that holds row 63 (rows 56 .. 63); the other lanes take theirs from a neighbour's registers
+__device__ __forceinline__ void k1t_dma_last(const uint8_t *const (&sb)[8], uint32_t vt_o, uint32_t par)
+{
+    par = __builtin_amdgcn_readfirstlane(par);
+    asm volatile("s_add_u32 m0, %2, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1 " AMR_K1_LDFLAGS
+                 :: "v"(vt_o), "s"(sb[7]), "s"(par), "n"(7 * 1024)
+                 : "memory", "scc");
+}
+
+// HS: the last tile out of the halo tiles the lanes kept: lane r <- lane r + 1; lane 63 keeps what it drained from LDS (its own row)
+template <int CL, class C>
+__device__ __forceinline__ void k1t_halo_shift(K1TLane<CL, C> &L)
+{
+#pragma unroll
+    for (int k = 0; k < 32; ++k)
+        L.tl[k] = (uint32_t)__builtin_amdgcn_update_dpp((int)L.tl[k], (int)L.keep[k], 0x130 /* wave_shl:1 */, 0xf, 0xf, false);
+}
+
 // Wait for the DMA of tile t+1.  Outstanding VMEM in issue order: DMA(t+1), the store burst of the previous boundary,
 // then (depth 2) DMA(t+2): vmcnt(8) leaves at most that tile's eight pieces in flight.  vmcnt retires in order.
 // Depth 1: the store burst goes out AFTER the DMA of the same boundary, so the wait skips it (vmcnt(NW/4)): a store is
@@ -396,6 +430,7 @@ __device__ __forceinline__ bool k1t_tile(K1TLane<CL, C> &L, K1TUni &U, const K1A
             if constexpr (C::PRIO == 6) __builtin_amdgcn_s_setprio(3);
             k1t_wait_tile<C>(U);
             k1t_drain<CL, C>(L, rdv, U.par);
+            if (C::HS && !TAIL && U.t + 2 == U.ntiles) k1t_halo_shift<CL, C>(L);      // (wave-uniform)
         }
         __builtin_amdgcn_sched_barrier(0);
         if (!skip) k1t_arith<CL, C, WARMUP>(L, (RB0 + g * 8) % R, 8, 0, TI * 64 + g * 8, zlim);
@@ -429,6 +464,8 @@ __device__ __forceinline__ bool k1t_tile(K1TLane<CL, C> &L, K1TUni &U, const K1A
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                 // the drain has left the buffer
         if (TAIL || WARMUP)
             k1_prefetch<CL, TAIL>(a, 0, wg, U.t + 1 + C::DEPTH, U.par, lane, voff_e, voff_o, rows_valid);
+        else if (C::HS && U.t + 2 + C::DEPTH == U.ntiles)
+            k1t_dma_last(sb, vt_o, U.par);
         else
             k1t_dma_fast(sb, vt_e, vt_o, U.par);
     }
@@ -557,6 +594,11 @@ __global__ __launch_bounds__(64, 2) void k1t_demod(const K1Args a)
     }
     k1t_drain<CL, C>(L, rdv, 0);
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    if constexpr (C::HS != 0 && !TAIL) {
+        static_assert(C::HS == 0 || (G::NPT == 1 && C::SCHED == 0 && C::DEPTH == 1), "halo shift: one halo tile, one tile in flight");
+#pragma unroll
+        for (int k = 0; k < 32; ++k) L.keep[k] = L.tl[k];
+    }
     if ((uint32_t)C::DEPTH < U.ntiles) k1_prefetch<CL, TAIL>(a, 0, wg, C::DEPTH, 0, lane, voff_e, voff_o, rows_valid);
     U.par = C::kFlip;
     if (C::SCHED == 1 && G::SKIP < 4) k1t_gather<CL, C>(L, 0, 4, 0);
