@@ -165,6 +165,7 @@ struct amr_handle {
     // as soon as the tail stream reaches it)
     uint32_t gate_delay_ticks = 600;
     bool gate_event = true;
+    size_t k2w_lds_min = 0;      // hook AMR_K2W_LDS_KB: dynamic LDS of the multi-preamble walk at least this (bytes)
     int gate_end_mode = 0;       // A/B hook AMR_GATE_END (round 6, lost: profiles/r06/bs2048/): the tail behind the END of a one-launch K1 instead of
                                  // behind a gate: 1 every one-launch batch, -1 those with more wave-tiles than the chip has slots, 0 never
     uint32_t k1_round_tiles = 0; // test hook AMR_K1_ROUND_TILES: wave-tiles per K1 launch (0: a chip's worth at BlockSize >= 4096, else one launch)

@@ -177,7 +177,11 @@ amr_status enqueue_k2(amr_handle *h, Slot &s, hipStream_t st, bool rerun, bool d
     if (walk_ok) {
         const uint32_t n_wg = (s.n_tiles + amr::kK2WWaves - 1) / amr::kK2WWaves + extra;
         const uint32_t grid = 8u * ((n_wg + 7u) / 8u);   // XCD-contiguous tile order: 8 equal runs
-        const size_t lds = amr::k2_walk_lds_bytes(h->hist_rows * h->sg.wpb);
+        size_t lds = amr::k2_walk_lds_bytes(h->hist_rows * h->sg.wpb);
+        // several preambles: the walk holds 168 registers, three waves of it leave a SIMD nothing -- and K3.. of the previous
+        // batch, which run next to this search, wait for its waves to retire.  LDS the walk does not need limits it to
+        // fewer workgroups per compute unit (hook AMR_K2W_LDS_KB; 0 = off)
+        if (n_pre > 1 && h->k2w_lds_min > lds) lds = h->k2w_lds_min;
         // one preamble: the whole row in registers (rows of 256 words: two lanes per row), the look-ahead from the
         // neighbour lane (k2_row.h); it sizes its own grid (one or two waves per tile) around the `extra` workgroups
         walk_ok = (n_pre == 1 && amr::launch_k2_row(h->sg.symbol_length, (uint32_t)last_kind, extra, lds, st, k2start, k2stop, k2, &le)) ||

@@ -160,6 +160,7 @@ __device__ __forceinline__ void k3_chunk(const K3Args &a, const SearchGeom &g, u
     uint64_t leaders = __ballot(ok && (lane == 0 || key != prev));
     while (leaders) {
         uint32_t v0[kK3Batch], slot[kK3Batch];
+        bool need_a[kK3Batch], need_b[kK3Batch];               // wave-uniform: hits in the first / second half of the word
         int nb = 0;
 #pragma unroll
         for (int e = 0; e < kK3Batch; ++e) {
@@ -172,6 +173,11 @@ __device__ __forceinline__ void k3_chunk(const K3Args &a, const SearchGeom &g, u
                 if (ok && key == key_s) tab[e][local & 31] = i_out0 + i;   // same wave: LDS operations execute in order
                 slot[e] = tab[e][31 - l32];                        // lane c of a block ends up with position 31-c
                 v0[e] = (key_s << 5) - base_bit;                   // first bit of the word (staged: counted from the staged rows)
+                // which halves of the word hold hits (bit c of the ballot = position 31 - c): a window at a half-word offset is
+                // the low half of one stream word (positions 0 .. 15) and the high half of the next (16 .. 31), and a lone noise
+                // hit -- eight to a tile in "all" -- needs one of the two
+                const uint32_t hm = (uint32_t)__ballot(slot[e] != 0xffffffffu);
+                need_a[e] = (hm & 0xffff0000u) != 0; need_b[e] = (hm & 0x0000ffffu) != 0;
                 nb = e + 1;
             }
         }
@@ -194,7 +200,13 @@ __device__ __forceinline__ void k3_chunk(const K3Args &a, const SearchGeom &g, u
                         // none at SL = 0 mod 32 (chip 32, 48, 64, 80, 96)
                         const bool two = (so & 16u) != 0;
                         if (LONG && staged) { A[e][k] = rows_lds[v >> 5]; B[e][k] = two ? rows_lds[(v >> 5) + 1] : 0u; }
-                        else { A[e][k] = word_at(v); B[e][k] = two ? word_at(v + 32) : 0u; }
+                        else {
+                            // ... and of the two only the half that holds hits (round 6: "all" at 4 GiB is 32 768 lone scm+ hits of
+                            // 736 symbols, 36 M line requests of which 12 M fetched halves nobody read; the lanes that skip
+                            // theirs do not load at all)
+                            A[e][k] = (!two || need_a[e]) ? word_at(v) : 0u;
+                            B[e][k] = (two && need_b[e]) ? word_at(v + 32) : 0u;
+                        }
                     }
                 }
 #pragma unroll
