@@ -165,6 +165,8 @@ struct amr_handle {
     // as soon as the tail stream reaches it)
     uint32_t gate_delay_ticks = 600;
     bool gate_event = true;
+    uint32_t k3_prio = 0;        // hook AMR_K3_PRIO: s_setprio level of K3's waves (0..3)
+    size_t k3_lds_min = 0;       // hook AMR_K3_LDS_KB: dynamic LDS of K3 at least this (bytes)
     size_t k2w_lds_min = 0;      // hook AMR_K2W_LDS_KB: dynamic LDS of the multi-preamble walk at least this (bytes)
     int gate_end_mode = 0;       // A/B hook AMR_GATE_END (round 6, lost: profiles/r06/bs2048/): the tail behind the END of a one-launch K1 instead of
                                  // behind a gate: 1 every one-launch batch, -1 those with more wave-tiles than the chip has slots, 0 never

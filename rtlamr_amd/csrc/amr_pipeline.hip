@@ -224,13 +224,15 @@ amr_status enqueue_tail(amr_handle *h, Slot &s, hipStream_t st, bool split)
         for (uint32_t q = 0; q < n_pre; ++q) k3.rule[q] = h->rules[q];
     }
     hipEvent_t k3e0 = (t2 && split) ? s.ev_t : nullptr, k3e1 = t2 ? s.ev2 : nullptr;
-    const size_t k3lds = amr::k3_lds_bytes(h->sg, h->validate);
+    size_t k3lds = amr::k3_lds_bytes(h->sg, h->validate);
+    if (h->k3_lds_min > k3lds) k3lds = h->k3_lds_min;     // A/B hook AMR_K3_LDS_KB: fewer K3 workgroups per compute unit
     k3.lds_bytes = (uint32_t)k3lds;
     HIP_TRY(hipFuncSetAttribute((const void *)amr::k3_slice_words, hipFuncAttributeMaxDynamicSharedMemorySize, (int)k3lds));
     // one workgroup per (tile, preamble) list (every list of a tile in one workgroup with shared row staging measured slower
     // on the four-preamble decoder: 188 against 173 us per 4 GiB); k3_fold: when the history tile's workgroup would be the
     // one too many for whole rounds of the chip, workgroup 0 takes its list as well
     k3.fold = amr::k3_fold(s.n_tiles, n_pre, (uint32_t)h->n_cus * 8u) ? 1u : 0u;
+    k3.prio = h->k3_prio;
     hipExtLaunchKernelGGL(amr::k3_slice_words, dim3(s.n_tiles - k3.fold, n_pre), dim3(256), k3lds, st, k3e0, k3e1, 0, k3);
     HIP_TRY(hipGetLastError());
     AMR_DBG(st, "k3_slice");

@@ -43,6 +43,7 @@ struct K3Args {
     uint32_t *vgcnt;            // [n_pre][n_groups] survivors summed over groups of 64 tiles (atomicAdd; zero before K3 runs)
     uint32_t lds_bytes;         // dynamic LDS of the launch (k3_lds_bytes)
     uint32_t fold;              // 1: grid (n_tiles - 1, n_pre), workgroup 0 also takes the history tile (k3_fold)
+    uint32_t prio;              // wave priority (s_setprio) of K3's waves: they share SIMDs with the next batch's search
     ValRule rule[AMR_MAX_PREAMBLES];
 };
 
@@ -567,6 +568,9 @@ __global__ __launch_bounds__(256, 8) void k3_slice_words(const K3Args a)   // 8 
     __shared__ uint32_t s_red[4];
     __shared__ ValRule s_rule;
     extern __shared__ __attribute__((aligned(16))) uint32_t rows_lds[];          // [n_rows][wpb] words, stream order; K5: packets
+    if (a.prio == 1) __builtin_amdgcn_s_setprio(1);
+    else if (a.prio == 2) __builtin_amdgcn_s_setprio(2);
+    else if (a.prio == 3) __builtin_amdgcn_s_setprio(3);
     const uint32_t passes = a.fold && blockIdx.x == 0 ? 2u : 1u;
 #pragma clang loop unroll(disable)
     for (uint32_t pass = 0; pass < passes; ++pass) {
