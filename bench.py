@@ -412,6 +412,8 @@ def main():
     ap.add_argument("--no-verify", action="store_true", help="skip the golden hit count / planted message check")
     ap.add_argument("--k1-events", type=int, default=4,
                     help="HIP events around the K1 dispatch of every N-th timed step (0 = none: roofline fields are NaN)")
+    ap.add_argument("--k1-level", type=int, default=1, choices=[1, 2],
+                    help="what those timed steps carry: 1 = K1's start / stop (search_ms then comes from the warm-up steps), 2 = K2 and K3.. as well")
     ap.add_argument("--measure-traffic", action="store_true",
                     help="N = 1: after the timed region, measure K1's HBM bytes per launch in THIS run: two rocprofv3 --pmc passes "
                          "(FETCH_SIZE, WRITE_SIZE; kernel trace only) of a short --depth 1 run of the same workload; needs rocprofv3 "
@@ -665,9 +667,11 @@ def main():
             pairs.append((t_pair[1] - t_pair[0]) / chunk)
         steady_ms = float(np.median(pairs[-3:])) if pairs else float("nan")
 
-    # Timing events ride on the kernel dispatches (a separate event record costs a ~5 us stream bubble each): the warm-up
-    # steps and every --k1-events-th timed step carry the full set (K1 start/stop for the roofline figure, K2 and K3..
-    # for search_ms); measured: on every step 2 % of the step, on every 4th 0.5 %, the averages are the same.
+    # Timing events ride on the kernel dispatches (a separate event record costs a ~5 us stream bubble each).  The warm-up
+    # steps carry the full set (K1, K2 and K3..: search_ms); every --k1-events-th TIMED step carries K1's start / stop alone
+    # (level 1: the roofline figure).  Measured on the driver's command (profiles/r06/fill.txt): the full set on every 4th of
+    # 20 timed steps costs 2 % of the line (a stop event on the search is a completion signal in front of the next K1
+    # launch), K1's pair alone 0.4 %; K1's average is the same either way.
     def state_under_load():
         """device_state() of this rank's GPU read WHILE the pipeline is busy: 64 untimed steps, the files are read when half of
         them have been submitted (an idle device drops its shader clock within milliseconds: a snapshot of an idle device
@@ -686,7 +690,7 @@ def main():
     sync_all()
     c0, r0 = gstat["consumed"], gstat["records"]
     t0 = time.perf_counter()
-    res = run(args.steps, 2, args.k1_events)
+    res = run(args.steps, args.k1_level, args.k1_events)
     if distributed:
         gatherer.wait()
     sync_all()
@@ -694,7 +698,8 @@ def main():
     consumed_timed, records_timed = gstat["consumed"] - c0, gstat["records"] - r0
     tms = [t for _, t in res if t is not None] or [t for _, t in warm]
     demod_ms = [t["demod_ms"] for t in tms] or [float("nan")]
-    search_ms = [t["search_ms"] for t in tms] or [float("nan")]
+    full = [t for _, t in (res if args.k1_level >= 2 else warm) if t is not None] or tms     # the steps that timed K2 as well
+    search_ms = [t["search_ms"] for t in full] or [float("nan")]
     last = res[-1][0]
     n_hits = len(last.hit_idx)
     n_searched = last.n_hits_searched
@@ -798,7 +803,8 @@ def main():
                          "whole_path_frac_timed": round(alg_bytes / (ms_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
                          "k1_ms": round(k1_ms, 4), "search_ms": round(float(np.mean(search_ms)), 4),
                          "kernel_timing": (f"HIP events on the dispatches of every {args.k1_events}th timed step ({len(demod_ms)} steps): "
-                                           "K1 duration; search_ms = K2 duration (with batches in flight K3.. of a batch run on a "
+                                           "K1 duration; search_ms = K2 duration" + (f", from the {len(search_ms)} warm-up steps" if args.k1_level < 2 else "") +
+                                           " (with batches in flight K3.. of a batch run on a "
                                            "second stream, let in when the following batch's K1 has all its waves on the chip: they "
                                            "fill its ragged end and the start of that batch's K2; steady_ms_per_step - k1_ms is "
                                            "everything a step costs besides K1)"),
