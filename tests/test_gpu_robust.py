@@ -113,6 +113,23 @@ def test_batches_of_several_k1_launches(protos, chip, env):
     assert got["seconds"] < 2.0, f"the pipelined part took {got['seconds']:.2f} s: a device-side wait ran into its time-out"
 
 
+@pytest.mark.parametrize("env", [{"AMR_GATE_END": "1"}, {"AMR_GATE_END": "-1"}, {"AMR_K3_LDS_KB": "40", "AMR_K2W_LDS_KB": "40"}, {"AMR_K3_PRIO": "3"}],
+                         ids=["tail-behind-k1-end", "tail-behind-k1-end-auto", "lds-padding", "k3-priority"])
+@pytest.mark.parametrize("protos,chip", [(["scm"], 40), (["scm"], 8), (["scm", "scm+", "idm", "r900"], 72)], ids=["scm-40", "scm-8", "all"])
+def test_round6_ab_hooks_change_no_result(protos, chip, env):
+    """The A/B hooks of round 6 (amr_host.h: the tail behind the END of a one-launch K1 instead of behind the gate kernel; LDS
+    padding of the multi-preamble search and of K3; K3's wave priority) are scheduling choices: every one of them must leave
+    hit lists and packet bytes alone.  Chip 8 and 40 also run the all-XCD announcement of K1's last eight workgroups and
+    (chip 8) the halo-shift kernel through the pipelined path."""
+    per, n = 256, 6
+    want = oracle_digest(protos, chip, per, n)
+    assert want["n_hits"] > 0
+    got = probe(protos, chip, per, n, env=dict(env, AMR_K1_COOP_MAX="0"))
+    assert {k: got[k] for k in want} == want, f"{env}: other hits than the oracle's"
+    assert "gate-timeouts" not in got["describe"]
+    assert got["seconds"] < 2.0
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("protos,depth", [(["r900"], 3), (["scm", "r900"], 3), (["r900"], 2)])
 def test_pipelined_r900_searches_every_batch_once(protos, depth):
