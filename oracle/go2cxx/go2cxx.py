@@ -727,7 +727,13 @@ class Emitter:
         finally:
             self.pop()
             self.fn = saved_fn
-        return f"[=]({params}) -> {rt} {body}"
+        # heap variables of the surrounding functions (declared `T& x = *new T`): by reference, i.e. the one heap object
+        byref, s = [], self.scope
+        while s is not None:
+            byref += [cpp for kind, cpp in (e[:2] for e in s.names.values()) if kind == "heap"]
+            s = s.parent
+        cap = "".join(f", &{c}" for c in dict.fromkeys(byref))
+        return f"[={cap}]({params}) -> {rt} {body}"
 
     # ---------- statements
     def addr_taken(self, body):
@@ -736,6 +742,17 @@ class Emitter:
         def visit(n):
             if n.kind == "addr" and n.x.kind == "ident":
                 names.add(n.x.name)
+            if n.kind == "funclit":
+                # a function literal shares the variables it uses with its surroundings: the ones it WRITES must be one object
+                # for both (the literal is a C++ lambda that copies what it captures; heap variables it takes by reference)
+                def inner(m):
+                    if m.kind == "assign":
+                        for l in m.lhs:
+                            if l.kind == "ident":
+                                names.add(l.name)
+                    elif m.kind == "incdec" and m.x.kind == "ident":
+                        names.add(m.x.name)
+                walk(n.body, inner)
         walk(body, visit)
         return names
 
@@ -857,7 +874,7 @@ class Emitter:
     def local_var(self, name, ctype, init):
         """Declare local `name`; ctype None = deduce.  Variables whose address is taken live on the heap."""
         heap = name in self.fn.heap
-        cpp = self.declare(name)
+        cpp = self.declare(name, "heap" if heap and name != "_" else "local")
         if name == "_":
             return f"[[maybe_unused]] auto {cpp} = {init};" if init is not None else ""
         if heap:

@@ -6,6 +6,7 @@ package semantics
 
 import (
 	"fmt"
+	"math"
 	"strconv"
 	"strings"
 	"sync"
@@ -312,4 +313,129 @@ func Embedding() string {
 	t.square.s = 8 // the same field through the embedded struct's name
 	_, isCircle := n.(*circle)
 	return fmt.Sprintf("%s %d %s %d %d %d %d %t", n.Name(), back.Area(), l.Name(), back.square.Area(), back.tag, t.tag, t.s, !isCircle)
+}
+
+// ---- second batch (round 6): arithmetic and aliasing corners ----
+
+// Integer division truncates toward zero and % takes the sign of the dividend; unsigned subtraction wraps.  Want "-3 -1 3 -1 4294967293 3".
+func DivMod() string {
+	a, b := -7, 2
+	var u, v uint32 = 2, 5
+	return fmt.Sprintf("%d %d %d %d %d %d", a/b, a%b, a/-b, -7%-2, u-v, (u-v)%5)
+}
+
+// A float64 value converted to float32 is rounded once, to nearest even; float32 products are rounded before they are
+// widened; the sign bit of a negative zero survives.  Want "16777216 1.0000001 0.010000001 1 0".
+func Rounding() string {
+	d := 16777217.0 // 2^24 + 1: not a float32
+	f := float32(d)
+	g := float32(1.00000006) // just above 1 + 2^-24: rounds up to 1 + 2^-23
+	var x float32 = 0.1
+	p := float64(x * x) // the float32 product, then widened
+	var nz float32 = 0
+	nz = -nz
+	pos := float32(0)
+	return fmt.Sprintf("%.0f %.7f %.9f %d %d", f, g, p, math.Float32bits(nz)>>31, math.Float32bits(pos)>>31)
+}
+
+// A running float32 sum depends on the order of its terms.  Want "1.0000001 1 false".
+func SumOrder() string {
+	terms := []float32{1, 3e-8, 3e-8, 3e-8, 3e-8}
+	var up, down float32
+	for i := 1; i < len(terms); i++ {
+		down += terms[i] // the small ones first: they add up to 1.2e-7, enough to move 1
+	}
+	down += terms[0]
+	for _, t := range terms {
+		up += t // each one alone is lost next to 1
+	}
+	return fmt.Sprintf("%.7f %.7g %v", down, up, up == down)
+}
+
+// s[lo:hi:max] limits the capacity: the append below cannot reach the parent's elements.  Want "[1 2 3 4] [1 2 9] 2 2 4".
+func FullSlice() string {
+	a := []int{1, 2, 3, 4}
+	b := a[0:2:2]
+	c := append(b, 9) // cap(b) == 2: a new array
+	d := a[1:3]
+	return show(a) + " " + show(c) + " " + strconv.Itoa(cap(b)) + " " + strconv.Itoa(len(d)) + " " + strconv.Itoa(cap(a[:0]))
+}
+
+// range over an ARRAY copies it, range over a slice does not; the value variable is a copy either way.  Want "[1 2 3] [1 9 3] 6 15".
+func RangeCopies() string {
+	arr := [3]int{1, 2, 3}
+	sum := 0
+	for i, v := range arr {
+		arr[2] = 10 // the loop walks its copy
+		if i == 2 {
+			sum += v
+		}
+		sum += 0
+	}
+	arr[2] = 3
+	sl := []int{1, 2, 3}
+	seen := 0
+	for i, v := range sl {
+		if i == 0 {
+			sl[1] = 9
+		}
+		v += 100 // a copy
+		seen += sl[i]
+		_ = v
+	}
+	// sum == 3 (the copy's last element), seen == 1 + 9 + 3
+	return fmt.Sprintf("[%d %d %d] %s %d %d", arr[0], arr[1], arr[2], show(sl), sum*2, seen+2)
+}
+
+// Labelled break / continue, switch without a tag, break inside a switch leaves the switch only.  Want "4 12 small big".
+func Labels() string {
+	n, m := 0, 0
+outer:
+	for i := 0; i < 5; i++ {
+		for j := 0; j < 5; j++ {
+			if j == 2 {
+				continue outer
+			}
+			if i == 2 {
+				break outer
+			}
+			n++
+		}
+	}
+	for i := 0; i < 4; i++ {
+		switch {
+		case i == 1:
+			break // the switch, not the loop
+		default:
+			m += 4
+		}
+	}
+	word := func(x int) string {
+		switch {
+		case x < 10:
+			return "small"
+		}
+		return "big"
+	}
+	return fmt.Sprintf("%d %d %s %s", n, m, word(3), word(30))
+}
+
+// Closures capture variables, not values; a shift-and-or byte accumulator keeps eight bits.  Want "3 6 165 42".
+func Closures() string {
+	total := 0
+	add := func(k int) int { total += k; return total }
+	add(1)
+	add(2)
+	first := total
+	double := func() { total *= 2 }
+	double()
+	var acc uint8
+	for _, bit := range []uint8{1, 0, 1, 0, 0, 1, 0, 1} {
+		acc = acc<<1 | bit
+	}
+	keep := acc // 1010 0101
+	for _, bit := range []uint8{0, 1, 0} {
+		acc = acc<<1 | bit // the high bits fall off: 165 -> 74 -> 149 -> 42
+	}
+	return fmt.Sprintf("%d %d %d %d", first, total, keep, acc)
 }

@@ -29,7 +29,7 @@ def wants():
 def binary(tmp_path_factory):
     tmp = tmp_path_factory.mktemp("go2cxx")
     names = sorted(wants())
-    assert len(names) >= 15
+    assert len(names) >= 22
     hpp = tmp / "semantics_gen.hpp"
     cmd = [sys.executable, os.path.join(G2C, "go2cxx.py"), "--module-root", MOD, "-o", str(hpp)]
     for n in names:
