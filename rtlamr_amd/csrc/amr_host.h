@@ -77,6 +77,7 @@ struct Slot {
     int timed = 0;                // timing level the batch in flight was submitted with
     bool tail_enqueued = true;    // K3.. of the batch in flight have been launched (false: collect launches them)
     bool tail_split = false;      // ... on the second stream
+    bool inwave = false;          // K1 searched the batch's tiles itself (k1_search.h): the search launch is the clean-up
     bool tail_gated = false;      // ... enqueued ahead, behind k_gate: K3 then runs next to the following K1's end and search
     bool folded = false;          // the state update ran inside the search kernel: no stream-A ticket for this batch
     int carry_in_slot = 0;        // k3_stale.h: the slot whose carry byte precedes this batch's first hit
@@ -144,6 +145,7 @@ struct amr_handle {
     uint64_t gate_timeout_ticks = 400000000ull;   // k_gate gives up after this many 100 MHz ticks (4 s; test hook AMR_GATE_TIMEOUT_US)
     uint64_t gate_timeouts = 0;   // batches searched again because their gate gave up (amr_describe)
     uint64_t researches = 0;      // batches searched again at collect, for any reason (amr_describe)
+    uint64_t inwave_batches = 0;  // batches whose tiles the K1 waves searched themselves (k1_search.h; amr_describe)
     uint64_t stale_reruns = 0;    // batches whose k_stale_bits pass alone ran again behind an older batch's re-search
     uint64_t *h_flags = nullptr;  // pinned: [0] ticket of the last batch whose search has started, [1] whose stream-A part is done
     bool timing_valid = false;
@@ -166,6 +168,7 @@ struct amr_handle {
     uint32_t gate_delay_ticks = 600;
     bool gate_event = true;
     uint32_t k3_prio = 0;        // hook AMR_K3_PRIO: s_setprio level of K3's waves (0..3)
+    bool inwave_mode = true;     // AMR_INWAVE=0: never search inside the K1 wave (A/B; BlockSize 512 then runs the early search)
     size_t k3_lds_min = 0;       // hook AMR_K3_LDS_KB: dynamic LDS of K3 at least this (bytes)
     size_t k2w_lds_min = 0;      // hook AMR_K2W_LDS_KB: dynamic LDS of the multi-preamble walk at least this (bytes)
     int gate_end_mode = 0;       // A/B hook AMR_GATE_END (round 6, lost: profiles/r06/bs2048/): the tail behind the END of a one-launch K1 instead of

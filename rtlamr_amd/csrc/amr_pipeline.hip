@@ -174,6 +174,20 @@ amr_status enqueue_k2(amr_handle *h, Slot &s, hipStream_t st, bool rerun, bool d
         walk_ok = kind >= 0;
         if (kind >= 0) { walk_set |= 1u << kind; k2.walk_pids |= q << (8 * kind); last_kind = kind; }
     }
+    if (walk_ok && s.inwave && !rerun && !dense && !early) {
+        // K1 searched every tile itself (k1_search.h) except row 63's last words and the history tile: the history tile + the
+        // state update as a launch of the row kernel over ONE tile, then the clean-up of the rows 63
+        amr::K2Args kh = k2;
+        kh.n_tiles = 1;
+        const size_t lds = amr::k2_walk_lds_bytes(h->hist_rows * h->sg.wpb);
+        if (!amr::launch_k2_row(h->sg.symbol_length, (uint32_t)last_kind, extra, lds, st, k2start, nullptr, kh, &le) ||
+            !amr::launch_k2_cleanup(h->sg.symbol_length, (uint32_t)last_kind, st, nullptr, k2stop, k2))
+            return fail(AMR_EHIP, "in-wave search: no clean-up kernel for this geometry");
+        HIP_TRY(le);
+        HIP_TRY(hipGetLastError());
+        AMR_DBG(st, "k2_cleanup");
+        return AMR_OK;
+    }
     if (walk_ok) {
         const uint32_t n_wg = (s.n_tiles + amr::kK2WWaves - 1) / amr::kK2WWaves + extra;
         const uint32_t grid = 8u * ((n_wg + 7u) / 8u);   // XCD-contiguous tile order: 8 equal runs
@@ -359,13 +373,32 @@ amr_status submit(amr_handle *h, const uint8_t *d_iq, size_t n_blocks, bool sear
     // as soon as the K1 waves that wrote it are done -- so that the next K1 launch follows this one directly.  For batches of
     // whole wave-tiles through the tile kernel, one preamble with a row kernel, nothing deferred; everything else keeps the
     // search between two K1 launches in stream order.
+    // IN-WAVE SEARCH (k1_search.h): rows of 16 words (BlockSize 512), one of rtlamr's preambles whose taps all fit the row: the K1
+    // wave searches its own tile before it stores it; the search launch shrinks to the history tile and the rows 63.
+    bool inwave = false;
+    if (search && h->inwave_mode && !all_coop && rem == 0 && full > 0 && h->r900_pid < 0 && !s.dense && !h->dense_search &&
+        h->sg.n_pre == 1 && h->sg.wpb == 16 && h->geom.chip_length == 8) {
+        const int kind = amr::k2_walk_kind_of(h->sg.pre_len[0], h->sg.pre_bits[0]);
+        amr::K2Args q{};                              // qt null: a question, not a launch
+        q.g = h->sg; q.n_tiles = s.n_tiles;
+        if (kind >= 0 && amr::launch_k2_cleanup(h->sg.symbol_length, (uint32_t)kind, nullptr, nullptr, nullptr, q)) {
+            inwave = true;
+            k1.srch.counts = s.d_counts; k1.srch.gcnt = s.d_gcnt; k1.srch.staging = s.d_staging; k1.srch.overflow = s.d_overflow;
+            k1.srch.cap = s.stage_cap; k1.srch.n_tiles = s.n_tiles;
+            k1.srch.n_lo = -(int64_t)h->geom.packet_length;
+            k1.srch.n_hi = (int64_t)s.n_blocks * bs - (int64_t)h->geom.packet_length;
+            k1.srch.kind_p1 = (uint32_t)kind + 1u;
+        }
+    }
+    s.inwave = inwave;
+    if (inwave) h->inwave_batches++;
     bool early = false;
     // Measured (profiles/r05/early_search_ab.txt): at BlockSize >= 2048 the next K1 launch, no longer held back by the search,
     // starts while the last searching waves (and the previous batch's K3) still hold wave slots; some of its waves start
     // late, the launch loses its lock-step and K1 takes 0.25-0.27 ms instead of 0.187: 20 % slower at chip 72, 1-6 % at chip
     // 32 .. 48.  At BlockSize 512 (chip 8) K1 is one launch of eight rounds, out of step anyway: 3-5 % faster.
     const bool early_here = h->early_mode > 0 || (h->early_mode < 0 && bs <= 512);
-    if (lazy && early_here && !all_coop && rem == 0 && full > 0 && n_head == 0 && new_head == 0 && h->r900_pid < 0 && !s.dense &&
+    if (lazy && early_here && !inwave && !all_coop && rem == 0 && full > 0 && n_head == 0 && new_head == 0 && h->r900_pid < 0 && !s.dense &&
         !h->dense_search && h->sg.n_pre == 1) {
         const int kind = amr::k2_walk_kind_of(h->sg.pre_len[0], h->sg.pre_bits[0]);
         amr::K2Args q{};                              // qt null: a question, not a launch
@@ -389,6 +422,9 @@ amr_status submit(amr_handle *h, const uint8_t *d_iq, size_t n_blocks, bool sear
     }
     amr::K1Args k1_last = k1;                     // the launch that announces itself to the gate: the batch's last one
     if (gate_prev || early) { k1_last.started = h->d_k1_started; k1_last.started_value = s.ticket; }
+    // in-wave search (BlockSize 512: one launch of eight rounds): the previous batch's tail comes in at this launch's START and
+    // shares its rounds; nothing is held back for it (below)
+    if (inwave) k1_last.started_first = 1u;
     // One launch per "round" for long blocks: K1 holds 8 waves per CU, and a launch that exactly fills the chip keeps its
     // waves in step -- all of them read together and write their output bursts together.  A larger grid runs the later
     // rounds out of step (output stores trickle into the read stream all the time): BlockSize 4096, 4 GiB: 0.895 ms in
@@ -489,7 +525,7 @@ amr_status submit(amr_handle *h, const uint8_t *d_iq, size_t n_blocks, bool sear
                      other.d_gcnt, other.gcnt_words,
                      lazy ? nullptr : s.h_done, s.ticket, &h->h_flags[1],
                      // (early: the next K1 launch no longer waits for this kernel, so there is nothing to hold back)
-                     (!early && prev.pending && prev.search && prev.tail_split) ? h->d_tail_done : nullptr, prev.ticket,
+                     (!early && !inwave && prev.pending && prev.search && prev.tail_split) ? h->d_tail_done : nullptr, prev.ticket,
                      early ? s.d_k1flags + (full - 1) : nullptr, (uint32_t)s.ticket};
     // pipelined callers: the update rides along with the search as more workgroups of its launch instead of following it
     // as a 5 us kernel

@@ -39,6 +39,19 @@ constexpr int kRows = 64;                       // block-rows per wave, one per 
 constexpr int kTileBytes = 128;                 // IQ bytes per row per staging tile (one cache line)
 constexpr int kTileBuf = kRows * kTileBytes;    // 8 KiB per buffer
 
+// In-wave search (round 6, k1_search.h): where a lane's whole row of decisions is still on the chip when its block ends (rows of
+// 16 words: BlockSize 512), the K1 wave searches its own tile -- lane = row, the look-ahead is the neighbour lane, exactly the
+// geometry of k2_search_row -- and writes what that kernel writes: the tile's list in the staging slot, its count, the group
+// sum.  Row 63's last words (their windows reach into the next tile, which another wave is still writing) and the history
+// tile are left to a clean-up launch (k2_row_cleanup, amr_pipeline.hip).  kind_p1 = 0: off.
+struct K1Search {
+    uint32_t *counts, *gcnt, *staging, *overflow;   // K2Args of the batch (one preamble)
+    int64_t n_lo, n_hi;                             // valid positions, as K2Args
+    uint32_t cap, n_tiles;
+    uint32_t kind_p1;                               // 1 + the preamble's kind (k2_walk_kind_of)
+    uint32_t pad_;
+};
+
 struct K1Args {
     const uint8_t *iq;     // row 0 of the launch, byte 0 (device); with head_rows the rows below 64 are never read from here
     const uint8_t *carry;  // the "head" buffer: the HBA stream bytes that precede row 0 of the launch, and behind them
@@ -64,6 +77,10 @@ struct K1Args {
     // dispatchers do not run in step: the last workgroup of the grid alone said nothing about the other seven.
     uint32_t *started_ctr;
     uint32_t started_target;
+    // 1: the FIRST min(8, grid) workgroups announce instead (a launch of many rounds that has no lock-step to protect, BlockSize
+    // 512: what the gate then says is "everything in front of this launch on its stream has finished", and the tail it lets in
+    // takes its slots round by round as K1 waves retire)
+    uint32_t started_first;
     // Early search (amr_pipeline.hip): the search of this batch runs off the compute stream, NEXT to this launch,
     // and takes a tile as soon as the waves that wrote it are done.  Every wave, at its end, waits for its stores (sc1:
     // written through, nothing stays dirty in the XCD's L2) and then stores done_value into done_flags[wave-tile]; the wave of
@@ -72,6 +89,7 @@ struct K1Args {
     uint32_t *done_flags;
     uint8_t *carry_out;
     uint32_t done_value;
+    K1Search srch;
 #if AMR_K1T_CLK
     uint32_t tl_seq;       // diagnostic builds: slot of this launch in k1t_timeline (k1_launch.inc counts)
 #endif
@@ -83,7 +101,7 @@ __device__ __forceinline__ void k1_announce(const K1Args &a, uint32_t lane)
     // the gate kernel reads the word with agent-scope loads on another XCD.  Written as __hip_atomic_store it makes hipcc give up
     // the scalar loads of the kernel arguments behind it: the DMA's base pointers then arrive in VGPR pairs, which the
     // "s" operands of the inline asm cannot take.
-    if (a.started && blockIdx.x + 8 >= gridDim.x && lane == 0) {
+    if (a.started && (a.started_first ? blockIdx.x < 8 : blockIdx.x + 8 >= gridDim.x) && lane == 0) {
         uint32_t *c = a.started_ctr;
         uint32_t old;
         // (device-scope atomic with return, issued before any of the wave's DMA: the counted waits of the tile loop never see it)

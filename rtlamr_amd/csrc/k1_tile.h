@@ -15,6 +15,7 @@
 // Output layout, arguments and the halo/carry conventions: k1_common.h (K1Args, "tiled4" bitstream).
 #pragma once
 #include "k1_common.h"
+#include "k1_search.h"
 
 // Developer diagnostics (K1TCfg::DIAG, 0 in the product): 1 = no HBM traffic after the prologue (arithmetic side
 // alone), 2 = staging + drains only (memory side alone), 3 = no output stores, 5 = no LUT gathers (one cheap ALU op per
@@ -511,8 +512,9 @@ __device__ __forceinline__ void k1t_warm(K1TLane<CL, C> &L, K1TUni &U, const K1A
     }
 }
 
-template <int CL, bool TAIL, class C>
-__global__ __launch_bounds__(64, 2) void k1t_demod(const K1Args a)
+// SRCH: 0, or 1 + the kind of the decoder's one preamble: the wave searches its tile before it stores it (k1_search.h)
+template <int CL, bool TAIL, class C, int SRCH>
+__device__ __forceinline__ void k1t_body(const K1Args &a)
 {
     using G = K1TGeom<CL>;
     extern __shared__ __attribute__((aligned(16))) uint8_t k1t_lds[];   // [0,16 KiB) two tile buffers, then the LUT
@@ -610,6 +612,19 @@ __global__ __launch_bounds__(64, 2) void k1t_demod(const K1Args a)
     uint32_t vt_e = voff_e + (G::NPT + 1 + C::DEPTH) * kTileBytes, vt_o = voff_o + (G::NPT + 1 + C::DEPTH) * kTileBytes;
     while (!k1t_super<CL, TAIL, C, 0>(L, U, a, sb, wg, lane, rdv, voff_e, voff_o, vt_e, vt_o, rows_valid, qrow)) {}
     if (C::DIAG == 3) U.nch = 0;
+    if constexpr (SRCH > 0) {
+        // the lane's row, whole: rows of 16 words are four chunks, all of them parked in LDS (NLC >= 4) and about to be stored
+        constexpr int WPB = 16;
+        static_assert(C::NLC >= WPB / 4 && !TAIL, "in-wave search: the row's chunks must all be parked");
+        if (a.block_size == 32u * WPB && U.nch == (uint32_t)(WPB / 4)) {          // (wave-uniform; anything else: the launcher's mistake)
+            typedef const __attribute__((address_space(3))) k2w_v4u *lds_v4;
+            K2WRing<WPB / 4> R;
+#pragma unroll
+            for (int c = 0; c < WPB / 4; ++c) R.c[c] = *(lds_v4)(uintptr_t)(C::kPark + c * 1024 + lane * 16);
+            // scratch: the tile buffer at LDS offset 0, which no DMA targets any more
+            k1s_search_tile<2 * CL, SRCH - 1, WPB>(a.srch, wg + 1, lane, R, reinterpret_cast<uint32_t *>(k1t_lds), 9u);
+        }
+    }
     if (U.nch) k1t_flush<CL, C>(L, U, qrow);
     if (C::DIAG == 3 || C::DIAG == 2) qrow[lane * 4] = L.xs ^ L.acc;
     if (a.done_flags) {
@@ -639,6 +654,19 @@ __global__ __launch_bounds__(64, 2) void k1t_demod(const K1Args a)
         t[0] = rt0; t[1] = __builtin_amdgcn_s_memrealtime(); t[2] = ((unsigned long long)xcc << 32) | hw;
     }
 #endif
+}
+
+template <int CL, bool TAIL, class C>
+__global__ __launch_bounds__(64, 2) void k1t_demod(const K1Args a)
+{
+    k1t_body<CL, TAIL, C, 0>(a);
+}
+
+// ... with the in-wave search for the decoder's one preamble (kind KIND), rows of 16 words
+template <int CL, class C, int KIND>
+__global__ __launch_bounds__(64, 2) void k1t_demod_srch(const K1Args a)
+{
+    k1t_body<CL, false, C, KIND + 1>(a);
 }
 
 }  // namespace amr

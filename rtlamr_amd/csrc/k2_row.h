@@ -434,4 +434,86 @@ __global__ __launch_bounds__(64 * kK2WWaves, AMR_K2R_WPE) void k2_search_row(con
     }
 }
 
+// ---- clean-up behind an in-wave search (k1_search.h): row 63 of every tile, the words whose windows reach into the next tile ----
+// One THREAD per tile: its row 63 from word w_cut on (the K1 wave searched the words below it), the look-ahead from row 0 of
+// the next tile, which is complete now.  The row is its own ring as in k2_search_row: slots below the first group hold the
+// next row's chunks from the start, a slot turns into look-ahead once its group has been swept.  The hits go behind the
+// tile's in-wave hits (row 63's last words are the last positions of the tile); count and group sum are brought up to date.
+// The history tile and the state update are a launch of k2_search_row with n_tiles = 1 (amr_pipeline.hip).
+template <int SL, int WPB, int KIND, int D, int GG, int G0>
+__device__ __forceinline__ void k2c_groups(K2WRing<WPB / 4> &R, const k2w_v4u (&N)[(K2RGeom<SL, WPB, D>::NLA)], uint32_t w_lo, uint32_t w_hi,
+                                           uint32_t (&M)[WPB], uint32_t &Bc)
+{
+    using G = K2RGeom<SL, WPB, D>;
+    if constexpr (GG < G::CPR) {
+        uint32_t m4[4];
+        k2r_sweep<SL, WPB, D, GG, (uint32_t)kK2WKnownAll[KIND]>(R, m4, Bc);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const uint32_t w = GG * 4 + j;
+            M[w] = (w >= w_lo && w < w_hi) ? m4[j] : 0u;
+        }
+        if constexpr (GG < G::NLA) R.c[GG] = N[GG];
+        k2c_groups<SL, WPB, KIND, D, GG + 1, G0>(R, N, w_lo, w_hi, M, Bc);
+    }
+}
+
+template <int SL, int KIND, int WPB>
+__global__ __launch_bounds__(256) void k2_row_cleanup(const K2Args a)
+{
+    constexpr int D = k2r_taps<SL, KIND, WPB>();
+    using G = K2RGeom<SL, WPB, D>;
+    constexpr int LG_WPB = WPB == 16 ? 4 : WPB == 32 ? 5 : WPB == 64 ? 6 : 7;
+    constexpr uint32_t lg_bs = LG_WPB + 5, tile_words = 64u << LG_WPB;
+    constexpr int w_cut = WPB - 1 - (((D - 1) * SL) >> 5), G0 = w_cut / 4;    // first word / group this kernel owns (k1s_wcut)
+    static_assert(D == (int)kK2WKnownLen[KIND] && w_cut >= 1, "as k1s_ok");
+    const uint32_t T = 1u + blockIdx.x * 256u + threadIdx.x;           // tile 0 is the history tile: k2_search_row's
+    if (T >= a.n_tiles) return;
+    const uint32_t *tw = a.qt + (size_t)T * tile_words;
+    // row 63: chunk c at tw + c * 256 + 63 * 4 words; row 0 of the next tile: chunk c at tw + tile_words + c * 256
+    K2WRing<G::CPR> R;
+    k2w_v4u N[G::NLA];
+#pragma unroll
+    for (int c = 0; c < G::NLA; ++c) N[c] = *reinterpret_cast<const k2w_v4u *>(tw + tile_words + c * 256);
+#pragma unroll
+    for (int c = 0; c < G::CPR; ++c) {
+        if (c >= G0) R.c[c] = *reinterpret_cast<const k2w_v4u *>(tw + c * 256 + 63 * 4);
+        else if (c < G::NLA) R.c[c] = N[c];
+        else R.c[c] = k2w_v4u{0u, 0u, 0u, 0u};                        // (swept by nobody, read by nobody)
+    }
+    const int64_t rowbase = ((int64_t)T * 64 + 63 - 64) << lg_bs;
+    const int64_t lo64 = (a.n_lo - rowbase) >> 5, hi64 = (a.n_hi - rowbase) >> 5;
+    uint32_t w_lo = (uint32_t)(lo64 < 0 ? 0 : lo64 > (int64_t)WPB ? WPB : lo64);
+    const uint32_t w_hi = (uint32_t)(hi64 < 0 ? 0 : hi64 > (int64_t)WPB ? WPB : hi64);
+    if (w_lo < (uint32_t)w_cut) w_lo = (uint32_t)w_cut;
+    if (w_lo >= w_hi) return;                                          // (the batch's last rows: searched with the next batch)
+    uint32_t M[WPB];
+#pragma unroll
+    for (int w = 0; w < WPB; ++w) M[w] = 0;
+    // class-B mask of the B-block in front of the first group: words of the row from 4 G0 on (and look-ahead slots below it)
+    uint32_t Bc = 0;
+    if constexpr (K2RTaps<SL>::kHalf) Bc = k2r_chain<SL, WPB, D, (uint32_t)kK2WKnownAll[KIND], 1, 2, true, false>(R, 4 * G0, 0u, 0u);
+    k2c_groups<SL, WPB, KIND, D, G0, G0>(R, N, w_lo, w_hi, M, Bc);
+    uint32_t extra = 0;
+#pragma unroll
+    for (int w = G0 * 4; w < WPB; ++w) extra += (uint32_t)__popc(M[w]);
+    if (!extra) return;
+    const uint32_t have = a.counts[T];                                 // the in-wave hits of the tile (clamped to cap)
+    uint32_t rank = have;
+#pragma unroll
+    for (int w = G0 * 4; w < WPB; ++w) {
+        uint32_t m = M[w];
+        while (m) {
+            const uint32_t b = (uint32_t)__clz((int)m);               // bit 31 = the word's first position
+            m &= ~(0x80000000u >> b);
+            if (rank < a.cap) a.staging[(size_t)T * a.cap + rank] = (63u << lg_bs) + ((uint32_t)w << 5) + b;
+            ++rank;
+        }
+    }
+    const uint32_t c = rank < a.cap ? rank : a.cap;
+    a.counts[T] = c;
+    if (c > have) atomicAdd(&a.gcnt[(T >> 6) * kGroupStride], c - have);
+    if (rank > a.cap) atomicOr(a.overflow, 1u);
+}
+
 }  // namespace amr

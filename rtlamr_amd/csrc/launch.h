@@ -26,6 +26,9 @@ bool launch_k2_walk(uint32_t symbol_length, uint32_t set, uint32_t grid, size_t 
 // deferred-block copies).  false: no kernel for this (SymbolLength, kind, row length)
 bool launch_k2_row(uint32_t symbol_length, uint32_t kind, uint32_t extra_wgs, size_t lds_bytes, hipStream_t st, hipEvent_t start, hipEvent_t stop,
                    const K2Args &a, hipError_t *err);
+// the clean-up launch behind an in-wave search (k1_search.h: K1 searched every tile but row 63's last words): rows of 16 words,
+// kind 0 / 1.  a.qt == nullptr: no launch, the answer says whether the geometry has one.  false: none
+bool launch_k2_cleanup(uint32_t symbol_length, uint32_t kind, hipStream_t st, hipEvent_t start, hipEvent_t stop, const K2Args &a);
 // which of rtlamr's four preambles (k2_walk.h) a registered preamble is, -1: none
 int k2_walk_kind_of(uint32_t len, uint64_t bits);
 // K2 fallbacks (k2_search.h): list-based for up to four short preambles / short rows, dense for everything else

@@ -46,9 +46,13 @@ def _sorted(rows, pkt):
     (["scm", "scm+", "idm"], 72, [129, 127, 66, 62], 3, False),
     (["scm"], 8, [1000, 1001, 37, 999], 3, True),                  # BlockSize 512, the list-based search kernel
     (["scm"], 96, [70, 70, 70], 2, False),                         # first-generation K1
+    (["scm"], 8, [300, 301, 37, 259, 64], 3, False),               # tile kernels at test size (see below): deferred head rows + the in-wave search
 ])
-def test_deferred_pipeline_equals_oracle(protos, chip, sizes, depth, host):
+def test_deferred_pipeline_equals_oracle(protos, chip, sizes, depth, host, monkeypatch):
     L = _lib.lib()
+    tile_kernels = chip == 8 and not host
+    if tile_kernels:      # read at amr_create: no batch is small enough for the one-wave-per-block K1, so whole wave-tiles run the
+        monkeypatch.setenv("AMR_K1_COOP_MAX", "0")       # tile kernel -- at chip 8 with its in-wave search (k1_search.h)
     dec = util.make_decoder(protos, chip)
     bufs, parts = [], []
     try:
@@ -93,6 +97,8 @@ def test_deferred_pipeline_equals_oracle(protos, chip, sizes, depth, host):
         assert len(want[2]) > 0 and np.array_equal(rows, want[2]), f"hits differ: gpu {len(rows)} oracle {len(want[2])}"
         nfull = dec.Cfg.PacketSymbols // 8
         assert np.array_equal(pkt[:, :nfull], want[3][:, :nfull])
+        if tile_kernels:
+            assert "in-wave-searches" in dec.describe()
     finally:
         dec.close()
         for d in bufs:

@@ -130,6 +130,28 @@ def test_round6_ab_hooks_change_no_result(protos, chip, env):
     assert got["seconds"] < 2.0
 
 
+@pytest.mark.parametrize("env", [{}, {"AMR_K1_ROUND_TILES": "1"}, {"AMD_SERIALIZE_KERNEL": "3"}, {"AMR_HIT_CAP": "64"}],
+                         ids=["plain", "a-launch-per-wave-tile", "serialize-kernel", "capacity-growth"])
+@pytest.mark.parametrize("protos,per,n", [(["scm"], 256, 7), (["scm+"], 256, 7), (["scm"], 128, 9), (["scm"], 100, 9)],
+                         ids=["scm", "scm+-rows-of-8-words", "scm-128", "scm-ragged-batches"])
+def test_in_wave_search_at_chip_8_equals_oracle(protos, per, n, env):
+    """Rows of 16 words (chip length 8, one preamble): the K1 wave searches its own tile before it stores it (k1_search.h), the
+    search launch is the history tile + the rows 63 (k2_row_cleanup).  Hits across tile and batch boundaries (row 63's last
+    words, the history rows), with batches that are no multiple of 64 blocks (the remainder runs the one-wave-per-block K1 and
+    the ordinary search), with every wave-tile a launch of its own, with a result that outgrows its buffers (re-search by the
+    ordinary kernel) -- against the oracle's literal Search; and AMR_INWAVE=0 must give the same."""
+    chip = 8
+    want = oracle_digest(protos, chip, per, n)
+    assert want["n_hits"] > 0
+    on = probe(protos, chip, per, n, env=dict(env, AMR_K1_COOP_MAX="0"))
+    off = probe(protos, chip, per, n, env=dict(env, AMR_K1_COOP_MAX="0", AMR_INWAVE="0"))
+    assert {k: on[k] for k in want} == want, "in-wave search: other hits than the oracle's"
+    assert {k: off[k] for k in want} == want
+    rows16 = protos == ["scm"]            # scm+ alone at chip 8 has rows of 8 words: the fallback search, never in-wave
+    assert ("in-wave-searches" in on["describe"]) == (rows16 and per % 64 == 0), on["describe"]
+    assert "in-wave-searches" not in off["describe"]
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("protos,depth", [(["r900"], 3), (["scm", "r900"], 3), (["r900"], 2)])
 def test_pipelined_r900_searches_every_batch_once(protos, depth):
