@@ -168,7 +168,8 @@ struct amr_handle {
     uint32_t gate_delay_ticks = 600;
     bool gate_event = true;
     uint32_t k3_prio = 0;        // hook AMR_K3_PRIO: s_setprio level of K3's waves (0..3)
-    bool inwave_mode = true;     // AMR_INWAVE=0: never search inside the K1 wave (A/B; BlockSize 512 then runs the early search)
+    int inwave_mode = 1;         // AMR_INWAVE: 0 never search inside the K1 wave (BlockSize 512 then runs the early search), 1 rows of 16 words
+                                 // (chip 8), 2 rows of 64 words as well (chip 32 / 40, scm: experiment)
     size_t k3_lds_min = 0;       // hook AMR_K3_LDS_KB: dynamic LDS of K3 at least this (bytes)
     size_t k2w_lds_min = 0;      // hook AMR_K2W_LDS_KB: dynamic LDS of the multi-preamble walk at least this (bytes)
     int gate_end_mode = 0;       // A/B hook AMR_GATE_END (round 6, lost: profiles/r06/bs2048/): the tail behind the END of a one-launch K1 instead of

@@ -377,7 +377,8 @@ amr_status submit(amr_handle *h, const uint8_t *d_iq, size_t n_blocks, bool sear
     // wave searches its own tile before it stores it; the search launch shrinks to the history tile and the rows 63.
     bool inwave = false;
     if (search && h->inwave_mode && !all_coop && rem == 0 && full > 0 && h->r900_pid < 0 && !s.dense && !h->dense_search &&
-        h->sg.n_pre == 1 && h->sg.wpb == 16 && h->geom.chip_length == 8) {
+        h->sg.n_pre == 1 && ((h->sg.wpb == 16 && h->geom.chip_length == 8) ||
+                             (h->inwave_mode >= 2 && h->sg.wpb == 64 && (h->geom.chip_length == 32 || h->geom.chip_length == 40)))) {
         const int kind = amr::k2_walk_kind_of(h->sg.pre_len[0], h->sg.pre_bits[0]);
         amr::K2Args q{};                              // qt null: a question, not a launch
         q.g = h->sg; q.n_tiles = s.n_tiles;

@@ -149,7 +149,7 @@ amr_status amr_create(const amr_protocol *protos, int32_t n_protos, int32_t devi
     if (const char *gd = getenv("AMR_GATE_DELAY_TICKS")) h->gate_delay_ticks = (uint32_t)strtoul(gd, nullptr, 10);   // A/B runs
     if (const char *ge = getenv("AMR_GATE_EVENT")) h->gate_event = ge[0] != '0';
     if (const char *ge = getenv("AMR_GATE_END")) h->gate_end_mode = atoi(ge);   // A/B runs
-    if (const char *iw = getenv("AMR_INWAVE")) h->inwave_mode = iw[0] != '0';   // A/B runs
+    if (const char *iw = getenv("AMR_INWAVE")) h->inwave_mode = atoi(iw);   // A/B runs
     if (const char *kp = getenv("AMR_K3_PRIO")) h->k3_prio = (uint32_t)atoi(kp) & 3u;   // A/B runs
     if (const char *kl = getenv("AMR_K3_LDS_KB")) h->k3_lds_min = (size_t)strtoul(kl, nullptr, 10) * 1024;   // A/B runs
     if (const char *kl = getenv("AMR_K2W_LDS_KB")) h->k2w_lds_min = (size_t)strtoul(kl, nullptr, 10) * 1024;   // A/B runs

@@ -170,6 +170,7 @@ struct K1TUni {
     uint32_t wdone;    // words stored
     uint32_t st;       // depth 1: 1 = a store burst was issued after the DMA in flight
     uint32_t odd;      // PRIO: 1 = this wave sits in an odd hardware wave slot of its SIMD
+    uint32_t hold_last; // in-wave search: the burst that completes at the LAST tile boundary stays on the chip (the epilogue searches, then stores)
 };
 
 // LUT gathers of `n` samples starting at sample s0 (0..63) of the register tile: lv[2j], lv[2j+1] = lut[I], lut[Q]
@@ -460,7 +461,8 @@ __device__ __forceinline__ bool k1t_tile(K1TLane<CL, C> &L, K1TUni &U, const K1A
     // tile boundary, second part
     if (C::DIAG == 3 && U.nch == (uint32_t)C::CAP) U.nch = 0;
     constexpr bool kStoreAfter = C::DEPTH == 1 && C::STORE_AFTER;
-    if (!kStoreAfter && !WARMUP && U.nch == (uint32_t)C::CAP && C::DIAG != 3) k1t_flush<CL, C>(L, U, qrow);
+    const bool held = U.hold_last && U.t + 1 >= U.ntiles;              // (wave-uniform; hold_last is a constant 0 without the in-wave search)
+    if (!kStoreAfter && !WARMUP && U.nch == (uint32_t)C::CAP && C::DIAG != 3 && !held) k1t_flush<CL, C>(L, U, qrow);
     if (U.t + 1 + C::DEPTH < U.ntiles && C::DIAG != 1) {
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                 // the drain has left the buffer
         if (TAIL || WARMUP)
@@ -472,7 +474,7 @@ __device__ __forceinline__ bool k1t_tile(K1TLane<CL, C> &L, K1TUni &U, const K1A
     }
     if (kStoreAfter) {
         U.st = 0;
-        if (!WARMUP && U.nch == (uint32_t)C::CAP && C::DIAG != 3) { k1t_flush<CL, C>(L, U, qrow); U.st = 1; }
+        if (!WARMUP && U.nch == (uint32_t)C::CAP && C::DIAG != 3 && !held) { k1t_flush<CL, C>(L, U, qrow); U.st = 1; }
     }
     if constexpr (C::PRIO == 5) __builtin_amdgcn_s_setprio(0);
     if constexpr ((C::PRIO >= 2 && C::PRIO <= 4) || C::PRIO == 6 || C::PRIO >= 10) {
@@ -574,6 +576,7 @@ __device__ __forceinline__ void k1t_body(const K1Args &a)
     K1TUni U;
     U.ntiles = (G::HBA / 2 + a.block_size) / 64;
     U.t = 0; U.wi = 0; U.nch = 0; U.wdone = 0; U.st = 0;
+    U.hold_last = SRCH > 0 ? 1u : 0u;
     U.odd = C::PRIO ? (__builtin_amdgcn_s_getreg(4 | (3 << 11)) & 1u) : 0u;   // HW_REG_HW_ID, wave_id: slot of this wave in its SIMD
     if (C::PRIO && U.odd) __builtin_amdgcn_s_setprio(1);
 
@@ -613,16 +616,22 @@ __device__ __forceinline__ void k1t_body(const K1Args &a)
     while (!k1t_super<CL, TAIL, C, 0>(L, U, a, sb, wg, lane, rdv, voff_e, voff_o, vt_e, vt_o, rows_valid, qrow)) {}
     if (C::DIAG == 3) U.nch = 0;
     if constexpr (SRCH > 0) {
-        // the lane's row, whole: rows of 16 words are four chunks, all of them parked in LDS (NLC >= 4) and about to be stored
-        constexpr int WPB = 16;
-        static_assert(C::NLC >= WPB / 4 && !TAIL, "in-wave search: the row's chunks must all be parked");
-        if (a.block_size == 32u * WPB && U.nch == (uint32_t)(WPB / 4)) {          // (wave-uniform; anything else: the launcher's mistake)
+        // the lane's row, whole and still on the chip: rows of 16 words (chip 8) are four chunks parked in LDS; rows of 64 words
+        // (chip 32, 40) are exactly one burst -- 11 chunks parked, 4 in the register vector, the last in the staging registers --
+        // which the last tile boundary held back (K1TUni::hold_last)
+        constexpr int WPB = CL == 8 ? 16 : 64, CPR = WPB / 4;
+        static_assert(!TAIL && (CPR <= C::NLC || CPR == C::CAP), "in-wave search: the whole row must be buffered when the block ends");
+        if (a.block_size == 32u * WPB && U.nch == (uint32_t)CPR) {                // (wave-uniform; anything else: the launcher's mistake)
             typedef const __attribute__((address_space(3))) k2w_v4u *lds_v4;
-            K2WRing<WPB / 4> R;
+            K2WRing<CPR> R;
 #pragma unroll
-            for (int c = 0; c < WPB / 4; ++c) R.c[c] = *(lds_v4)(uintptr_t)(C::kPark + c * 1024 + lane * 16);
+            for (int c = 0; c < CPR; ++c) {
+                if (c < C::NLC) R.c[c] = *(lds_v4)(uintptr_t)(C::kPark + c * 1024 + lane * 16);
+                else if (c < C::CAP - 1) R.c[c] = k2w_v4u{L.ow[(c - C::NLC) * 4], L.ow[(c - C::NLC) * 4 + 1], L.ow[(c - C::NLC) * 4 + 2], L.ow[(c - C::NLC) * 4 + 3]};
+                else R.c[c] = k2w_v4u{L.st4.x, L.st4.y, L.st4.z, L.st4.w};
+            }
             // scratch: the tile buffer at LDS offset 0, which no DMA targets any more
-            k1s_search_tile<2 * CL, SRCH - 1, WPB>(a.srch, wg + 1, lane, R, reinterpret_cast<uint32_t *>(k1t_lds), 9u);
+            k1s_search_tile<2 * CL, SRCH - 1, WPB>(a.srch, wg + 1, lane, R, reinterpret_cast<uint32_t *>(k1t_lds), WPB == 16 ? 9u : 11u);
         }
     }
     if (U.nch) k1t_flush<CL, C>(L, U, qrow);

@@ -152,6 +152,19 @@ def test_in_wave_search_at_chip_8_equals_oracle(protos, per, n, env):
     assert "in-wave-searches" not in off["describe"]
 
 
+@pytest.mark.parametrize("chip", [32, 40])
+def test_in_wave_search_at_rows_of_64_words_equals_oracle(chip):
+    """AMR_INWAVE=2 (an experiment that lost on speed, profiles/r06/inwave/: off by default): at chip 32 / 40 a row of 64 words
+    is exactly the burst the last tile boundary completes; K1 holds it back, searches it and stores it.  Same hits as the
+    oracle's, and the path must really have run."""
+    protos, per, n = ["scm"], 256, 7
+    want = oracle_digest(protos, chip, per, n)
+    assert want["n_hits"] > 0
+    got = probe(protos, chip, per, n, env={"AMR_K1_COOP_MAX": "0", "AMR_INWAVE": "2"})
+    assert {k: got[k] for k in want} == want
+    assert "in-wave-searches" in got["describe"]
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("protos,depth", [(["r900"], 3), (["scm", "r900"], 3), (["r900"], 2)])
 def test_pipelined_r900_searches_every_batch_once(protos, depth):
