@@ -52,6 +52,32 @@ def test_hip_equals_translated_reference(protos, chip, n_blocks, batches):
         dec.close()
 
 
+@pytest.mark.parametrize("protos,chip,n_blocks,batches", [
+    (["scm"], 8, 704, [256, 448]),        # halo-shift K1 + the in-wave search + k2_row_cleanup (k1_search.h)
+    (["scm"], 32, 256, None),             # halo-shift K1, rows of 64 words
+    (["scm"], 40, 320, [64, 256]),        # two halo tiles; the all-XCD announcement is scheduling only
+    (["scm"], 72, 192, [128, 64]),
+])
+def test_tile_kernels_equal_translated_reference(protos, chip, n_blocks, batches, monkeypatch):
+    """The same comparison with the whole-wave-tile K1 kernels at test size (AMR_K1_COOP_MAX=0, read at amr_create: by default
+    batches this small run one wave per block): round 6's halo shift and in-wave search straight against the translated Go."""
+    monkeypatch.setenv("AMR_K1_COOP_MAX", "0")
+    dec = util.make_decoder(protos, chip)
+    try:
+        iq, _ = util.synth_stream(protos, chip, n_blocks, dec.Cfg.BlockSize, seed=77 + chip, n_packets=6, edge_every=2)
+        a = iq.size // 3
+        iq[a:a + 40_000] = np.random.default_rng(chip).integers(0, 256, 40_000, dtype=np.uint8)
+        _, q, h, p, _ = ref_run(protos, chip, iq)
+        gq, gh, gp = util.gpu_run(dec, iq, batches)
+        assert np.array_equal(q, gq), "quantized bitstream differs from the translated reference"
+        assert h.shape == gh.shape and np.array_equal(h, gh), "hit lists differ from the translated literal Search"
+        assert np.array_equal(p, gp), "packet bytes differ from the translated Slice"
+        assert len(h) > 20
+        assert ("in-wave-searches" in dec.describe()) == (chip == 8)
+    finally:
+        dec.close()
+
+
 def test_capture_through_hip_equals_translated_reference():
     raw = util.load_capture()
     for protos, chip in ((["scm"], 72), (["scm"], 80), (["idm"], 72)):
